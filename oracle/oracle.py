@@ -1,0 +1,216 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class OrcOptions(C.Structure):
+    # src/options.jl:1-15
+    _fields_ = [
+        ("line_search", C.c_int), ("max_iterations", C.c_int), ("max_dual_updates", C.c_int),
+        ("min_step_size", C.c_double), ("objective_tolerance", C.c_double),
+        ("lagrangian_gradient_tolerance", C.c_double), ("constraint_tolerance", C.c_double),
+        ("constraint_norm", C.c_double), ("initial_constraint_penalty", C.c_double),
+        ("scaling_penalty", C.c_double), ("max_penalty", C.c_double),
+        ("reset_cache", C.c_int), ("verbose", C.c_int),
+    ]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [
+        ("objective", C.c_double), ("gradient_norm", C.c_double), ("max_violation", C.c_double),
+        ("step_size", C.c_double), ("iterations", C.c_int), ("outer_iterations", C.c_int),
+        ("status", C.c_int), ("potrf_info", C.c_int), ("rollouts", C.c_int),
+    ]
+
+
+class OrcTrace(C.Structure):
+    _fields_ = [
+        ("outer", C.c_int), ("inner", C.c_int), ("objective", C.c_double),
+        ("gradient_norm", C.c_double), ("max_violation", C.c_double), ("step_size", C.c_double),
+        ("status", C.c_int),
+    ]
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [
+        ("T", C.c_int), ("nx", C.c_int), ("nu", C.c_int), ("nw", C.c_int),
+        ("dynamics", C.c_void_p), ("costs", C.c_void_p), ("constraints", C.c_void_p),
+        ("owner", C.c_void_p),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ilqr_oracle.cpp", "models.cpp", "ilqr_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_default_options.argtypes = [C.POINTER(OrcOptions)]
+        L.orc_problem_builtin.argtypes = [C.c_char_p, C.c_int, C.POINTER(OrcProblem)]
+        L.orc_problem_builtin.restype = C.c_int
+        L.orc_problem_free.argtypes = [C.POINTER(OrcProblem)]
+        L.orc_solver_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p, C.POINTER(OrcOptions)]
+        L.orc_solver_create.restype = C.c_void_p
+        L.orc_solver_destroy.argtypes = [C.c_void_p]
+        L.orc_initialize_controls.argtypes = [C.c_void_p, c_double_p]
+        L.orc_initialize_states.argtypes = [C.c_void_p, c_double_p]
+        L.orc_rollout.argtypes = [C.c_int, C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]
+        for f in ("orc_solve", "orc_gradients", "orc_backward_pass", "orc_forward_pass", "orc_lagrangian_gradient",
+                  "orc_reset_model_objective", "orc_ilqr_solve", "orc_augmented_lagrangian_update"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = None
+        L.orc_cost_bang.argtypes = [C.c_void_p, C.c_int]
+        L.orc_cost_bang.restype = C.c_double
+        L.orc_rollout_bang.argtypes = [C.c_void_p, C.c_double]
+        L.orc_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.orc_buffer.restype = c_double_p
+        L.orc_get_stats.argtypes = [C.c_void_p, C.POINTER(OrcStats)]
+        L.orc_set_trace.argtypes = [C.c_void_p, C.POINTER(OrcTrace), C.c_int]
+        L.orc_trace_len.argtypes = [C.c_void_p]
+        L.orc_trace_len.restype = C.c_int
+        L.orc_solve_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(OrcOptions),
+                                      C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(OrcStats)]
+        L.orc_solve_batch.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def default_options(**kw):
+    o = OrcOptions()
+    lib().orc_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _p(a):
+    return a.ctypes.data_as(c_double_p) if a is not None else None
+
+
+class Problem:
+    """Built-in oracle problem (model zoo of oracle/models.cpp)."""
+
+    def __init__(self, name, T):
+        self.name, self.T = name, T
+        self.c = OrcProblem()
+        if lib().orc_problem_builtin(name.encode(), T, C.byref(self.c)) != 0:
+            raise ValueError("unknown oracle model %r" % name)
+        self.nx, self.nu = self.c.nx, self.c.nu
+
+    def rollout(self, x1, u):
+        """rollout(dynamics, x1, ū) — src/rollout.jl:33-42."""
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        x = np.zeros((self.T, self.nx))
+        lib().orc_rollout(self.T, self.c.dynamics, _p(x1), _p(u), None, _p(x))
+        return x
+
+    def __del__(self):
+        try:
+            lib().orc_problem_free(C.byref(self.c))
+        except Exception:
+            pass
+
+
+class Solver:
+    """Solver(dynamics, costs, constraints) of the oracle — src/solver.jl:28-46."""
+
+    def __init__(self, problem, options=None):
+        self.problem = problem
+        self.opt = options if options is not None else default_options()
+        self.h = lib().orc_solver_create(problem.T, problem.c.dynamics, problem.c.costs, problem.c.constraints,
+                                         None, C.byref(self.opt))
+        if not self.h:
+            raise RuntimeError("orc_solver_create failed")
+        self._trace = None
+
+    def initialize_controls(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        lib().orc_initialize_controls(self.h, _p(u))
+
+    def initialize_states(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lib().orc_initialize_states(self.h, _p(x))
+
+    def enable_trace(self, capacity=4096):
+        self._trace = (OrcTrace * capacity)()
+        lib().orc_set_trace(self.h, self._trace, capacity)
+
+    def trace(self):
+        n = lib().orc_trace_len(self.h)
+        return [self._trace[i] for i in range(n)]
+
+    def solve(self):
+        lib().orc_solve(self.h)
+
+    def call(self, name, *args):
+        return getattr(lib(), "orc_" + name)(self.h, *args)
+
+    def buffer(self, name):
+        n = C.c_int(0)
+        p = lib().orc_buffer(self.h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def set_buffer(self, name, values):
+        n = C.c_int(0)
+        p = lib().orc_buffer(self.h, name.encode(), C.byref(n))
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        assert v.size == n.value, (name, v.size, n.value)
+        np.ctypeslib.as_array(p, shape=(n.value,))[:] = v
+
+    def stats(self):
+        st = OrcStats()
+        lib().orc_get_stats(self.h, C.byref(st))
+        return st
+
+    def get_trajectory(self):
+        T, n, m = self.problem.T, self.problem.nx, self.problem.nu
+        return (self.buffer("nominal_states").reshape(T, n), self.buffer("nominal_actions").reshape(T - 1, m))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_solver_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def solve_batch(model, T, x1, ubar, options=None, nthreads=1, want_policy=True):
+    """CPU baseline / batch oracle: returns dict(x,u,K,k,stats)."""
+    pr = Problem(model, T)
+    n, m = pr.nx, pr.nu
+    x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, n)
+    B = x1.shape[0]
+    ubar = np.ascontiguousarray(ubar, dtype=np.float64).reshape(B, T - 1, m)
+    opt = options if options is not None else default_options()
+    x = np.zeros((B, T, n)); u = np.zeros((B, T - 1, m))
+    K = np.zeros((B, T - 1, n, m)) if want_policy else None   # column-major m×n per step → [n][m]
+    k = np.zeros((B, T - 1, m)) if want_policy else None
+    st = (OrcStats * B)()
+    rc = lib().orc_solve_batch(model.encode(), T, B, _p(x1), _p(ubar), C.byref(opt), nthreads,
+                               _p(x), _p(u), _p(K), _p(k), st)
+    if rc != 0:
+        raise RuntimeError("orc_solve_batch rc=%d" % rc)
+    stats = {f: np.array([getattr(s, f) for s in st]) for f, _ in OrcStats._fields_}
+    return dict(x=x, u=u, K=K, k=k, stats=stats)
