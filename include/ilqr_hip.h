@@ -1,0 +1,166 @@
+/*
+ * ilqr_hip.h — C-ABI of the MI355X-native batched iLQR / augmented-Lagrangian solver.
+ *
+ * The reference (thowell/IterativeLQR.jl v0.2.3, pure Julia) has no FFI layer;
+ * this header is the boundary a Julia `ccall` wrapper (or the Python ctypes
+ * mirror in iterativelqr.jl_amd/) binds to. Each entry point names the reference
+ * interface it replaces (paths relative to /root/reference). One handle owns a
+ * BATCH of independent problem instances of one model on one GPU; every
+ * instance behaves exactly like one reference `Solver`.
+ *
+ * Conventions: every function returns 0 on success, <0 on error (never
+ * throws); ilqr_last_error() gives the message. The caller owns all host
+ * pointers; the handle owns device memory. Host arrays are instance-major:
+ * x[b][t][i], u[b][t][j]; matrices are column-major like Julia
+ * (K[b][t][col][row]). All arithmetic is fp64 (the reference is Float64 only).
+ * A handle is not thread-safe. Calls that return data synchronise the stream.
+ */
+#ifndef ILQR_HIP_H
+#define ILQR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQR_OK 0
+#define ILQR_ERR_INVALID (-1)
+#define ILQR_ERR_HIP (-2)
+#define ILQR_ERR_MODEL (-3)
+#define ILQR_ERR_NO_DEVICE (-4)
+#define ILQR_ERR_LDS (-5)
+
+typedef struct ilqr_handle ilqr_handle;
+
+/* Options{T} — src/options.jl:1-15, field for field (constraint_norm is
+ * carried but, as in the reference, never read). line_search: 1 = :armijo,
+ * 0 = :none. verbose is accepted and ignored on the device path. */
+typedef struct {
+    int32_t line_search;
+    int32_t max_iterations;
+    int32_t max_dual_updates;
+    double min_step_size;
+    double objective_tolerance;
+    double lagrangian_gradient_tolerance;
+    double constraint_tolerance;
+    double constraint_norm;
+    double initial_constraint_penalty;
+    double scaling_penalty;
+    double max_penalty;
+    int32_t reset_cache;
+    int32_t verbose;
+} ilqr_options;
+
+/* What `Solver(dynamics, costs[, constraints])` needs — src/solver.jl:11-46. */
+typedef struct {
+    const char* model;          /* built-in model name ("acrobot", "car", ...) or the
+                                   name registered by a generated model library */
+    const char* model_library;  /* optional path of a generated model module (.so)
+                                   to dlopen first (iterativelqr.jl_amd/codegen.py) */
+    int32_t horizon;            /* T (number of states) */
+    int32_t batch;              /* B independent instances */
+    int32_t device;             /* HIP device ordinal */
+    int32_t constrained;        /* 1: Solver(dynamics, costs, constraints) → AL solve
+                                   0: Solver(dynamics, costs) → plain iLQR */
+} ilqr_problem_desc;
+
+/* SolverData scalars — src/data/solver.jl:4-18 — plus bookkeeping. */
+typedef struct {
+    double objective;
+    double gradient_norm;
+    double max_violation;
+    double step_size;
+    int32_t iterations;        /* data.iterations (inner iterations, all outer loops) */
+    int32_t outer_iterations;  /* AL iterations executed */
+    int32_t status;            /* data.status of the last forward pass */
+    int32_t potrf_info;        /* first non-zero LAPACK-style info of the Quu Cholesky
+                                  (the reference ignores it, src/backward_pass.jl:69) */
+    int32_t rollouts;          /* closed-loop rollouts executed */
+    int32_t reserved;
+} ilqr_stats;
+
+const char* ilqr_last_error(void);
+int ilqr_device_count(void);
+
+/* Options() defaults — src/options.jl:1-15 */
+int ilqr_default_options(ilqr_options* opt);
+
+/* Solver(...) — src/solver.jl:11-46. Fails loudly (ILQR_ERR_NO_DEVICE) when no
+ * HIP device is present: there is no CPU fallback. */
+int ilqr_create(const ilqr_problem_desc* desc, ilqr_handle** out);
+int ilqr_destroy(ilqr_handle* h);
+int ilqr_set_options(ilqr_handle* h, const ilqr_options* opt);   /* solver.options */
+int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw,
+                  int32_t* nc_stage, int32_t* nc_term, int32_t* horizon, int32_t* batch);
+
+/* Fresh-solver state (all buffers zero, objective = Inf) — what constructing a
+ * new reference Solver gives (src/data/problem.jl:32-38, src/data/solver.jl:37). */
+int ilqr_reset(ilqr_handle* h);
+
+/* initialize_controls!(solver, ū) / initialize_states!(solver, x̄) — src/solver.jl:56-66.
+ * Host pointers. */
+int ilqr_initialize_controls(ilqr_handle* h, const double* u);
+int ilqr_initialize_states(ilqr_handle* h, const double* x);
+/* x̄ = rollout(dynamics, x1, ū) (src/rollout.jl:33-42) followed by both
+ * initialisers, executed on the device. x1: [B][nx], u: [B][T-1][nu].
+ * The *_device variant takes DEVICE pointers (inputs already resident in HBM)
+ * and is asynchronous on the handle's stream. */
+int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u);
+int ilqr_initialize_rollout_device(ilqr_handle* h, const double* d_x1, const double* d_u);
+
+/* solve!(solver) — src/solve.jl:137-143. Asynchronous: enqueues the whole
+ * AL/iLQR solve of every instance on the handle's stream. */
+int ilqr_solve(ilqr_handle* h);
+int ilqr_synchronize(ilqr_handle* h);
+
+/* Stage-level entry points for parity tests (one kernel each, mode = :nominal):
+ * the reference functions they run are listed per id. */
+enum {
+    ILQR_STAGE_COST_NOMINAL = 0,   /* cost!(data, problem, mode=:nominal) — src/data/methods.jl:13-30 */
+    ILQR_STAGE_GRADIENTS = 1,      /* gradients!(problem)                 — src/gradients.jl:92-98   */
+    ILQR_STAGE_BACKWARD_PASS = 2,  /* backward_pass! + lagrangian_gradient! — src/backward_pass.jl, src/solve.jl:67-83 */
+    ILQR_STAGE_FORWARD_PASS = 3,   /* forward_pass!                       — src/forward_pass.jl:1-56 */
+    ILQR_STAGE_RESET_MODEL_OBJECTIVE = 4, /* reset!(model); reset!(objective) — src/solve.jl:9-10 */
+    ILQR_STAGE_ILQR_SOLVE = 5,     /* ilqr_solve!                         — src/solve.jl:1-54       */
+    ILQR_STAGE_AL_UPDATE = 6       /* augmented_lagrangian_update!        — src/augmented_lagrangian.jl:87-110 */
+};
+int ilqr_run_stage(ilqr_handle* h, int32_t stage);
+
+/* get_trajectory(solver) — src/solver.jl:48-50: nominal states [B][T][nx] and
+ * actions [B][T-1][nu]. */
+int ilqr_get_trajectory(ilqr_handle* h, double* x, double* u);
+/* solver.policy.K / .k — src/data/policy.jl:25-26. K: [B][T-1][nx][nu] (column-major nu×nx). */
+int ilqr_get_policy(ilqr_handle* h, double* K, double* k);
+/* solver.data.* — one record per instance. */
+int ilqr_get_stats(ilqr_handle* h, ilqr_stats* stats);
+
+/* Raw workspace access by reference field name (parity tests):
+ * "nominal_states","nominal_actions","states","actions","jacobian_state",
+ * "jacobian_action","gradient_state","gradient_action","hessian_state_state",
+ * "hessian_action_action","hessian_action_state","K","k","P","p",
+ * "gradient_state_lagrangian"(Qx−p),"gradient_action_lagrangian"(Qu),
+ * "violations","constraint_dual","constraint_penalty","active_set".
+ * Layout: [B][per-instance length]; ilqr_buffer_len gives the per-instance length. */
+int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len);
+int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out);
+int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in);
+
+/* Device-side handles for callers that time or chain work themselves. */
+int ilqr_get_stream(ilqr_handle* h, void** hip_stream);
+/* Average device time (ms) of the solve kernel over the ilqr_solve calls since
+ * the last ilqr_timing_reset, measured with HIP events on the handle's stream. */
+int ilqr_timing_reset(ilqr_handle* h);
+int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launches);
+
+/* Model registry (generated model modules call this from a static initialiser). */
+struct ilqr_model_vtable;
+int ilqr_register_model(const struct ilqr_model_vtable* vt);
+int ilqr_model_count(void);
+const char* ilqr_model_name(int32_t i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""ctypes binding of the C-ABI (include/ilqr_hip.h). No torch types cross it."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libilqr_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class Options(C.Structure):
+    """Options{T} — src/options.jl:1-15 (same field names and defaults)."""
+    _fields_ = [
+        ("line_search", C.c_int32), ("max_iterations", C.c_int32), ("max_dual_updates", C.c_int32),
+        ("min_step_size", C.c_double), ("objective_tolerance", C.c_double),
+        ("lagrangian_gradient_tolerance", C.c_double), ("constraint_tolerance", C.c_double),
+        ("constraint_norm", C.c_double), ("initial_constraint_penalty", C.c_double),
+        ("scaling_penalty", C.c_double), ("max_penalty", C.c_double),
+        ("reset_cache", C.c_int32), ("verbose", C.c_int32),
+    ]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [("model", C.c_char_p), ("model_library", C.c_char_p), ("horizon", C.c_int32),
+                ("batch", C.c_int32), ("device", C.c_int32), ("constrained", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("objective", C.c_double), ("gradient_norm", C.c_double), ("max_violation", C.c_double),
+                ("step_size", C.c_double), ("iterations", C.c_int32), ("outer_iterations", C.c_int32),
+                ("status", C.c_int32), ("potrf_info", C.c_int32), ("rollouts", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/ilqr_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ilqr_last_error": (C.c_char_p, []),
+    "ilqr_device_count": (C.c_int, []),
+    "ilqr_default_options": (C.c_int, [C.POINTER(Options)]),
+    "ilqr_create": (C.c_int, [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),
+    "ilqr_destroy": (C.c_int, [C.c_void_p]),
+    "ilqr_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
+    "ilqr_get_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 7),
+    "ilqr_reset": (C.c_int, [C.c_void_p]),
+    "ilqr_initialize_controls": (C.c_int, [C.c_void_p, c_double_p]),
+    "ilqr_initialize_states": (C.c_int, [C.c_void_p, c_double_p]),
+    "ilqr_initialize_rollout": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "ilqr_initialize_rollout_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ilqr_solve": (C.c_int, [C.c_void_p]),
+    "ilqr_synchronize": (C.c_int, [C.c_void_p]),
+    "ilqr_run_stage": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ilqr_get_trajectory": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "ilqr_get_policy": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "ilqr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "ilqr_buffer_len": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]),
+    "ilqr_get_buffer": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
+    "ilqr_set_buffer": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
+    "ilqr_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ilqr_timing_reset": (C.c_int, [C.c_void_p]),
+    "ilqr_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "ilqr_register_model": (C.c_int, [C.c_void_p]),
+    "ilqr_model_count": (C.c_int, []),
+    "ilqr_model_name": (C.c_char_p, [C.c_int32]),
+}
+
+STAGES = dict(cost_nominal=0, gradients=1, backward_pass=2, forward_pass=3, reset_model_objective=4,
+              ilqr_solve=5, al_update=6)
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s"]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    """Load libilqr_hip.so; the product path has no fallback if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP extension %s is not built; run __graft_entry__.build() "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class IlqrError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise IlqrError("ilqr error %d: %s" % (rc, lib().ilqr_last_error().decode()))

@@ -1,0 +1,197 @@
+"""Host-side mirror of IterativeLQR.jl's user API over the C-ABI.
+
+Names follow src/IterativeLQR.jl:30-45: Dynamics, Cost, Constraint (codegen.py),
+Solver, Options, initialize_controls!, initialize_states!, solve!, get_trajectory,
+rollout. Julia's `f!` becomes `f_`. One Solver here owns a BATCH of B independent
+instances; every array gains a leading batch axis.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _ffi, codegen
+from ._ffi import Options as _COptions
+
+
+def Options(**kw):
+    """Options(; kwargs...) — src/options.jl:1-15. line_search: "armijo" | "none"."""
+    o = _COptions()
+    _ffi.check(_ffi.lib().ilqr_default_options(C.byref(o)))
+    for k, v in kw.items():
+        if k == "line_search" and isinstance(v, str):
+            v = {"armijo": 1, "none": 0}[v]
+        if not hasattr(o, k):
+            raise TypeError("Options has no field %r" % k)
+        setattr(o, k, v)
+    return o
+
+
+def _p(a):
+    return a.ctypes.data_as(_ffi.c_double_p)
+
+
+def compile_model(name, dynamics, cost_stage, cost_term, con_stage=None, con_term=None):
+    """Symbolic model objects -> generated device code -> model module (.so), cached by source hash."""
+    sname, src = codegen.generate_model_source(name, dynamics, cost_stage, cost_term, con_stage, con_term)
+    tag = codegen.source_hash(src)
+    cache = os.path.join(_ffi.LIB_DIR, "models")
+    os.makedirs(cache, exist_ok=True)
+    so = os.path.join(cache, "libilqr_model_%s_%s.so" % (name, tag))
+    if not os.path.exists(so):
+        hip = os.path.join(cache, "model_%s_%s.hip" % (name, tag))
+        with open(hip, "w") as f:
+            f.write('#include "ilqr_device.hpp"\n' + src + "ILQR_DEFINE_MODEL(%s)\n" % sname)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-Wno-unused-parameter", "-I", _ffi.CSRC, hip, "-o", so,
+                               "-L", _ffi.LIB_DIR, "-lilqr_hip", "-Wl,-rpath," + _ffi.LIB_DIR])
+    return so
+
+
+class Solver:
+    """Solver(dynamics, costs[, constraints]; options) — src/solver.jl:11-46 — for a batch.
+
+    `dynamics` / `costs` / `constraints` are either lists of codegen objects laid
+    out like the reference's (T-1 dynamics, T costs, T constraints; stage objects
+    identical, terminal object last) or omitted when `model` names a built-in.
+    """
+
+    def __init__(self, dynamics=None, costs=None, constraints=None, *, model=None, horizon=None, batch=1,
+                 options=None, device=0, name="user"):
+        L = _ffi.lib()
+        model_library = None
+        if model is None:
+            T = len(costs)
+            assert len(dynamics) == T - 1, "need T-1 dynamics and T costs"          # src/data/problem.jl:30
+            assert all(d is dynamics[0] for d in dynamics), "time-varying dynamics are not supported yet"
+            assert all(c is costs[0] for c in costs[:-1]), "stage costs must be one shared object"
+            cs = ct = None
+            if constraints is not None:
+                assert len(constraints) == T
+                assert all(c is constraints[0] for c in constraints[:-1]), "stage constraints must be one shared object"
+                cs, ct = constraints[0], constraints[-1]
+            model_library = compile_model(name, dynamics[0], costs[0], costs[-1], cs, ct)
+            model, horizon = name, T
+            constrained = constraints is not None
+        else:
+            constrained = True if constraints is None else bool(constraints)
+        self.model, self.T, self.B = model, int(horizon), int(batch)
+        desc = _ffi.ProblemDesc(model.encode(), model_library.encode() if model_library else None,
+                                self.T, self.B, device, 1 if constrained else 0)
+        h = C.c_void_p()
+        _ffi.check(L.ilqr_create(C.byref(desc), C.byref(h)))
+        self._h = h
+        d = [C.c_int32() for _ in range(7)]
+        _ffi.check(L.ilqr_get_dims(self._h, *[C.byref(v) for v in d]))
+        self.nx, self.nu, self.nw, self.nc_stage, self.nc_term = [v.value for v in d[:5]]
+        self.options = options if options is not None else Options()
+        _ffi.check(L.ilqr_set_options(self._h, C.byref(self.options)))
+
+    # -- src/solver.jl:56-66
+    def initialize_controls_(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.B, self.T - 1, self.nu)
+        _ffi.check(_ffi.lib().ilqr_initialize_controls(self._h, _p(u)))
+
+    def initialize_states_(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.B, self.T, self.nx)
+        _ffi.check(_ffi.lib().ilqr_initialize_states(self._h, _p(x)))
+
+    def initialize_rollout_(self, x1, u):
+        """x̄ = rollout(dynamics, x1, ū); initialize_controls!; initialize_states! on the device."""
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(self.B, self.nx)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.B, self.T - 1, self.nu)
+        _ffi.check(_ffi.lib().ilqr_initialize_rollout(self._h, _p(x1), _p(u)))
+
+    def initialize_rollout_device_(self, d_x1_ptr, d_u_ptr):
+        _ffi.check(_ffi.lib().ilqr_initialize_rollout_device(self._h, C.c_void_p(d_x1_ptr), C.c_void_p(d_u_ptr)))
+
+    def reset_(self):
+        _ffi.check(_ffi.lib().ilqr_reset(self._h))
+
+    # -- src/solve.jl:137-143
+    def solve_(self, sync=True):
+        _ffi.check(_ffi.lib().ilqr_set_options(self._h, C.byref(self.options)))
+        _ffi.check(_ffi.lib().ilqr_solve(self._h))
+        if sync:
+            self.synchronize()
+
+    def synchronize(self):
+        _ffi.check(_ffi.lib().ilqr_synchronize(self._h))
+
+    def run_stage_(self, stage):
+        _ffi.check(_ffi.lib().ilqr_set_options(self._h, C.byref(self.options)))
+        _ffi.check(_ffi.lib().ilqr_run_stage(self._h, _ffi.STAGES[stage]))
+
+    # -- src/solver.jl:48-50
+    def get_trajectory(self):
+        x = np.empty((self.B, self.T, self.nx)); u = np.empty((self.B, self.T - 1, self.nu))
+        _ffi.check(_ffi.lib().ilqr_get_trajectory(self._h, _p(x), _p(u)))
+        return x, u
+
+    def get_policy(self):
+        """(K, k): K[b, t] is the nu×nx gain as a [nx][nu] column-major block."""
+        K = np.empty((self.B, self.T - 1, self.nx, self.nu)); k = np.empty((self.B, self.T - 1, self.nu))
+        _ffi.check(_ffi.lib().ilqr_get_policy(self._h, _p(K), _p(k)))
+        return K, k
+
+    def stats(self):
+        st = (_ffi.Stats * self.B)()
+        _ffi.check(_ffi.lib().ilqr_get_stats(self._h, st))
+        return {f: np.array([getattr(s, f) for s in st]) for f, _ in _ffi.Stats._fields_ if f != "reserved"}
+
+    def buffer(self, name):
+        n = C.c_size_t(0)
+        _ffi.check(_ffi.lib().ilqr_buffer_len(self._h, name.encode(), C.byref(n)))
+        out = np.empty((self.B, n.value))
+        if n.value:
+            _ffi.check(_ffi.lib().ilqr_get_buffer(self._h, name.encode(), _p(out)))
+        return out
+
+    def set_buffer(self, name, values):
+        n = C.c_size_t(0)
+        _ffi.check(_ffi.lib().ilqr_buffer_len(self._h, name.encode(), C.byref(n)))
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(self.B, n.value)
+        if n.value:
+            _ffi.check(_ffi.lib().ilqr_set_buffer(self._h, name.encode(), _p(v)))
+
+    def timing(self):
+        ms = C.c_double(0); nl = C.c_int32(0)
+        _ffi.check(_ffi.lib().ilqr_timing_get(self._h, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    def timing_reset(self):
+        _ffi.check(_ffi.lib().ilqr_timing_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().ilqr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# free-function spellings of the reference's exports (src/IterativeLQR.jl:40-45)
+def initialize_controls_(solver, u):
+    solver.initialize_controls_(u)
+
+
+def initialize_states_(solver, x):
+    solver.initialize_states_(x)
+
+
+def solve_(solver, *args):
+    """solve!(solver[, states, actions]) — src/solve.jl:56-60,131-135."""
+    if args:
+        states, actions = args
+        solver.initialize_controls_(actions)
+        solver.initialize_states_(states)
+    solver.solve_()
+
+
+def get_trajectory(solver):
+    return solver.get_trajectory()

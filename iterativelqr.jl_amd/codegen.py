@@ -1,0 +1,262 @@
+"""Model code generation: user function on symbols -> derivatives -> HIP device code.
+
+This is the MI355X-side twin of the reference's Symbolics pipeline
+(src/dynamics.jl:16-34, src/costs.jl:17-44, src/constraints.jl:17-43): the user
+function is traced on symbolic vectors, Jacobians / gradients / Hessians are
+derived symbolically, and instead of `eval(build_function(...))` producing a
+Julia closure, a C++ struct of `__device__` functions is emitted that the
+solve kernels (csrc/ilqr_device.hpp) are instantiated with.
+"""
+import hashlib
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+from sympy.printing.precedence import PRECEDENCE
+
+
+def _variables(prefix, n):
+    return [sp.Symbol("%s%d" % (prefix, i), real=True) for i in range(n)]
+
+
+class _Traced:
+    def _trace(self, f, num_state, num_action, num_parameter):
+        self.num_state, self.num_action, self.num_parameter = num_state, num_action, num_parameter
+        self.x = _variables("x", num_state)
+        self.u = _variables("u", num_action)
+        self.w = _variables("w", num_parameter)
+        out = f(self.x, self.u, self.w) if num_parameter > 0 else f(self.x, self.u)   # src/dynamics.jl:23
+        return out
+
+
+def _as_list(y):
+    if isinstance(y, sp.MatrixBase):
+        return [sp.sympify(v) for v in y]
+    if isinstance(y, (list, tuple)):
+        return [sp.sympify(v) for v in y]
+    try:
+        import numpy as np
+        if isinstance(y, np.ndarray):
+            return [sp.sympify(v) for v in y.ravel().tolist()]
+    except ImportError:
+        pass
+    return [sp.sympify(y)]
+
+
+def _jac(exprs, vars_):
+    return [[sp.diff(e, v) for v in vars_] for e in exprs]   # [row][col]
+
+
+class Dynamics(_Traced):
+    """Dynamics(f, num_state, num_action; num_parameter=0) — src/dynamics.jl:16-34."""
+
+    def __init__(self, f, num_state, num_action, num_parameter=0):
+        self.evaluate = _as_list(self._trace(f, num_state, num_action, num_parameter))
+        self.num_next_state = len(self.evaluate)
+        self.jacobian_state = _jac(self.evaluate, self.x)
+        self.jacobian_action = _jac(self.evaluate, self.u)
+
+
+class Cost(_Traced):
+    """Cost(f, num_state, num_action; num_parameter=0) — src/costs.jl:17-44."""
+
+    def __init__(self, f, num_state, num_action, num_parameter=0):
+        ev = _as_list(self._trace(f, num_state, num_action, num_parameter))
+        assert len(ev) == 1, "cost must be scalar"
+        self.evaluate = ev[0]
+        self.gradient_state = [sp.diff(self.evaluate, v) for v in self.x]
+        self.gradient_action = [sp.diff(self.evaluate, v) for v in self.u]
+        self.hessian_state_state = _jac(self.gradient_state, self.x)
+        self.hessian_action_action = _jac(self.gradient_action, self.u)
+        self.hessian_action_state = _jac(self.gradient_action, self.x)
+
+
+class Constraint(_Traced):
+    """Constraint(f, num_state, num_action; indices_inequality, num_parameter) — src/constraints.jl:17-43.
+
+    `Constraint()` (no arguments) is the empty constraint of src/constraints.jl:45-52.
+    indices_inequality is 1-based like the reference.
+    """
+
+    def __init__(self, f=None, num_state=0, num_action=0, indices_inequality=(), num_parameter=0):
+        if f is None:
+            self.num_state = self.num_action = self.num_parameter = 0
+            self.x, self.u, self.w = [], [], []
+            self.evaluate, self.jacobian_state, self.jacobian_action = [], [], []
+            self.num_constraint = 0
+            self.indices_inequality = []
+            return
+        self.evaluate = _as_list(self._trace(f, num_state, num_action, num_parameter))
+        self.num_constraint = len(self.evaluate)
+        self.jacobian_state = _jac(self.evaluate, self.x)
+        self.jacobian_action = _jac(self.evaluate, self.u)
+        self.indices_inequality = [int(i) for i in indices_inequality]
+        assert all(1 <= i <= self.num_constraint for i in self.indices_inequality)
+
+
+# --------------------------------------------------------------------------- printing
+class _Printer(C99CodePrinter):
+    def _print_Float(self, expr):
+        return repr(float(expr))
+
+    def _print_Integer(self, expr):
+        return "%d.0" % int(expr)
+
+    def _print_Rational(self, expr):
+        return "(%d.0/%d.0)" % (expr.p, expr.q)
+
+    def _print_Pow(self, expr):
+        b, e = expr.base, expr.exp
+        if e.is_Integer and 2 <= int(e) <= 4:
+            s = self.parenthesize(b, PRECEDENCE["Mul"])
+            return "(" + "*".join([s] * int(e)) + ")"
+        if e == -1:
+            return "(1.0/%s)" % self.parenthesize(b, PRECEDENCE["Mul"])
+        if e.is_Integer and -4 <= int(e) <= -2:
+            s = self.parenthesize(b, PRECEDENCE["Mul"])
+            return "(1.0/(" + "*".join([s] * (-int(e))) + "))"
+        return super()._print_Pow(expr)
+
+
+_P = _Printer({"strict": False})
+
+
+def _emit_block(outputs, prefix):
+    """outputs: list of (lhs_string, expr). Returns C statements with CSE."""
+    exprs = [sp.sympify(e) for _, e in outputs]
+    syms = sp.numbered_symbols(prefix)
+    repl, red = sp.cse(exprs, symbols=syms, optimizations="basic") if exprs else ([], [])
+    lines = []
+    for s, e in repl:
+        lines.append("const double %s = %s;" % (s, _P.doprint(e)))
+    for (lhs, _), e in zip(outputs, red):
+        lines.append("%s = %s;" % (lhs, _P.doprint(e)))
+    return lines
+
+
+def _unpack(names_dims):
+    lines = []
+    for arr, syms in names_dims:
+        for i, s in enumerate(syms):
+            lines.append("const double %s = %s[%d];" % (s, arr, i))
+    return lines
+
+
+def _fn(ret, name, args, body):
+    out = ["    __device__ __forceinline__ static %s %s(%s) {" % (ret, name, ", ".join(args))]
+    out += ["        " + l for l in body]
+    out.append("    }")
+    return out
+
+
+def _arr(name, n, const=True):
+    return "%sdouble (&%s)[%d]" % ("const " if const else "", name, max(n, 1))
+
+
+def _used(lines, sym):
+    import re
+    pat = re.compile(r"\b%s\b" % sym)
+    return any(pat.search(l) for l in lines)
+
+
+def _prune_unpack(unpack, body):
+    """Drop unused `const double x3 = x[3];` lines (keeps -Wunused quiet)."""
+    keep = []
+    for l in unpack:
+        sym = l.split()[2]
+        if _used(body, sym):
+            keep.append(l)
+    return keep
+
+
+def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None, con_term=None):
+    """Return (struct_name, C++ source) of the device model struct.
+
+    dynamics: Dynamics; cost_stage/cost_term: Cost (terminal has num_action == 0);
+    con_stage/con_term: Constraint or None (= empty constraint).
+    Matrices are emitted column-major to match Julia / the C-ABI.
+    """
+    con_stage = con_stage if con_stage is not None else Constraint()
+    con_term = con_term if con_term is not None else Constraint()
+    n, m, nw = dynamics.num_state, dynamics.num_action, dynamics.num_parameter
+    assert dynamics.num_next_state == n, "time-uniform state dimension required"
+    assert cost_stage.num_state == n and cost_stage.num_action == m
+    assert cost_term.num_state == n and cost_term.num_action == 0
+    ncs, nct = con_stage.num_constraint, con_term.num_constraint
+    assert ncs <= 64 and nct <= 64
+    ineq_s = sum(1 << (i - 1) for i in con_stage.indices_inequality)
+    ineq_t = sum(1 << (i - 1) for i in con_term.indices_inequality)
+    sname = "Model_" + name
+    L = []
+    L.append("// GENERATED by iterativelqr.jl_amd/codegen.py — do not edit.")
+    L.append("// Device model functions (value + symbolic derivatives), column-major outputs.")
+    L.append("struct %s {" % sname)
+    L.append("    static constexpr int NX = %d, NU = %d, NW = %d, NCS = %d, NCT = %d;" % (n, m, nw, ncs, nct))
+    L.append("    static constexpr unsigned long long INEQ_S = 0x%xull, INEQ_T = 0x%xull;" % (ineq_s, ineq_t))
+    L.append('    static constexpr const char* NAME = "%s";' % name)
+
+    def rename(obj):
+        # every traced object has its own x*/u*/w* symbols with identical names, so no renaming needed
+        return obj
+
+    xs, us, ws = dynamics.x, dynamics.u, dynamics.w
+    sig_xu = [_arr("x", n), _arr("u", m), _arr("w", nw)]
+    sig_x = [_arr("x", n), _arr("w", nw)]
+
+    def unpack_xu(obj, with_u=True):
+        items = [("x", [str(s) for s in obj.x])]
+        if with_u:
+            items.append(("u", [str(s) for s in obj.u]))
+        items.append(("w", [str(s) for s in obj.w]))
+        return _unpack(items)
+
+    def add(ret, fname, sig, obj, outputs, with_u=True, ret_expr=None):
+        body = _emit_block(outputs + ([("const double ret_", ret_expr)] if ret_expr is not None else []), "t")
+        if ret_expr is not None:
+            body.append("return ret_;")
+        un = _prune_unpack(unpack_xu(obj, with_u), body)
+        L.extend(_fn(ret, fname, sig, un + body))
+
+    # dynamics
+    add("void", "dyn", sig_xu + [_arr("y", n, False)], dynamics,
+        [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)])
+    outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
+    outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
+    add("void", "dyn_jac", sig_xu + [_arr("fx", n * n, False), _arr("fu", n * m, False)], dynamics, outs)
+    # stage cost
+    add("double", "cost_s", sig_xu, cost_stage, [], ret_expr=cost_stage.evaluate)
+    outs = [("gx[%d]" % i, e) for i, e in enumerate(cost_stage.gradient_state)]
+    outs += [("gu[%d]" % i, e) for i, e in enumerate(cost_stage.gradient_action)]
+    add("void", "cost_s_grad", sig_xu + [_arr("gx", n, False), _arr("gu", m, False)], cost_stage, outs)
+    outs = [("gxx[%d]" % (j * n + i), cost_stage.hessian_state_state[i][j]) for j in range(n) for i in range(n)]
+    outs += [("guu[%d]" % (j * m + i), cost_stage.hessian_action_action[i][j]) for j in range(m) for i in range(m)]
+    outs += [("gux[%d]" % (j * m + i), cost_stage.hessian_action_state[i][j]) for j in range(n) for i in range(m)]
+    add("void", "cost_s_hess", sig_xu + [_arr("gxx", n * n, False), _arr("guu", m * m, False), _arr("gux", m * n, False)],
+        cost_stage, outs)
+    # terminal cost
+    add("double", "cost_t", sig_x, cost_term, [], with_u=False, ret_expr=cost_term.evaluate)
+    add("void", "cost_t_grad", sig_x + [_arr("gx", n, False)], cost_term,
+        [("gx[%d]" % i, e) for i, e in enumerate(cost_term.gradient_state)], with_u=False)
+    add("void", "cost_t_hess", sig_x + [_arr("gxx", n * n, False)], cost_term,
+        [("gxx[%d]" % (j * n + i), cost_term.hessian_state_state[i][j]) for j in range(n) for i in range(n)], with_u=False)
+    # constraints
+    if ncs > 0:
+        assert con_stage.num_state == n and con_stage.num_action == m
+    add("void", "con_s", sig_xu + [_arr("c", ncs, False)], con_stage if ncs else dynamics,
+        [("c[%d]" % i, e) for i, e in enumerate(con_stage.evaluate)])
+    outs = [("cx[%d]" % (j * ncs + i), con_stage.jacobian_state[i][j]) for j in range(n) for i in range(ncs)]
+    outs += [("cu[%d]" % (j * ncs + i), con_stage.jacobian_action[i][j]) for j in range(m) for i in range(ncs)]
+    add("void", "con_s_jac", sig_xu + [_arr("cx", ncs * n, False), _arr("cu", ncs * m, False)],
+        con_stage if ncs else dynamics, outs)
+    if nct > 0:
+        assert con_term.num_state == n
+    add("void", "con_t", sig_x + [_arr("c", nct, False)], con_term if nct else dynamics,
+        [("c[%d]" % i, e) for i, e in enumerate(con_term.evaluate)], with_u=False)
+    add("void", "con_t_jac", sig_x + [_arr("cx", nct * n, False)], con_term if nct else dynamics,
+        [("cx[%d]" % (j * nct + i), con_term.jacobian_state[i][j]) for j in range(n) for i in range(nct)], with_u=False)
+    L.append("};")
+    src = "\n".join(L) + "\n"
+    return sname, src
+
+
+def source_hash(src):
+    return hashlib.sha256(src.encode()).hexdigest()[:16]

@@ -1,0 +1,16 @@
+// Built-in model zoo: instantiates the solve kernels for each generated model
+// header (csrc/models/, produced by tools/gen_builtin_models.py) and registers
+// them with the library.
+#include "ilqr_device.hpp"
+
+#include "models/model_particle.h"
+#include "models/model_pendulum_euler.h"
+#include "models/model_acrobot.h"
+#include "models/model_car.h"
+#include "models/model_car_goal.h"
+
+ILQR_DEFINE_MODEL(Model_particle)
+ILQR_DEFINE_MODEL(Model_pendulum_euler)
+ILQR_DEFINE_MODEL(Model_acrobot)
+ILQR_DEFINE_MODEL(Model_car)
+ILQR_DEFINE_MODEL(Model_car_goal)

@@ -1,0 +1,390 @@
+// C-ABI implementation (include/ilqr_hip.h): handle management, HBM workspace,
+// kernel launches on a private HIP stream, host<->device accessors.
+// No CPU fallback: without a HIP device ilqr_create fails loudly.
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ilqr_device.hpp"
+
+namespace ilqr {
+// fresh-solver defaults after the workspace has been zero-filled:
+// objective = Inf, step_size = 1 (src/data/solver.jl:37-39), ρ = 1, a = 1
+// (src/augmented_lagrangian.jl:17-22).
+__global__ void defaults_kernel(KArgs a) {
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    const Layout& L = a.L;
+    double* g = a.ws + (size_t)b * (size_t)L.stride;
+    for (int i = threadIdx.x; i < L.C; i += blockDim.x) { g[L.rho + i] = 1.0; g[L.act + i] = 1.0; }
+    if (threadIdx.x == 0) {
+        g[L.scal + S_OBJECTIVE] = __builtin_huge_val();
+        g[L.scal + S_STEP_SIZE] = 1.0;
+    }
+}
+
+}  // namespace ilqr
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ILQR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+std::vector<const ilqr_model_vtable*>& registry() {
+    static std::vector<const ilqr_model_vtable*> r;
+    return r;
+}
+
+const ilqr_model_vtable* find_model(const char* name) {
+    for (auto* vt : registry())
+        if (!std::strcmp(vt->name, name)) return vt;
+    return nullptr;
+}
+
+struct BufferDesc { const char* name; int offset; int len; };
+
+}  // namespace
+
+struct ilqr_handle {
+    const ilqr_model_vtable* vt;
+    ilqr::Layout L;
+    int B, device, constrained;
+    ilqr_options opt;
+    double* ws;
+    size_t ws_bytes, lds_bytes;
+    hipStream_t stream;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
+    double* d_x1;
+    double* d_u;   // staging for host-pointer initialize_rollout
+    std::vector<BufferDesc> buffers;
+};
+
+namespace {
+
+ilqr::KArgs make_args(const ilqr_handle* h) {
+    ilqr::KArgs a;
+    a.ws = h->ws; a.L = h->L; a.B = h->B; a.constrained = h->constrained; a.stage = 0; a.opt = h->opt;
+    a.x1 = nullptr; a.u_in = nullptr;
+    return a;
+}
+
+void fill_buffers(ilqr_handle* h) {
+    const ilqr::Layout& L = h->L;
+    const int T = L.T, N = T - 1, n = L.nx, m = L.nu;
+    h->buffers = {
+        {"nominal_states", L.xb, T * n}, {"nominal_actions", L.ub, N * m},
+        {"states", L.x, T * n}, {"actions", L.u, N * m},
+        {"jacobian_state", L.fx, N * n * n}, {"jacobian_action", L.fu, N * n * m},
+        {"gradient_state", L.gx, T * n}, {"gradient_action", L.gu, N * m},
+        {"hessian_state_state", L.gxx, T * n * n}, {"hessian_action_action", L.guu, N * m * m},
+        {"hessian_action_state", L.gux, N * m * n},
+        {"K", L.K, N * m * n}, {"k", L.k, N * m}, {"P", L.P, T * n * n}, {"p", L.p, T * n},
+        {"gradient_state_lagrangian", L.Lx, N * n}, {"gradient_action_lagrangian", L.Lu, N * m},
+        {"violations", L.c, L.C}, {"constraint_dual", L.lam, L.C},
+        {"constraint_penalty", L.rho, L.C}, {"active_set", L.act, L.C},
+        {"_scalars", L.scal, ilqr::S_COUNT},
+    };
+}
+
+const BufferDesc* find_buffer(const ilqr_handle* h, const char* name) {
+    for (auto& b : h->buffers)
+        if (!std::strcmp(b.name, name)) return &b;
+    return nullptr;
+}
+
+int copy_out(ilqr_handle* h, const BufferDesc* bd, double* out) {
+    if (bd->len == 0) return ILQR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy2D(out, (size_t)bd->len * 8, h->ws + bd->offset, (size_t)h->L.stride * 8,
+                        (size_t)bd->len * 8, (size_t)h->B, hipMemcpyDeviceToHost));
+    return ILQR_OK;
+}
+
+int copy_in(ilqr_handle* h, const BufferDesc* bd, const double* in) {
+    if (bd->len == 0) return ILQR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy2D(h->ws + bd->offset, (size_t)h->L.stride * 8, in, (size_t)bd->len * 8,
+                        (size_t)bd->len * 8, (size_t)h->B, hipMemcpyHostToDevice));
+    // any direct write may break states == nominal: drop the shortcut flag
+    std::vector<double> zeros(h->B, 0.0);
+    HIP_TRY(hipMemcpy2D(h->ws + h->L.scal + ilqr::S_STATES_EQ_NOMINAL, (size_t)h->L.stride * 8, zeros.data(), 8, 8,
+                        (size_t)h->B, hipMemcpyHostToDevice));
+    return ILQR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ilqr_last_error(void) { return g_err.c_str(); }
+
+int ilqr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ilqr_default_options(ilqr_options* o) {
+    if (!o) return fail(ILQR_ERR_INVALID, "null options");
+    // src/options.jl:1-15
+    o->line_search = 1; o->max_iterations = 100; o->max_dual_updates = 10;
+    o->min_step_size = 1.0e-5; o->objective_tolerance = 1.0e-3; o->lagrangian_gradient_tolerance = 1.0e-3;
+    o->constraint_tolerance = 5.0e-3; o->constraint_norm = INFINITY; o->initial_constraint_penalty = 1.0;
+    o->scaling_penalty = 10.0; o->max_penalty = 1.0e8; o->reset_cache = 0; o->verbose = 1;
+    return ILQR_OK;
+}
+
+int ilqr_register_model(const ilqr_model_vtable* vt) {
+    if (!vt || !vt->name) return ILQR_ERR_INVALID;
+    auto& r = registry();
+    for (auto& e : r)
+        if (!std::strcmp(e->name, vt->name)) { e = vt; return ILQR_OK; }
+    r.push_back(vt);
+    return ILQR_OK;
+}
+int ilqr_model_count(void) { return (int)registry().size(); }
+const char* ilqr_model_name(int32_t i) {
+    return (i >= 0 && i < (int)registry().size()) ? registry()[i]->name : nullptr;
+}
+
+int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
+    if (!d || !out || !d->model) return fail(ILQR_ERR_INVALID, "null descriptor/model");
+    if (d->horizon < 2 || d->batch < 1) return fail(ILQR_ERR_INVALID, "horizon must be >= 2 and batch >= 1");
+    if (d->model_library && d->model_library[0]) {
+        if (!dlopen(d->model_library, RTLD_NOW | RTLD_GLOBAL))
+            return fail(ILQR_ERR_MODEL, std::string("dlopen failed: ") + dlerror());
+    }
+    const ilqr_model_vtable* vt = find_model(d->model);
+    if (!vt) return fail(ILQR_ERR_MODEL, std::string("unknown model '") + d->model + "'");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(ILQR_ERR_NO_DEVICE, "no HIP device available: the batched solver has no CPU fallback");
+    if (d->device < 0 || d->device >= ndev) return fail(ILQR_ERR_INVALID, "device ordinal out of range");
+    ilqr_handle* h = new ilqr_handle();
+    h->vt = vt; h->B = d->batch; h->device = d->device; h->constrained = d->constrained ? 1 : 0;
+    h->L = ilqr::make_layout(vt->nx, vt->nu, vt->ncs, vt->nct, d->horizon);
+    h->lds_bytes = (size_t)h->L.lds_doubles * 8;
+    h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
+    ilqr_default_options(&h->opt);
+    fill_buffers(h);
+    if (h->lds_bytes > 160 * 1024) {
+        delete h;
+        return fail(ILQR_ERR_LDS, "per-instance working set exceeds the 160 KiB LDS of a gfx950 CU "
+                                  "(LDS-resident wave-per-instance kernel); reduce the horizon");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->ws_bytes = (size_t)h->B * (size_t)h->L.stride * 8;
+    HIP_TRY(hipMalloc((void**)&h->ws, h->ws_bytes));
+    *out = h;
+    int rc = ilqr_reset(h);
+    if (rc != ILQR_OK) { ilqr_destroy(h); *out = nullptr; return rc; }
+    return ILQR_OK;
+}
+
+int ilqr_destroy(ilqr_handle* h) {
+    if (!h) return ILQR_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto& p : h->timing) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (h->ws) hipFree(h->ws);
+    if (h->d_x1) hipFree(h->d_x1);
+    if (h->d_u) hipFree(h->d_u);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return ILQR_OK;
+}
+
+int ilqr_set_options(ilqr_handle* h, const ilqr_options* opt) {
+    if (!h || !opt) return fail(ILQR_ERR_INVALID, "null argument");
+    h->opt = *opt;
+    return ILQR_OK;
+}
+
+int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw, int32_t* ncs, int32_t* nct,
+                  int32_t* horizon, int32_t* batch) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (nx) *nx = h->vt->nx;
+    if (nu) *nu = h->vt->nu;
+    if (nw) *nw = h->vt->nw;
+    if (ncs) *ncs = h->vt->ncs;
+    if (nct) *nct = h->vt->nct;
+    if (horizon) *horizon = h->L.T;
+    if (batch) *batch = h->B;
+    return ILQR_OK;
+}
+
+int ilqr_reset(ilqr_handle* h) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
+    ilqr::KArgs a = make_args(h);
+    hipLaunchKernelGGL(ilqr::defaults_kernel, dim3(h->B), dim3(64), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return ILQR_OK;
+}
+
+int ilqr_initialize_controls(ilqr_handle* h, const double* u) {
+    if (!h || !u) return fail(ILQR_ERR_INVALID, "null argument");
+    return copy_in(h, find_buffer(h, "nominal_actions"), u);
+}
+int ilqr_initialize_states(ilqr_handle* h, const double* x) {
+    if (!h || !x) return fail(ILQR_ERR_INVALID, "null argument");
+    return copy_in(h, find_buffer(h, "nominal_states"), x);
+}
+
+int ilqr_initialize_rollout_device(ilqr_handle* h, const double* d_x1, const double* d_u) {
+    if (!h || !d_x1 || !d_u) return fail(ILQR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    ilqr::KArgs a = make_args(h);
+    a.x1 = d_x1; a.u_in = d_u;
+    if (h->vt->launch_init(&a, h->stream) != 0) return fail(ILQR_ERR_HIP, "init_rollout launch failed");
+    return ILQR_OK;
+}
+
+int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u) {
+    if (!h || !x1 || !u) return fail(ILQR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bx = (size_t)h->B * h->vt->nx * 8, bu = (size_t)h->B * (h->L.T - 1) * h->vt->nu * 8;
+    if (!h->d_x1) HIP_TRY(hipMalloc((void**)&h->d_x1, bx));
+    if (!h->d_u) HIP_TRY(hipMalloc((void**)&h->d_u, bu));
+    HIP_TRY(hipMemcpyAsync(h->d_x1, x1, bx, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_u, u, bu, hipMemcpyHostToDevice, h->stream));
+    int rc = ilqr_initialize_rollout_device(h, h->d_x1, h->d_u);
+    if (rc != ILQR_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
+    return ILQR_OK;
+}
+
+int ilqr_solve(ilqr_handle* h) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    ilqr::KArgs a = make_args(h);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "solve launch failed");
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    h->timing.emplace_back(e0, e1);
+    return ILQR_OK;
+}
+
+int ilqr_run_stage(ilqr_handle* h, int32_t stage) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    ilqr::KArgs a = make_args(h);
+    a.stage = stage;
+    if (h->vt->launch_stage(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "stage launch failed");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ILQR_OK;
+}
+
+int ilqr_synchronize(ilqr_handle* h) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ILQR_OK;
+}
+
+int ilqr_get_trajectory(ilqr_handle* h, double* x, double* u) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    int rc = ILQR_OK;
+    if (x) rc = copy_out(h, find_buffer(h, "nominal_states"), x);
+    if (rc == ILQR_OK && u) rc = copy_out(h, find_buffer(h, "nominal_actions"), u);
+    return rc;
+}
+
+int ilqr_get_policy(ilqr_handle* h, double* K, double* k) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    int rc = ILQR_OK;
+    if (K) rc = copy_out(h, find_buffer(h, "K"), K);
+    if (rc == ILQR_OK && k) rc = copy_out(h, find_buffer(h, "k"), k);
+    return rc;
+}
+
+int ilqr_get_stats(ilqr_handle* h, ilqr_stats* st) {
+    if (!h || !st) return fail(ILQR_ERR_INVALID, "null argument");
+    std::vector<double> s((size_t)h->B * ilqr::S_COUNT);
+    int rc = copy_out(h, find_buffer(h, "_scalars"), s.data());
+    if (rc != ILQR_OK) return rc;
+    for (int b = 0; b < h->B; ++b) {
+        const double* v = &s[(size_t)b * ilqr::S_COUNT];
+        st[b].objective = v[ilqr::S_OBJECTIVE]; st[b].gradient_norm = v[ilqr::S_GRADIENT_NORM];
+        st[b].max_violation = v[ilqr::S_MAX_VIOLATION]; st[b].step_size = v[ilqr::S_STEP_SIZE];
+        st[b].iterations = (int32_t)v[ilqr::S_ITERATIONS]; st[b].outer_iterations = (int32_t)v[ilqr::S_OUTER_ITERATIONS];
+        st[b].status = (int32_t)v[ilqr::S_STATUS]; st[b].potrf_info = (int32_t)v[ilqr::S_POTRF_INFO];
+        st[b].rollouts = (int32_t)v[ilqr::S_ROLLOUTS]; st[b].reserved = 0;
+    }
+    return ILQR_OK;
+}
+
+int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len) {
+    if (!h || !name || !len) return fail(ILQR_ERR_INVALID, "null argument");
+    const BufferDesc* bd = find_buffer(h, name);
+    if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
+    *len = (size_t)bd->len;
+    return ILQR_OK;
+}
+int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out) {
+    if (!h || !name || !out) return fail(ILQR_ERR_INVALID, "null argument");
+    const BufferDesc* bd = find_buffer(h, name);
+    if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
+    return copy_out(h, bd, out);
+}
+int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
+    if (!h || !name || !in) return fail(ILQR_ERR_INVALID, "null argument");
+    const BufferDesc* bd = find_buffer(h, name);
+    if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
+    return copy_in(h, bd, in);
+}
+
+int ilqr_get_stream(ilqr_handle* h, void** s) {
+    if (!h || !s) return fail(ILQR_ERR_INVALID, "null argument");
+    *s = (void*)h->stream;
+    return ILQR_OK;
+}
+
+int ilqr_timing_reset(ilqr_handle* h) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& p : h->timing) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    h->timing.clear();
+    return ILQR_OK;
+}
+
+int ilqr_timing_get(ilqr_handle* h, double* ms_avg, int32_t* launches) {
+    if (!h || !ms_avg) return fail(ILQR_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double total = 0.0;
+    for (auto& p : h->timing) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        total += ms;
+    }
+    *ms_avg = h->timing.empty() ? 0.0 : total / (double)h->timing.size();
+    if (launches) *launches = (int32_t)h->timing.size();
+    return ILQR_OK;
+}
+
+}  // extern "C"

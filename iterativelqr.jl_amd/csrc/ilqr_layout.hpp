@@ -1,0 +1,63 @@
+// Workspace layouts shared by host (C-ABI) and device (kernels).
+//
+// HBM workspace: instance-major — one contiguous block of `stride` doubles per
+// problem instance, so the wavefront that owns an instance streams contiguous,
+// fully-coalesced lines and instances never share a cache line. Within the
+// block every reference buffer (src/data/*.jl) is stored time-major with
+// column-major per-timestep matrices, i.e. exactly Julia's memory order.
+#pragma once
+
+namespace ilqr {
+
+// scalar slots (stored as doubles) at Layout::scal
+enum {
+    S_OBJECTIVE = 0, S_MAX_VIOLATION, S_STEP_SIZE, S_STATUS, S_ITERATIONS, S_GRADIENT_NORM,
+    S_OUTER_ITERATIONS, S_POTRF_INFO, S_ROLLOUTS, S_STATES_EQ_NOMINAL, S_COUNT = 16
+};
+
+struct Layout {
+    int T, nx, nu, ncs, nct;
+    int C;   // total number of constraints over the horizon
+    // offsets (in doubles) inside one instance block
+    int xb, ub, x, u, fx, fu, gx, gu, K, k, Lx, Lu, c, lam, rho, act;   // LDS-resident set
+    int lds_doubles;                                                    // size of that set
+    int gxx, guu, gux, P, p, scal;                                      // HBM-only set
+    int stride;
+};
+
+inline __host__ __device__ int pad2(int v) { return (v + 1) & ~1; }   // keep 16-B alignment
+
+inline __host__ __device__ Layout make_layout(int nx, int nu, int ncs, int nct, int T) {
+    Layout L;
+    const int N = T - 1;
+    L.T = T; L.nx = nx; L.nu = nu; L.ncs = ncs; L.nct = nct;
+    L.C = N * ncs + nct;
+    int o = 0;
+    L.xb = o; o += pad2(T * nx);
+    L.ub = o; o += pad2(N * nu);
+    L.x = o; o += pad2(T * nx);
+    L.u = o; o += pad2(N * nu);
+    L.fx = o; o += pad2(N * nx * nx);
+    L.fu = o; o += pad2(N * nx * nu);
+    L.gx = o; o += pad2(T * nx);
+    L.gu = o; o += pad2(N * nu);
+    L.K = o; o += pad2(N * nu * nx);
+    L.k = o; o += pad2(N * nu);
+    L.Lx = o; o += pad2(N * nx);
+    L.Lu = o; o += pad2(N * nu);
+    L.c = o; o += pad2(L.C);
+    L.lam = o; o += pad2(L.C);
+    L.rho = o; o += pad2(L.C);
+    L.act = o; o += pad2(L.C);
+    L.lds_doubles = o;
+    L.gxx = o; o += pad2(T * nx * nx);
+    L.guu = o; o += pad2(N * nu * nu);
+    L.gux = o; o += pad2(N * nu * nx);
+    L.P = o; o += pad2(T * nx * nx);
+    L.p = o; o += pad2(T * nx);
+    L.scal = o; o += S_COUNT;
+    L.stride = (o + 15) & ~15;   // 128-B aligned instance blocks
+    return L;
+}
+
+}  // namespace ilqr

@@ -1,0 +1,143 @@
+"""Built-in model zoo: the reference's example problems written the way a user
+of the reference writes them (plain functions of x, u on symbolic vectors).
+
+particle  examples/particle.jl:17-43      acrobot  test/acrobot.jl:9-101
+car       test/car.jl:10-61               pendulum test/dynamics.jl:8-19 (KAT)
+synth32   SURVEY.md §8(d) C5 (synthetic nx=32, nu=8 with action box)
+"""
+import math
+
+import sympy as sp
+
+from .codegen import Constraint, Cost, Dynamics, generate_model_source
+
+
+def _dot(a, b):
+    return sum(ai * bi for ai, bi in zip(a, b))
+
+
+# ---------------------------------------------------------------- particle
+def particle_discrete(x, u):
+    A = [[1.0, 1.0], [0.0, 1.0]]
+    Bm = [0.0, 1.0]
+    return [A[i][0] * x[0] + A[i][1] * x[1] + Bm[i] * u[0] for i in range(2)]
+
+
+def particle():
+    xT = [1.0, 0.0]
+    return dict(
+        dynamics=Dynamics(particle_discrete, 2, 1),
+        cost_stage=Cost(lambda x, u: 0.1 * _dot(x, x) + 0.1 * _dot(u, u), 2, 1),
+        cost_term=Cost(lambda x, u: 0.1 * _dot(x, x), 2, 0),
+        con_stage=Constraint(),
+        con_term=Constraint(lambda x, u: [x[i] - xT[i] for i in range(2)], 2, 0),
+    )
+
+
+# ---------------------------------------------------------------- pendulum (explicit Euler)
+def pendulum_euler_discrete(x, u):
+    mass, lc, gravity, damping, h = 1.0, 1.0, 9.81, 0.1, 0.1
+    f = [x[1], u[0] / (mass * lc * lc) - gravity * sp.sin(x[0]) / lc - damping * x[1] / (mass * lc * lc)]
+    return [x[i] + h * f[i] for i in range(2)]
+
+
+def pendulum_euler():
+    return dict(
+        dynamics=Dynamics(pendulum_euler_discrete, 2, 1),
+        cost_stage=Cost(lambda x, u: _dot(x, x) + 0.1 * _dot(u, u), 2, 1),
+        cost_term=Cost(lambda x, u: 10.0 * _dot(x, x), 2, 0),
+        con_stage=Constraint(), con_term=Constraint(),
+    )
+
+
+# ---------------------------------------------------------------- acrobot
+def acrobot_continuous(x, u):
+    mass1, inertia1, length1, lengthcom1 = 1.0, 0.33, 1.0, 0.5
+    mass2, inertia2, length2, lengthcom2 = 1.0, 0.33, 1.0, 0.5
+    gravity, friction1, friction2 = 9.81, 0.1, 0.1
+    q = x[0:2]
+    v = x[2:4]
+    a = inertia1 + inertia2 + mass2 * length1 * length1 + 2.0 * mass2 * length1 * lengthcom2 * sp.cos(q[1])
+    b = inertia2 + mass2 * length1 * lengthcom2 * sp.cos(q[1])
+    c = inertia2
+    det = a * c - b * b
+    Minv = [[c / det, -b / det], [-b / det, a / det]]
+    tau = [-1.0 * mass1 * gravity * lengthcom1 * sp.sin(q[0])
+           - mass2 * gravity * (length1 * sp.sin(q[0]) + lengthcom2 * sp.sin(q[0] + q[1])),
+           -1.0 * mass2 * gravity * lengthcom2 * sp.sin(q[0] + q[1])]
+    Cm = [[-2.0 * mass2 * length1 * lengthcom2 * sp.sin(x[1]) * x[3], -1.0 * mass2 * length1 * lengthcom2 * sp.sin(x[1]) * x[3]],
+          [mass2 * length1 * lengthcom2 * sp.sin(x[1]) * x[2], 0.0]]
+    Bv = [0.0, 1.0]
+    fr = [friction1, friction2]
+    rhs = [-1.0 * (Cm[i][0] * v[0] + Cm[i][1] * v[1]) + tau[i] + Bv[i] * u[0] - fr[i] * v[i] for i in range(2)]
+    qdd = [Minv[i][0] * rhs[0] + Minv[i][1] * rhs[1] for i in range(2)]
+    return [x[2], x[3], qdd[0], qdd[1]]
+
+
+def _midpoint(fc, n, h):
+    def f(x, u):
+        k1 = fc(x, u)
+        xm = [x[i] + 0.5 * h * k1[i] for i in range(n)]
+        k2 = fc(xm, u)
+        return [x[i] + h * k2[i] for i in range(n)]
+    return f
+
+
+def acrobot():
+    xT = [math.pi, 0.0, 0.0, 0.0]
+    return dict(
+        dynamics=Dynamics(_midpoint(acrobot_continuous, 4, 0.1), 4, 1),
+        cost_stage=Cost(lambda x, u: 0.1 * _dot(x[2:4], x[2:4]) + 0.1 * _dot(u, u), 4, 1),
+        cost_term=Cost(lambda x, u: 0.1 * _dot(x[2:4], x[2:4]), 4, 0),
+        con_stage=Constraint(),
+        con_term=Constraint(lambda x, u: [x[i] - xT[i] for i in range(4)], 4, 0),
+    )
+
+
+# ---------------------------------------------------------------- car
+def car_continuous(x, u):
+    return [u[0] * sp.cos(x[2]), u[0] * sp.sin(x[2]), u[1]]
+
+
+def car(goal_only=False):
+    xT = [1.0, 1.0, 0.0]
+    ul, uu = [-5.0, -5.0], [5.0, 5.0]
+    p_obs, r_obs = [0.5, 0.5], 0.1
+
+    def e(x):
+        return [x[0] - p_obs[0], x[1] - p_obs[1]]
+
+    def stage(x, u):
+        ee = e(x)
+        return [ul[0] - u[0], ul[1] - u[1], u[0] - uu[0], u[1] - uu[1], r_obs ** 2.0 - _dot(ee, ee)]
+
+    def term(x, u):
+        ee = e(x)
+        return [x[0] - xT[0], x[1] - xT[1], x[2] - xT[2], r_obs ** 2.0 - _dot(ee, ee)]
+
+    d = dict(
+        dynamics=Dynamics(_midpoint(car_continuous, 3, 0.1), 3, 2),
+        cost_stage=Cost(lambda x, u: 1.0 * _dot([x[i] - xT[i] for i in range(3)], [x[i] - xT[i] for i in range(3)])
+                        + 1.0e-2 * _dot(u, u), 3, 2),
+        cost_term=Cost(lambda x, u: 1000.0 * _dot([x[i] - xT[i] for i in range(3)], [x[i] - xT[i] for i in range(3)]), 3, 0),
+    )
+    if goal_only:
+        d["con_stage"] = Constraint()
+        d["con_term"] = Constraint(lambda x, u: [x[i] - xT[i] for i in range(3)], 3, 0)
+    else:
+        d["con_stage"] = Constraint(stage, 3, 2, indices_inequality=[1, 2, 3, 4, 5])
+        d["con_term"] = Constraint(term, 3, 0, indices_inequality=[4])
+    return d
+
+
+BUILTIN = {
+    "particle": particle,
+    "pendulum_euler": pendulum_euler,
+    "acrobot": acrobot,
+    "car": car,
+    "car_goal": lambda: car(goal_only=True),
+}
+
+
+def builtin_source(name):
+    return generate_model_source(name, **BUILTIN[name]())

@@ -1,0 +1,36 @@
+"""Deterministic synthetic inputs for the BASELINE.json configurations
+(SURVEY.md §8(d)); one generator feeds the GPU path, the oracle and the bench."""
+import numpy as np
+
+SEED = 20240607
+
+# name -> (model, T, constrained)
+CONFIGS = {
+    "particle": ("particle", 11, True),
+    "acrobot": ("acrobot", 101, True),
+    "acrobot51": ("acrobot", 51, True),
+    "car": ("car", 51, True),
+    "car_goal": ("car_goal", 51, True),
+}
+DIMS = {"particle": (2, 1), "acrobot": (4, 1), "car": (3, 2), "car_goal": (3, 2), "pendulum_euler": (2, 1)}
+
+
+def make_inputs(config, batch, seed=SEED, offset=0):
+    """Returns (model, T, x1[B,n], ubar[B,T-1,m]). `offset` shifts the instance
+    index so that shards of a larger batch draw disjoint, reproducible instances."""
+    model, T, _ = CONFIGS[config]
+    n, m = DIMS[model]
+    x1 = np.zeros((batch, n))
+    ub = np.zeros((batch, T - 1, m))
+    for b in range(batch):
+        rng = np.random.default_rng([seed, offset + b])
+        if model == "particle":
+            ub[b] = 0.1 * rng.standard_normal((T - 1, m))          # examples/particle.jl:30
+        elif model == "acrobot":
+            ub[b] = 1.0 * rng.standard_normal((T - 1, m))          # test/acrobot.jl:88
+        elif model in ("car", "car_goal"):
+            ub[b] = 1.0e-2 * np.array([1.0, 0.1])                  # test/car.jl:28
+            if offset + b > 0:
+                ub[b] *= 1.0 + 0.5 * rng.uniform(-1.0, 1.0)
+                x1[b, :2] = 0.05 * rng.standard_normal(2)
+    return model, T, x1, ub
