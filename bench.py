@@ -42,6 +42,18 @@ def algorithmic_bytes(n, m, T, C, iterations, rollouts):
     return 8.0 * (iterations * per_iter + extra * tr)
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,7 +146,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = host_cores()
         sample = min(B, 64 * threads)
         c0 = time.perf_counter()
         O.solve_batch(model, T, x1[:sample], ub[:sample], nthreads=threads, want_policy=False)

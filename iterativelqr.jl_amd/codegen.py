@@ -120,16 +120,119 @@ class _Printer(C99CodePrinter):
 _P = _Printer({"strict": False})
 
 
-def _emit_block(outputs, prefix):
-    """outputs: list of (lhs_string, expr). Returns C statements with CSE."""
+def _extract_trig(exprs):
+    """Replace every sin(a)/cos(a) by opaque symbols, innermost first, so that one fused
+    sincos per distinct argument can be emitted. Returns (exprs, defs) with
+    defs = [(arg_expr, s_sym, c_sym, need_s, need_c)] in dependency order."""
+    defs = []
+    exprs = list(exprs)
+    k = 0
+    rnd = 0
+    while True:
+        atoms = set()
+        for e in exprs + [d[0] for d in defs]:
+            atoms |= e.atoms(sp.sin, sp.cos)
+        inner = [a for a in atoms if not a.args[0].has(sp.sin, sp.cos)]
+        if not inner:
+            break
+        by_arg = {}
+        for a in inner:
+            by_arg.setdefault(a.args[0], set()).add(type(a))
+        rep = {}
+        for arg in sorted(by_arg, key=sp.default_sort_key):
+            s_sym, c_sym = sp.Symbol("sn%d" % k, real=True), sp.Symbol("cs%d" % k, real=True)
+            k += 1
+            kinds = by_arg[arg]
+            defs.append([arg, s_sym, c_sym, sp.sin in kinds, sp.cos in kinds, rnd])
+            rep[sp.sin(arg)] = s_sym
+            rep[sp.cos(arg)] = c_sym
+        exprs = [e.xreplace(rep) for e in exprs]
+        for d in defs:
+            d[0] = d[0].xreplace(rep)
+        rnd += 1
+    return exprs, defs
+
+
+def _emit_block(outputs, prefix, coop=False):
+    """outputs: list of (lhs_string, expr). Returns C statements: CSE temporaries, one
+    fused ilqr::sincos_fast per distinct trig argument, then the outputs, in dependency order.
+
+    coop=True emits the WAVE-COOPERATIVE form used on the serial rollout path: all lanes
+    hold the same values, so up to four trig arguments of one dependency level are
+    evaluated by a single sincos (lane&3 picks the argument) and handed back to every
+    lane with DPP quad broadcasts. Needs `const int ql = lane & 3;` in scope."""
     exprs = [sp.sympify(e) for _, e in outputs]
+    if not exprs:
+        return []
+    exprs, trig = _extract_trig(exprs)
+    nout = len(exprs)
     syms = sp.numbered_symbols(prefix)
-    repl, red = sp.cse(exprs, symbols=syms, optimizations="basic") if exprs else ([], [])
-    lines = []
+    repl, red = sp.cse(exprs + [d[0] for d in trig], symbols=syms, optimizations="basic")
+    # nodes: (defined symbols, expression, text emitter)
+    nodes = []
     for s, e in repl:
-        lines.append("const double %s = %s;" % (s, _P.doprint(e)))
-    for (lhs, _), e in zip(outputs, red):
-        lines.append("%s = %s;" % (lhs, _P.doprint(e)))
+        nodes.append(({s}, e, "const double %s = %s;" % (s, _P.doprint(e))))
+    trig_red = list(zip(trig, red[nout:]))
+    if coop:
+        rounds = {}
+        for d, e in trig_red:
+            rounds.setdefault(d[5], []).append((d, e))
+        batch_id = 0
+        for r in sorted(rounds):
+            items = rounds[r]
+            for b0 in range(0, len(items), 4):
+                chunk = items[b0:b0 + 4]
+                if len(chunk) == 1:
+                    continue   # a lone argument: plain (wave-uniform) sincos below
+                j = batch_id
+                batch_id += 1
+                txt = ["double ta%d = %s;" % (j, _P.doprint(chunk[0][1]))]
+                for qi, (_, e) in enumerate(chunk[1:], start=1):
+                    txt.append("ta%d = (ql == %d) ? (%s) : ta%d;" % (j, qi, _P.doprint(e), j))
+                txt.append("double ts%d, tc%d; ilqr::sincos_fast(ta%d, ts%d, tc%d);" % (j, j, j, j, j))
+                defined, dep = set(), sp.Tuple(*[e for _, e in chunk])
+                for qi, (d, _) in enumerate(chunk):
+                    _, s_sym, c_sym, need_s, need_c, _ = d
+                    if need_s:
+                        txt.append("const double %s = ilqr::quad_bcast<%d>(ts%d);" % (s_sym, qi, j))
+                    if need_c:
+                        txt.append("const double %s = ilqr::quad_bcast<%d>(tc%d);" % (c_sym, qi, j))
+                    defined |= {s_sym, c_sym}
+                    d.append("done")
+                nodes.append((defined, dep, "\n".join(txt)))
+    for d, e in trig_red:
+        if len(d) > 6:
+            continue
+        _, s_sym, c_sym, need_s, need_c = d[:5]
+        a = _P.doprint(e)
+        if need_s and need_c:
+            txt = "double %s, %s; ilqr::sincos_fast(%s, %s, %s);" % (s_sym, c_sym, a, s_sym, c_sym)
+        elif need_s:
+            txt = "const double %s = ilqr::sin_fast(%s);" % (s_sym, a)
+        else:
+            txt = "const double %s = ilqr::cos_fast(%s);" % (c_sym, a)
+        nodes.append(({s_sym, c_sym}, e, txt))
+    for (lhs, _), e in zip(outputs, red[:nout]):
+        nodes.append((set(), e, "%s = %s;" % (lhs, _P.doprint(e))))
+    defined_by = {}
+    for i, (ds, _, _) in enumerate(nodes):
+        for s in ds:
+            defined_by[s] = i
+    lines, done = [], set()
+
+    def visit(i):
+        if i in done:
+            return
+        done.add(i)
+        for s in sorted(nodes[i][1].free_symbols, key=str):
+            if s in defined_by and defined_by[s] != i:
+                visit(defined_by[s])
+        lines.extend(nodes[i][2].split("\n"))
+
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    for i in range(len(nodes)):
+        visit(i)
     return lines
 
 
@@ -209,16 +312,21 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         items.append(("w", [str(s) for s in obj.w]))
         return _unpack(items)
 
-    def add(ret, fname, sig, obj, outputs, with_u=True, ret_expr=None):
-        body = _emit_block(outputs + ([("const double ret_", ret_expr)] if ret_expr is not None else []), "t")
+    def add(ret, fname, sig, obj, outputs, with_u=True, ret_expr=None, coop=False):
+        body = _emit_block(outputs + ([("const double ret_", ret_expr)] if ret_expr is not None else []), "t", coop=coop)
         if ret_expr is not None:
             body.append("return ret_;")
         un = _prune_unpack(unpack_xu(obj, with_u), body)
+        if coop:
+            un = ["const int ql = lane & 3; (void)ql;"] + un
         L.extend(_fn(ret, fname, sig, un + body))
 
     # dynamics
     add("void", "dyn", sig_xu + [_arr("y", n, False)], dynamics,
         [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)])
+    # wave-cooperative variant for the serial closed-loop rollout (all lanes hold the same x, u)
+    add("void", "dyn_wave", ["const int lane"] + sig_xu + [_arr("y", n, False)], dynamics,
+        [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)], coop=True)
     outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
     outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
     add("void", "dyn_jac", sig_xu + [_arr("fx", n * n, False), _arr("fu", n * m, False)], dynamics, outs)

@@ -28,6 +28,7 @@
 
 #include "../../include/ilqr_hip.h"
 #include "ilqr_layout.hpp"
+#include "ilqr_math.hpp"
 
 namespace ilqr {
 
@@ -583,25 +584,48 @@ __device__ void rollout_bang(Inst<M>& I, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) I.x[i] = xt[i];
     }
+    // policy operands of step t are fetched from LDS one step ahead so that their
+    // latency hides under the previous step's dynamics chain
+    double Kn[m * n], kn[m], ubn[m], xbn[n];
+#pragma unroll
+    for (int i = 0; i < m * n; ++i) Kn[i] = I.K[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) { kn[i] = I.k[i]; ubn[i] = I.ub[i]; }
+#pragma unroll
+    for (int i = 0; i < n; ++i) xbn[i] = xt[i];
     for (int t = 0; t < I.N; ++t) {
+        double Kt[m * n], kt[m], ubt[m], xbt[n];
+#pragma unroll
+        for (int i = 0; i < m * n; ++i) Kt[i] = Kn[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) { kt[i] = kn[i]; ubt[i] = ubn[i]; }
+#pragma unroll
+        for (int i = 0; i < n; ++i) xbt[i] = xbn[i];
+        if (t + 1 < I.N) {
+#pragma unroll
+            for (int i = 0; i < m * n; ++i) Kn[i] = I.K[(t + 1) * m * n + i];
+#pragma unroll
+            for (int i = 0; i < m; ++i) { kn[i] = I.k[(t + 1) * m + i]; ubn[i] = I.ub[(t + 1) * m + i]; }
+#pragma unroll
+            for (int i = 0; i < n; ++i) xbn[i] = I.xb[(t + 1) * n + i];
+        }
         double ut[m];
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-            double v = I.k[t * m + i] * alpha;                        // (:24-25)
-            v += I.ub[t * m + i];                                     // (:26)
+            double v = kt[i] * alpha;                                 // (:24-25)
+            v += ubt[i];                                              // (:26)
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                const double Kij = I.K[t * m * n + j * m + i];
-                a1 += Kij * xt[j];
-                a2 += Kij * I.xb[t * n + j];
+                a1 += Kt[j * m + i] * xt[j];
+                a2 += Kt[j * m + i] * xbt[j];
             }
             v += a1;                                                  // (:27)
             v += -1.0 * a2;                                           // (:28)
             ut[i] = v;
         }
         double y[n];
-        M::dyn(xt, ut, w, y);                                         // (:29)
+        M::dyn_wave(I.lane, xt, ut, w, y);                            // (:29)
         if (I.lane == 0) {
 #pragma unroll
             for (int i = 0; i < m; ++i) I.u[t * m + i] = ut[i];

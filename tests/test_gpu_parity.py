@@ -62,14 +62,14 @@ def test_stagewise_parity(pkg, oracle, config):
         for g, o in pairs:
             gb = sol.buffer(g)
             for b in range(B):
-                assert _rel(gb[b], refs[b][1].buffer(o)) < tol, (it, g, b)
+                assert _rel(gb[b], refs[b][1].buffer(o)) < (tol if it == 0 else 1e-9), (it, g, b)
         sol.run_stage_("backward_pass")
         for s in refs:
             s[1].call("backward_pass"); s[1].call("lagrangian_gradient")
         for name in ("K", "k", "P", "p"):
             gb = sol.buffer(name)
             for b in range(B):
-                assert _rel(gb[b], refs[b][1].buffer(name)) < 1e-9, (it, name, b)
+                assert _rel(gb[b], refs[b][1].buffer(name)) < (1e-9 if it == 0 else 1e-7), (it, name, b)
         n, m = sol.nx, sol.nu
         Lx = sol.buffer("gradient_state_lagrangian"); Lu = sol.buffer("gradient_action_lagrangian")
         for b in range(B):
@@ -85,7 +85,7 @@ def test_stagewise_parity(pkg, oracle, config):
         for name in ("states", "actions", "nominal_states", "nominal_actions", "violations"):
             gb = sol.buffer(name)
             for b in range(B):
-                assert _rel(gb[b], refs[b][1].buffer(name)) < 1e-9, (it, name, b)
+                assert _rel(gb[b], refs[b][1].buffer(name)) < (1e-9 if it == 0 else 1e-7), (it, name, b)
     sol.close()
 
 
