@@ -60,6 +60,18 @@ __device__ __forceinline__ double nanmax(double a, double b) { return (b > a || 
 
 template <int N_> struct cdim { static constexpr int v = N_ > 0 ? N_ : 1; };
 
+// Optional per-phase cycle accounting (build with -DILQR_PROFILE): shader-clock
+// ticks (s_memtime) spent in each phase are accumulated per instance and written
+// to scalar slots S_PROF.. of the workspace (tools/phase_cycles.py prints them).
+#ifdef ILQR_PROFILE
+#define ILQR_PROF_BEGIN() const long long prof_t0_ = clock64()
+#define ILQR_PROF_END(I, slot) (I).prof[slot] += (double)(clock64() - prof_t0_)
+#else
+#define ILQR_PROF_BEGIN() do {} while (0)
+#define ILQR_PROF_END(I, slot) do {} while (0)
+#endif
+enum { PROF_COST = 0, PROF_GRAD, PROF_BACKWARD, PROF_DELTA, PROF_ROLLOUT, PROF_OTHER, PROF_N };
+
 // Per-instance context. LDS pointers first, then HBM pointers, then the
 // wave-uniform SolverData scalars (src/data/solver.jl:4-18) kept in registers.
 template <class M>
@@ -70,6 +82,9 @@ struct Inst {
     int T, N, C, lane;
     double objective, max_violation, step_size, gradient_norm;
     int status, iterations, outer_iterations, potrf_info, rollouts, states_eq_nominal;
+#ifdef ILQR_PROFILE
+    double prof[PROF_N];
+#endif
 };
 
 // ------------------------------------------------------------------ cost!
@@ -80,6 +95,7 @@ template <class M>
 __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd_J, bool upd_viol,
                           bool constrained, double& J_out, double& viol_out) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    ILQR_PROF_BEGIN();
     double Jp = 0.0, vp = 0.0;
     const double w[cdim<M::NW>::v] = {0.0};
     for (int t = I.lane; t < I.T; t += 64) {
@@ -156,6 +172,7 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
     J_out = wave_sum(Jp);
     viol_out = wave_max(vp);
     __syncthreads();
+    ILQR_PROF_END(I, PROF_COST);
 }
 
 // cost!(data, problem, mode) — src/data/methods.jl:13-30.
@@ -163,19 +180,17 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
 // (SURVEY Appendix A, Q2); when states == nominal bitwise one pass suffices.
 template <class M>
 __device__ void cost_bang(Inst<M>& I, bool mode_current, bool constrained) {
-    double J, v;
-    if (mode_current || I.states_eq_nominal) {
-        cost_pass<M>(I, mode_current ? I.x : I.xb, mode_current ? I.u : I.ub, true, true, constrained, J, v);
-        I.objective = J;
-        if (constrained) I.max_violation = v;
-    } else {
-        cost_pass<M>(I, I.xb, I.ub, true, false, constrained, J, v);
-        I.objective = J;
-        if (constrained) {
-            double J2;
-            cost_pass<M>(I, I.x, I.u, false, true, constrained, J2, v);
-            I.max_violation = v;
-        }
+    // one or two passes through a SINGLE instantiation of cost_pass (code size)
+    const bool one_pass = mode_current || I.states_eq_nominal || !constrained;
+    const int npass = one_pass ? 1 : 2;
+    for (int pass = 0; pass < npass; ++pass) {
+        const bool at_states = mode_current || pass == 1;
+        const bool upd_J = pass == 0;
+        const bool upd_viol = one_pass || pass == 1;
+        double J, v;
+        cost_pass<M>(I, at_states ? I.x : I.xb, at_states ? I.u : I.ub, upd_J, upd_viol, constrained, J, v);
+        if (upd_J) I.objective = J;
+        if (upd_viol && constrained) I.max_violation = v;
     }
 }
 
@@ -186,6 +201,7 @@ __device__ void cost_bang(Inst<M>& I, bool mode_current, bool constrained) {
 template <class M>
 __device__ void gradients(Inst<M>& I, bool constrained) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    ILQR_PROF_BEGIN();
     const double w[cdim<M::NW>::v] = {0.0};
     for (int t = I.lane; t < I.T; t += 64) {
         double xt[n];
@@ -317,6 +333,7 @@ __device__ void gradients(Inst<M>& I, bool constrained) {
         }
     }
     __syncthreads();
+    ILQR_PROF_END(I, PROF_GRAD);
 }
 
 // ------------------------------------------------ LAPACK potrf('U') / potrs('U')
@@ -367,7 +384,7 @@ __device__ __forceinline__ void potrs_U(const double (&U)[m * m], double (&B)[m 
 // Sequential Riccati recursion, wave-uniform, value function in registers.
 // Also produces the Lagrangian gradient (src/solve.jl:67-83) and its ∞-norm.
 template <class M, bool STORE_VALUE>
-__device__ void backward_pass(Inst<M>& I) {
+__device__ void backward_pass_valu(Inst<M>& I) {
     constexpr int n = M::NX, m = M::NU;
     const int N = I.N;
     double P[n * n], p[n];
@@ -570,12 +587,174 @@ __device__ void backward_pass(Inst<M>& I) {
     __syncthreads();
 }
 
+// ------------------------------------------------- backward_pass! on the matrix cores
+// For nx <= 4, nu <= 4 the whole Riccati step runs on v_mfma_f64_4x4x4 (4 blocks).
+// Measured on gfx950 (tools/probes/probe_mfma.hip): with one wave per SIMD a fp64
+// VALU instruction issues only every ~14 clk, a dependent 4x4x4 f64 MFMA every
+// 24-32 clk — one MFMA replaces ~16 DP FMAs plus the cross-lane traffic they need.
+// Lane layout of the instruction (decoded by the probe), block beta = (lane>>2)&3:
+//     A[i][k] at lane i + 4*beta + 16*k,  B[k][j] at lane j + 4*beta + 16*k,
+//     C/D[i][j] at lane j + 4*beta + 16*i.
+// Hence with every (zero-padded) 4x4 matrix X held as X(r,c) on lane c + 4*beta + 16*r,
+//     mfma(A<-X, B<-Y, C<-Z) = X^T * Y + Z   in the same layout,
+// and D feeds the next instruction's operands without any data movement.
+// Block 0 carries the recursion; block 1 is borrowed for the k column during the
+// triangular solves so that K and k share the (expensive) fp64 divisions.
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {   // uniform value from one lane
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+// Cross-block moves inside a 16-lane row. Written as volatile asm: hipcc sinks the
+// update_dpp builtin into the divergent arm of a following select, where the source
+// lanes are masked off and DPP then reads 0. The s_nop covers the VALU->DPP and
+// EXEC->DPP wait states that hipcc does not insert around inline asm.
+__device__ __forceinline__ double row_from_next_quad(double v) {   // lane l <- lane l+4 (row_shl:4)
+    int lo = __double2loint(v), hi = __double2hiint(v), olo, ohi;
+    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %2 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %1, %3 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
+                 : "=&v"(olo), "=&v"(ohi) : "v"(lo), "v"(hi));
+    return __hiloint2double(ohi, olo);
+}
+__device__ __forceinline__ double row_from_prev_quad(double v) {   // lane l <- lane l-4 (row_shr:4)
+    int lo = __double2loint(v), hi = __double2hiint(v), olo, ohi;
+    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %1, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
+                 : "=&v"(olo), "=&v"(ohi) : "v"(lo), "v"(hi));
+    return __hiloint2double(ohi, olo);
+}
+__device__ __forceinline__ double mfma444(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <class M, bool STORE_VALUE>
+__device__ void backward_pass_mfma(Inst<M>& I) {
+    constexpr int n = M::NX, m = M::NU;
+    static_assert(n <= 4 && m <= 4, "MFMA Riccati step handles nx, nu <= 4");
+    const int lane = I.lane, r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
+    const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n, vmm = r < m && c < m;
+    const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m;
+    // every lane loads from a clamped (always valid) address and zeroes the padding by
+    // select: no divergent branches around the operand loads
+    const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
+    const int o_nn = cn * n + rn, o_nm = cm * n + rn, o_mn = cn * m + rm, o_mm = cm * m + rm;
+    const int N = I.N;
+    double P = I.gxx[N * n * n + o_nn];                                // P[H] .= gxx[H]  (:39)
+    P = vnn ? P : 0.0;
+    double p = I.gx[N * n + rn];                                       // p[H] .= gx[H]   (:40)
+    p = vn1 ? p : 0.0;
+    if (STORE_VALUE && blk == 0) {
+        if (vnn) I.P[N * n * n + c * n + r] = P;
+        if (vn1) I.p[N * n + r] = p;
+    }
+    double gmax = 0.0;
+    // accumulated Hessians live in HBM/L2: prefetch one step ahead
+    const int tl = N > 0 ? N - 1 : 0;
+    double nxx = I.gxx[tl * n * n + o_nn], nuu = I.guu[tl * m * m + o_mm], nux = I.gux[tl * m * n + o_mn];
+    for (int t = N - 1; t >= 0; --t) {                                  // (:42)
+        const double gxx = vnn ? nxx : 0.0, guu = vmm ? nuu : 0.0, gux = vmn ? nux : 0.0;
+        {
+            const int tp = t > 0 ? t - 1 : 0;
+            nxx = I.gxx[tp * n * n + o_nn];
+            nuu = I.guu[tp * m * m + o_mm];
+            nux = I.gux[tp * m * n + o_mn];
+        }
+        double fx = I.fx[t * n * n + o_nn], fu = I.fu[t * n * m + o_nm], gx = I.gx[t * n + rn], gu = I.gu[t * m + rm];
+        fx = vnn ? fx : 0.0;
+        fu = vnm ? fu : 0.0;
+        gx = vn1 ? gx : 0.0;
+        gu = vm1 ? gu : 0.0;
+        // level 1: W = P'^T fx (= (fx^T P')^T), Wu = P'^T fu, Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49)
+        const double W = mfma444(P, fx, 0.0);
+        const double Wu = mfma444(P, fu, 0.0);
+        const double Qx = mfma444(fx, p, gx);
+        const double Qu = mfma444(fu, p, gu);
+        // level 2: Qxx = (fx^T P') fx + gxx, Qux = (fu^T P') fx + gux, Quu = (fu^T P') fu + guu   (:52-64)
+        const double Qxx = mfma444(W, fx, gxx);
+        const double Qux = mfma444(Wu, fx, gux);
+        const double Quu = mfma444(Wu, fu, guu);
+        // potrf('U') of Quu on wave-uniform scalars (upper triangle only, info ignored)   (:68-69)
+        double Uc[m * m];
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
+        const int info = potrf_U<m>(Uc);
+        if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
+        // potrs('U') for K (block 0: m x n) and k (block 1, column 0) at once   (:70-75)
+        const double Qu_b1 = row_from_prev_quad(Qu);                    // block 0 -> block 1
+        double Y = (blk == 1) ? Qu_b1 : Qux;
+#pragma unroll
+        for (int i = 0; i < m; ++i) {                                   // U^T y = b
+#pragma unroll
+            for (int l = 0; l < i; ++l) {
+                const double yl = __shfl(Y, lane - 16 * (i - l));
+                const double v = Y - Uc[i * m + l] * yl;
+                Y = (r == i) ? v : Y;
+            }
+            const double q = Y / Uc[i * m + i];
+            Y = (r == i) ? q : Y;
+        }
+#pragma unroll
+        for (int i = m - 1; i >= 0; --i) {                              // U x = y
+#pragma unroll
+            for (int l = i + 1; l < m; ++l) {
+                const double xl = __shfl(Y, lane + 16 * (l - i));
+                const double v = Y - Uc[l * m + i] * xl;
+                Y = (r == i) ? v : Y;
+            }
+            const double q = Y / Uc[i * m + i];
+            Y = (r == i) ? q : Y;
+        }
+        Y *= -1.0;                                                      // K .*= -1, k .*= -1
+        const double K = Y;                                             // valid in block 0
+        const double k = row_from_next_quad(Y);                         // block 1 -> block 0, column 0
+        // ux_tmp = Quu K   (:79)   (Quu^T K; Quu is symmetric up to rounding)
+        const double uxt = mfma444(Quu, K, 0.0);
+        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84)
+        double Pn = mfma444(K, uxt, 0.0);
+        Pn = mfma444(K, Qux, Pn);
+        Pn = mfma444(Qux, K, Pn);
+        Pn += Qxx;
+        // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89)
+        double pn = mfma444(uxt, k, 0.0);
+        pn = mfma444(K, Qu, pn);
+        pn = mfma444(Qux, k, pn);
+        pn += Qx;
+        // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81)
+        const double Lx = Qx - pn;
+        if (blk == 0) {
+            if (vn1) { gmax = nanmax(gmax, fabs(Lx)); I.Lx[t * n + r] = Lx; }
+            if (vm1) { gmax = nanmax(gmax, fabs(Qu)); I.Lu[t * m + r] = Qu; I.k[t * m + r] = k; }
+            if (vmn) I.K[t * m * n + c * m + r] = K;
+            if (STORE_VALUE) {
+                if (vnn) I.P[t * n * n + c * n + r] = Pn;
+                if (vn1) I.p[t * n + r] = pn;
+            }
+        }
+        P = Pn;
+        p = pn;
+    }
+    I.gradient_norm = wave_max(gmax);
+    __syncthreads();
+}
+
+template <class M, bool STORE_VALUE>
+__device__ __forceinline__ void backward_pass(Inst<M>& I) {
+    ILQR_PROF_BEGIN();
+    if constexpr (M::NX <= 4 && M::NU <= 4) backward_pass_mfma<M, STORE_VALUE>(I);
+    else backward_pass_valu<M, STORE_VALUE>(I);
+    ILQR_PROF_END(I, PROF_BACKWARD);
+}
+
 // ------------------------------------------------------------- rollout!
 // Closed-loop rollout u = αk + ū + Kx − Kx̄ in the reference's operation order
 // (src/rollout.jl:24-28), wave-uniform; lane 0 writes the trial trajectory.
 template <class M>
 __device__ void rollout_bang(Inst<M>& I, double alpha) {
     constexpr int n = M::NX, m = M::NU;
+    ILQR_PROF_BEGIN();
     const double w[cdim<M::NW>::v] = {0.0};
     double xt[n];
 #pragma unroll
@@ -638,6 +817,7 @@ __device__ void rollout_bang(Inst<M>& I, double alpha) {
     I.rollouts += 1;
     I.states_eq_nominal = 0;
     __syncthreads();
+    ILQR_PROF_END(I, PROF_ROLLOUT);
 }
 
 // --------------------------------------------------------- forward_pass!
@@ -652,6 +832,7 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     // trajectory_sensitivities (src/data/methods.jl:42-54) fused with the
     // product gradientᵀ·Δz (:20).
     double delta = 0.0;
+    ILQR_PROF_BEGIN();
     if (opt.line_search == 1) {
         double zx[n];
 #pragma unroll
@@ -682,6 +863,7 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
             for (int i = 0; i < n; ++i) zx[i] = zy[i];
         }
     }
+    ILQR_PROF_END(I, PROF_DELTA);
     I.step_size = 1.0;                                                // (:26)
     int iteration = 1;
     while (I.step_size >= opt.min_step_size) {                        // (:28)
@@ -718,31 +900,6 @@ __device__ void reset_model_objective(Inst<M>& I) {
     __syncthreads();
 }
 
-// ilqr_solve! — src/solve.jl:1-54
-template <class M, bool STORE_VALUE>
-__device__ void ilqr_solve(Inst<M>& I, const ilqr_options& opt, bool constrained) {
-    reset_model_objective<M>(I);                                      // (:9-10)
-    if (opt.reset_cache) {                                            // (:12) reset!(data)
-        I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0;
-    }
-    cost_bang<M>(I, false, constrained);                              // (:14)
-    gradients<M>(I, constrained);                                     // (:16)
-    backward_pass<M, STORE_VALUE>(I);                                 // (:18)
-    double obj_prev = I.objective;                                    // (:21)
-    for (int i = 1; i <= opt.max_iterations; ++i) {                   // (:22)
-        forward_pass<M>(I, opt, constrained);                         // (:23)
-        if (opt.line_search != 0) {                                   // (:27-33)
-            gradients<M>(I, constrained);
-            backward_pass<M, STORE_VALUE>(I);
-        }
-        I.iterations += 1;                                            // (:39)
-        if (I.gradient_norm < opt.lagrangian_gradient_tolerance) break;          // (:48)
-        if (fabs(I.objective - obj_prev) < opt.objective_tolerance) break;       // (:49)
-        obj_prev = I.objective;
-        if (!I.status) break;                                         // (:50)
-    }
-}
-
 // augmented_lagrangian_update! — src/augmented_lagrangian.jl:87-110
 template <class M>
 __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
@@ -761,23 +918,50 @@ __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
     __syncthreads();
 }
 
-// constrained_ilqr_solve! — src/solve.jl:88-129
-template <class M>
-__device__ void constrained_ilqr_solve(Inst<M>& I, const ilqr_options& opt) {
-    // reset!(solver.data) (:93, src/data/solver.jl:49-59)
-    I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
-    for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
-    for (int i = I.lane; i < I.N * M::NU; i += 64) I.Lu[i] = 0.0;
-    for (int i = I.lane; i < I.C; i += 64) {                          // (:96-103)
-        I.lam[i] = 0.0;
-        I.rho[i] = opt.initial_constraint_penalty;
+// solve!(solver): constrained_ilqr_solve! (src/solve.jl:88-129) around ilqr_solve!
+// (src/solve.jl:1-54), written as ONE loop nest in which every heavy phase
+// (linearise, Riccati, line search) is instantiated exactly once.
+//   al_outer = true : AL outer loop (Solver with constraints)
+//   al_outer = false: a single ilqr_solve! (plain Objective, or the stage test)
+template <class M, bool STORE_VALUE>
+__device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constrained, bool al_outer) {
+    if (al_outer) {
+        // reset!(solver.data) (:93, src/data/solver.jl:49-59); λ ← 0, ρ ← ρ0 (:96-103)
+        I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
+        for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
+        for (int i = I.lane; i < I.N * M::NU; i += 64) I.Lu[i] = 0.0;
+        for (int i = I.lane; i < I.C; i += 64) {
+            I.lam[i] = 0.0;
+            I.rho[i] = opt.initial_constraint_penalty;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     I.outer_iterations = 0;
-    for (int i = 1; i <= opt.max_dual_updates; ++i) {                 // (:105)
-        I.outer_iterations = i;
-        ilqr_solve<M, false>(I, opt, true);                           // (:109)
-        cost_bang<M>(I, false, true);                                 // (:113)
+    const int outer_max = al_outer ? opt.max_dual_updates : 1;
+    for (int o = 1; o <= outer_max; ++o) {                            // src/solve.jl:105
+        if (al_outer) I.outer_iterations = o;
+        // ---------------- ilqr_solve! (src/solve.jl:1-54)
+        reset_model_objective<M>(I);                                  // (:9-10)
+        if (opt.reset_cache) {                                        // (:12) reset!(data)
+            I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0;
+        }
+        double obj_prev = 0.0;
+        for (int it = 0; it <= opt.max_iterations; ++it) {            // it = 0: (:14-21); it ≥ 1: (:22-51)
+            if (it == 0) cost_bang<M>(I, false, constrained);         // (:14)
+            else forward_pass<M>(I, opt, constrained);                // (:23)
+            if (it == 0 || opt.line_search != 0) {                    // (:16-18), (:27-33)
+                gradients<M>(I, constrained);
+                backward_pass<M, STORE_VALUE>(I);
+            }
+            if (it == 0) { obj_prev = I.objective; continue; }        // (:21)
+            I.iterations += 1;                                        // (:39)
+            if (I.gradient_norm < opt.lagrangian_gradient_tolerance) break;          // (:48)
+            if (fabs(I.objective - obj_prev) < opt.objective_tolerance) break;       // (:49)
+            obj_prev = I.objective;
+            if (!I.status) break;                                     // (:50)
+        }
+        if (!al_outer) break;
+        cost_bang<M>(I, false, true);                                 // src/solve.jl:113
         if (I.max_violation <= opt.constraint_tolerance) break;       // (:117)
         al_update<M>(I, opt);                                         // (:120-122)
     }
@@ -803,6 +987,9 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.status = (int)I.scal[S_STATUS]; I.iterations = (int)I.scal[S_ITERATIONS];
     I.outer_iterations = (int)I.scal[S_OUTER_ITERATIONS]; I.potrf_info = (int)I.scal[S_POTRF_INFO];
     I.rollouts = (int)I.scal[S_ROLLOUTS]; I.states_eq_nominal = (int)I.scal[S_STATES_EQ_NOMINAL];
+#ifdef ILQR_PROFILE
+    for (int i = 0; i < PROF_N; ++i) I.prof[i] = 0.0;
+#endif
     __syncthreads();
 }
 
@@ -820,6 +1007,9 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
         I.scal[S_STATUS] = (double)I.status; I.scal[S_ITERATIONS] = (double)I.iterations;
         I.scal[S_OUTER_ITERATIONS] = (double)I.outer_iterations; I.scal[S_POTRF_INFO] = (double)I.potrf_info;
         I.scal[S_ROLLOUTS] = (double)I.rollouts; I.scal[S_STATES_EQ_NOMINAL] = (double)I.states_eq_nominal;
+#ifdef ILQR_PROFILE
+        for (int i = 0; i < PROF_N; ++i) I.scal[S_PROF + i] = I.prof[i];
+#endif
     }
 }
 
@@ -832,8 +1022,11 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
     Inst<M> I;
     inst_setup<M>(I, a, smem, b);
     I.potrf_info = 0; I.rollouts = 0;
-    if (a.constrained) constrained_ilqr_solve<M>(I, a.opt);
-    else { I.outer_iterations = 0; ilqr_solve<M, false>(I, a.opt, false); }
+    {
+        ILQR_PROF_BEGIN();
+        solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0);
+        ILQR_PROF_END(I, PROF_OTHER);   // total; phases are subtracted on the host
+    }
     inst_writeback<M>(I, a, smem, b);
 }
 
@@ -852,7 +1045,7 @@ __global__ __launch_bounds__(64) void stage_kernel(KArgs a) {
         case ILQR_STAGE_BACKWARD_PASS: backward_pass<M, true>(I); break;
         case ILQR_STAGE_FORWARD_PASS: forward_pass<M>(I, a.opt, con); break;
         case ILQR_STAGE_RESET_MODEL_OBJECTIVE: reset_model_objective<M>(I); break;
-        case ILQR_STAGE_ILQR_SOLVE: ilqr_solve<M, true>(I, a.opt, con); break;
+        case ILQR_STAGE_ILQR_SOLVE: solve_loops<M, true>(I, a.opt, con, false); break;
         case ILQR_STAGE_AL_UPDATE: al_update<M>(I, a.opt); break;
         default: break;
     }
