@@ -325,8 +325,10 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     add("void", "dyn", sig_xu + [_arr("y", n, False)], dynamics,
         [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)])
     # wave-cooperative variant for the serial closed-loop rollout (all lanes hold the same x, u)
+    L.append("#if defined(__HIPCC__)")
     add("void", "dyn_wave", ["const int lane"] + sig_xu + [_arr("y", n, False)], dynamics,
         [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)], coop=True)
+    L.append("#endif")
     outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
     outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
     add("void", "dyn_jac", sig_xu + [_arr("fx", n * n, False), _arr("fu", n * m, False)], dynamics, outs)

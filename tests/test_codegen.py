@@ -1,0 +1,169 @@
+"""The model code generator (sympy twin of the reference's Symbolics constructors,
+src/dynamics.jl:16-34, src/costs.jl:17-44, src/constraints.jl:17-43): the generated device
+structs are compiled for the HOST and compared with the oracle's independently derived
+model zoo (dual-number Jacobians) on random points."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ilqr_amd_loader import load_package
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HARNESS = r'''
+#include <cmath>
+#define __device__
+#define __forceinline__ inline
+using std::sin; using std::cos; using std::fma; using std::fabs; using std::rint;
+#include "ilqr_math.hpp"
+#include "%(header)s"
+typedef %(struct)s M;
+template <int N> struct cd { static const int v = N > 0 ? N : 1; };
+extern "C" {
+int dims(int* o) { o[0]=M::NX; o[1]=M::NU; o[2]=M::NCS; o[3]=M::NCT; return 0; }
+unsigned long long ineq(int term) { return term ? M::INEQ_T : M::INEQ_S; }
+void dyn(const double* x, const double* u, double* y) {
+  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, yy[M::NX];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+  M::dyn(xx,uu,w,yy); for (int i=0;i<M::NX;++i) y[i]=yy[i]; }
+void dyn_jac(const double* x, const double* u, double* fx, double* fu) {
+  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[M::NX*M::NX], b[M::NX*cd<M::NU>::v];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+  M::dyn_jac(xx,uu,w,a,b); for (int i=0;i<M::NX*M::NX;++i) fx[i]=a[i]; for (int i=0;i<M::NX*M::NU;++i) fu[i]=b[i]; }
+double cost_s(const double* x, const double* u) {
+  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0};
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i]; return M::cost_s(xx,uu,w); }
+double cost_t(const double* x) { double xx[M::NX], w[1]={0}; for (int i=0;i<M::NX;++i) xx[i]=x[i]; return M::cost_t(xx,w); }
+void cost_s_grad(const double* x, const double* u, double* gx, double* gu) {
+  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[M::NX], b[cd<M::NU>::v];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+  M::cost_s_grad(xx,uu,w,a,b); for (int i=0;i<M::NX;++i) gx[i]=a[i]; for (int i=0;i<M::NU;++i) gu[i]=b[i]; }
+void cost_s_hess(const double* x, const double* u, double* gxx, double* guu, double* gux) {
+  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[M::NX*M::NX], b[cd<M::NU*M::NU>::v], c[cd<M::NU*M::NX>::v];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+  M::cost_s_hess(xx,uu,w,a,b,c); for (int i=0;i<M::NX*M::NX;++i) gxx[i]=a[i];
+  for (int i=0;i<M::NU*M::NU;++i) guu[i]=b[i]; for (int i=0;i<M::NU*M::NX;++i) gux[i]=c[i]; }
+void con_s(const double* x, const double* u, double* c) {
+  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, cc[cd<M::NCS>::v];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+  M::con_s(xx,uu,w,cc); for (int i=0;i<M::NCS;++i) c[i]=cc[i]; }
+void con_s_jac(const double* x, const double* u, double* cx, double* cu) {
+  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[cd<M::NCS*M::NX>::v], b[cd<M::NCS*M::NU>::v];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+  M::con_s_jac(xx,uu,w,a,b); for (int i=0;i<M::NCS*M::NX;++i) cx[i]=a[i]; for (int i=0;i<M::NCS*M::NU;++i) cu[i]=b[i]; }
+void con_t(const double* x, double* c) { double xx[M::NX], w[1]={0}, cc[cd<M::NCT>::v];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; M::con_t(xx,w,cc); for (int i=0;i<M::NCT;++i) c[i]=cc[i]; }
+void con_t_jac(const double* x, double* cx) { double xx[M::NX], w[1]={0}, a[cd<M::NCT*M::NX>::v];
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; M::con_t_jac(xx,w,a); for (int i=0;i<M::NCT*M::NX;++i) cx[i]=a[i]; }
+}
+'''
+
+
+def _build(tmp, header, struct):
+    src = tmp / ("h_%s.cpp" % struct)
+    src.write_text(HARNESS % dict(header=header, struct=struct))
+    so = tmp / ("h_%s.so" % struct)
+    subprocess.check_call(["g++", "-O1", "-mfma", "-std=c++17", "-shared", "-fPIC", "-w",
+                           "-I", os.path.join(ROOT, "iterativelqr.jl_amd", "csrc"), str(src), "-o", str(so)])
+    L = ctypes.CDLL(str(so))
+    L.cost_s.restype = ctypes.c_double
+    L.cost_t.restype = ctypes.c_double
+    L.ineq.restype = ctypes.c_ulonglong
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+@pytest.mark.parametrize("model", ["particle", "pendulum_euler", "acrobot", "car", "car_goal"])
+def test_generated_builtin_matches_oracle(tmp_path, oracle, model):
+    hdr = os.path.join(ROOT, "iterativelqr.jl_amd", "csrc", "models", "model_%s.h" % model)
+    L = _build(tmp_path, hdr, "Model_" + model)
+    d = (ctypes.c_int * 4)(); L.dims(d)
+    n, m, ncs, nct = list(d)
+    T = 3
+    pr = oracle.Problem(model, T)
+    assert (pr.nx, pr.nu) == (n, m)
+    rng = np.random.default_rng(2)
+    for trial in range(5):
+        x = rng.standard_normal((T, n)) * (1.0 if trial else 3.0); u = rng.standard_normal((T - 1, m))
+        s = oracle.Solver(pr); s.initialize_states(x); s.initialize_controls(u)
+        s.set_buffer("states", x); s.set_buffer("actions", u)
+        s.call("reset_model_objective"); s.call("cost_bang", 0); s.call("gradients")
+        # dynamics value and Jacobians
+        y = np.zeros(n); L.dyn(_p(x[0]), _p(u[0]), _p(y))
+        assert np.allclose(y, pr.rollout(x[0], u)[1], rtol=1e-13, atol=1e-14)
+        fx = np.zeros(n * n); fu = np.zeros(n * m); L.dyn_jac(_p(x[0]), _p(u[0]), _p(fx), _p(fu))
+        assert np.allclose(fx, s.buffer("jacobian_state")[:n * n], rtol=1e-11, atol=1e-12)
+        assert np.allclose(fu, s.buffer("jacobian_action")[:n * m], rtol=1e-11, atol=1e-12)
+        # costs
+        J = sum(L.cost_s(_p(x[t]), _p(u[t])) for t in range(T - 1)) + L.cost_t(_p(x[-1]))
+        gx = np.zeros(n); gu = np.zeros(m); L.cost_s_grad(_p(x[0]), _p(u[0]), _p(gx), _p(gu))
+        gxx = np.zeros(n * n); guu = np.zeros(m * m); gux = np.zeros(m * n)
+        L.cost_s_hess(_p(x[0]), _p(u[0]), _p(gxx), _p(guu), _p(gux))
+        if pr.c.constraints is None:
+            assert J == pytest.approx(s.stats().objective, rel=1e-13)
+            assert np.allclose(gx, s.buffer("gradient_state")[:n]) and np.allclose(gu, s.buffer("gradient_action")[:m])
+            assert np.allclose(gxx, s.buffer("hessian_state_state")[:n * n])
+        # constraints (values via the violations buffer = c(states))
+        if ncs:
+            c = np.zeros(ncs); L.con_s(_p(x[0]), _p(u[0]), _p(c))
+            assert np.allclose(c, s.buffer("violations")[:ncs], rtol=1e-13, atol=1e-14)
+        if nct:
+            c = np.zeros(nct); L.con_t(_p(x[-1]), _p(c))
+            assert np.allclose(c, s.buffer("violations")[(T - 1) * ncs:], rtol=1e-13, atol=1e-14)
+
+
+def test_user_model_codegen_roundtrip(tmp_path):
+    """A user-defined model through the public constructors: values and derivatives vs finite differences."""
+    import sympy as sp
+    pkg = load_package()
+    f = lambda x, u: [x[0] + 0.1 * x[1] * sp.cos(x[0]), x[1] + 0.1 * (u[0] - 9.81 * sp.sin(x[0]) - 0.1 * x[1] * u[1])]
+    dyn = pkg.Dynamics(f, 2, 2)
+    stage = pkg.Cost(lambda x, u: x[0] ** 2 * x[1] + 0.1 * u[0] ** 2 + sp.sin(u[1]) * x[1], 2, 2)
+    term = pkg.Cost(lambda x, u: 10.0 * (x[0] ** 2 + x[1] ** 4), 2, 0)
+    cs = pkg.Constraint(lambda x, u: [u[0] - 2.0, -2.0 - u[0], x[0] * u[1]], 2, 2, indices_inequality=[1, 2])
+    ct = pkg.Constraint(lambda x, u: [x[0] - 3.0, x[1] * x[0]], 2, 0)
+    sname, src = pkg.codegen.generate_model_source("usr", dyn, stage, term, cs, ct)
+    hdr = tmp_path / "model_usr.h"
+    hdr.write_text(src)
+    L = _build(tmp_path, str(hdr), sname)
+    assert L.ineq(0) == 0b011 and L.ineq(1) == 0
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(2); u = rng.standard_normal(2)
+
+    def fd(fun, z, k, eps=1e-6):
+        out = []
+        for i in range(z.size):
+            zp, zm = z.copy(), z.copy(); zp[i] += eps; zm[i] -= eps
+            out.append((fun(zp) - fun(zm)) / (2 * eps))
+        return np.array(out).T.reshape(k, z.size)
+
+    def F(z):
+        y = np.zeros(2); L.dyn(_p(np.ascontiguousarray(z[:2])), _p(np.ascontiguousarray(z[2:])), _p(y)); return y
+    fx = np.zeros(4); fu = np.zeros(4); L.dyn_jac(_p(x), _p(u), _p(fx), _p(fu))
+    Jfd = fd(F, np.r_[x, u], 2)
+    assert np.allclose(np.c_[fx.reshape(2, 2).T, fu.reshape(2, 2).T], Jfd, atol=1e-7)
+    assert np.allclose(F(np.r_[x, u]), [float(v) for v in f(list(x), list(u))], rtol=1e-14)
+
+    def Cst(z):
+        return np.array([L.cost_s(_p(np.ascontiguousarray(z[:2])), _p(np.ascontiguousarray(z[2:])))])
+    gx = np.zeros(2); gu = np.zeros(2); L.cost_s_grad(_p(x), _p(u), _p(gx), _p(gu))
+    assert np.allclose(np.r_[gx, gu], fd(Cst, np.r_[x, u], 1)[0], atol=1e-6)
+
+    def G(z):
+        a = np.zeros(2); b = np.zeros(2)
+        L.cost_s_grad(_p(np.ascontiguousarray(z[:2])), _p(np.ascontiguousarray(z[2:])), _p(a), _p(b)); return np.r_[a, b]
+    H = fd(G, np.r_[x, u], 4)
+    gxx = np.zeros(4); guu = np.zeros(4); gux = np.zeros(4); L.cost_s_hess(_p(x), _p(u), _p(gxx), _p(guu), _p(gux))
+    assert np.allclose(gxx.reshape(2, 2).T, H[:2, :2], atol=1e-6) and np.allclose(guu.reshape(2, 2).T, H[2:, 2:], atol=1e-6)
+    assert np.allclose(gux.reshape(2, 2).T, H[2:, :2], atol=1e-6)      # hessian_action_state is nu×nx
+
+    def Cn(z):
+        c = np.zeros(3); L.con_s(_p(np.ascontiguousarray(z[:2])), _p(np.ascontiguousarray(z[2:])), _p(c)); return c
+    cx = np.zeros(6); cu = np.zeros(6); L.con_s_jac(_p(x), _p(u), _p(cx), _p(cu))
+    assert np.allclose(np.c_[cx.reshape(2, 3).T, cu.reshape(2, 3).T], fd(Cn, np.r_[x, u], 3), atol=1e-7)
