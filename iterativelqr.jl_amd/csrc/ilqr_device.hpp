@@ -685,27 +685,33 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         // potrs('U') for K (block 0: m x n) and k (block 1, column 0) at once   (:70-75)
         const double Qu_b1 = row_from_prev_quad(Qu);                    // block 0 -> block 1
         double Y = (blk == 1) ? Qu_b1 : Qux;
+        if (m == 1 && info == 0) {
+            // 1x1: (b / sqrt(q)) / sqrt(q) == b / q up to one rounding; saves a sqrt and a division
+            // (~220 clk) on the serial chain. The literal path below still runs when potrf fails.
+            Y = Y / lane_bcast(Quu, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < m; ++i) {                                   // U^T y = b
+            for (int i = 0; i < m; ++i) {                               // U^T y = b
 #pragma unroll
-            for (int l = 0; l < i; ++l) {
-                const double yl = __shfl(Y, lane - 16 * (i - l));
-                const double v = Y - Uc[i * m + l] * yl;
-                Y = (r == i) ? v : Y;
+                for (int l = 0; l < i; ++l) {
+                    const double yl = __shfl(Y, lane - 16 * (i - l));
+                    const double v = Y - Uc[i * m + l] * yl;
+                    Y = (r == i) ? v : Y;
+                }
+                const double q = Y / Uc[i * m + i];
+                Y = (r == i) ? q : Y;
             }
-            const double q = Y / Uc[i * m + i];
-            Y = (r == i) ? q : Y;
-        }
 #pragma unroll
-        for (int i = m - 1; i >= 0; --i) {                              // U x = y
+            for (int i = m - 1; i >= 0; --i) {                          // U x = y
 #pragma unroll
-            for (int l = i + 1; l < m; ++l) {
-                const double xl = __shfl(Y, lane + 16 * (l - i));
-                const double v = Y - Uc[l * m + i] * xl;
-                Y = (r == i) ? v : Y;
+                for (int l = i + 1; l < m; ++l) {
+                    const double xl = __shfl(Y, lane + 16 * (l - i));
+                    const double v = Y - Uc[l * m + i] * xl;
+                    Y = (r == i) ? v : Y;
+                }
+                const double q = Y / Uc[i * m + i];
+                Y = (r == i) ? q : Y;
             }
-            const double q = Y / Uc[i * m + i];
-            Y = (r == i) ? q : Y;
         }
         Y *= -1.0;                                                      // K .*= -1, k .*= -1
         const double K = Y;                                             // valid in block 0
@@ -751,9 +757,15 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
 // ------------------------------------------------------------- rollout!
 // Closed-loop rollout u = αk + ū + Kx − Kx̄ in the reference's operation order
 // (src/rollout.jl:24-28), wave-uniform; lane 0 writes the trial trajectory.
+// With `with_delta` (first line-search trial) the loop also carries the sensitivity
+// recursion Δu = k + KΔx, Δx⁺ = fuΔu + fxΔx (src/data/methods.jl:42-54) and the product
+// ∇Lᵀ·Δz (src/forward_pass.jl:20) as three f64 MFMAs per step on column vectors in
+// the MFMA lane layout: the matrix pipe works asynchronously beside the VALU dynamics
+// chain, so Δ costs issue slots only (it used to be a separate 54 k-cycle serial loop).
 template <class M>
-__device__ void rollout_bang(Inst<M>& I, double alpha) {
+__device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
     constexpr int n = M::NX, m = M::NU;
+    constexpr bool MF = (n <= 4 && m <= 4);
     ILQR_PROF_BEGIN();
     const double w[cdim<M::NW>::v] = {0.0};
     double xt[n];
@@ -763,56 +775,90 @@ __device__ void rollout_bang(Inst<M>& I, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) I.x[i] = xt[i];
     }
-    // policy operands of step t are fetched from LDS one step ahead so that their
-    // latency hides under the previous step's dynamics chain
-    double Kn[m * n], kn[m], ubn[m], xbn[n];
+    // sensitivity state (MFMA layout: element (r, c) on lane c + 4*blk + 16*r, vectors in column 0)
+    const int lane = I.lane, r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
+    const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
+    const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n;
+    const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m;
+    double zx = 0.0, dacc = 0.0;
+    (void)blk; (void)rn; (void)cn; (void)rm; (void)cm; (void)vnn; (void)vnm; (void)vmn; (void)vn1; (void)vm1;
+    // policy operands of step t are fetched from LDS one step ahead so that their latency
+    // hides under the previous step's dynamics chain; the loop is unrolled by two with
+    // ping-pong operand sets so that no register copies are needed
+    struct Ops { double K[m * n], k[m], ub[m], xb[n]; };
+    auto fetch = [&](Ops& o, int t) {
 #pragma unroll
-    for (int i = 0; i < m * n; ++i) Kn[i] = I.K[i];
+        for (int i = 0; i < m * n; ++i) o.K[i] = I.K[t * m * n + i];
 #pragma unroll
-    for (int i = 0; i < m; ++i) { kn[i] = I.k[i]; ubn[i] = I.ub[i]; }
+        for (int i = 0; i < m; ++i) { o.k[i] = I.k[t * m + i]; o.ub[i] = I.ub[t * m + i]; }
 #pragma unroll
-    for (int i = 0; i < n; ++i) xbn[i] = xt[i];
-    for (int t = 0; t < I.N; ++t) {
-        double Kt[m * n], kt[m], ubt[m], xbt[n];
-#pragma unroll
-        for (int i = 0; i < m * n; ++i) Kt[i] = Kn[i];
-#pragma unroll
-        for (int i = 0; i < m; ++i) { kt[i] = kn[i]; ubt[i] = ubn[i]; }
-#pragma unroll
-        for (int i = 0; i < n; ++i) xbt[i] = xbn[i];
-        if (t + 1 < I.N) {
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) Kn[i] = I.K[(t + 1) * m * n + i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) { kn[i] = I.k[(t + 1) * m + i]; ubn[i] = I.ub[(t + 1) * m + i]; }
-#pragma unroll
-            for (int i = 0; i < n; ++i) xbn[i] = I.xb[(t + 1) * n + i];
+        for (int i = 0; i < n; ++i) o.xb[i] = I.xb[t * n + i];
+    };
+    auto step = [&](const Ops& o, int t, const double (&xin)[n], double (&xout)[n]) {
+        // sensitivity recursion, first half: issued before the VALU dynamics chain so that the
+        // matrix pipe works underneath it (operands are transposed straight from LDS:
+        // mfma(A<-X^T, B<-v, C) = X v + C; the dot product ∇Lᵀ·Δz accumulates in element (0,0))
+        double zu = 0.0, fz = 0.0, fuT = 0.0, Luc = 0.0;
+        if constexpr (MF) {
+            if (with_delta) {
+                double KT = I.K[t * m * n + rn * m + cm];      // K^T(r,c) = K(c,r), r<n, c<m
+                double fxT = I.fx[t * n * n + rn * n + cn];    // fx^T(r,c) = fx(c,r)
+                fuT = I.fu[t * n * m + rm * n + cn];           // fu^T(r,c) = fu(c,r), r<m, c<n
+                double kc = I.k[t * m + rm], Lxc = I.Lx[t * n + rn];
+                Luc = I.Lu[t * m + rm];
+                KT = vnm ? KT : 0.0; fxT = vnn ? fxT : 0.0; fuT = vmn ? fuT : 0.0;
+                kc = vm1 ? kc : 0.0; Lxc = vn1 ? Lxc : 0.0; Luc = vm1 ? Luc : 0.0;
+                zu = mfma444(KT, zx, kc);                       // Δu = k + K Δx
+                fz = mfma444(fxT, zx, 0.0);                     // fx Δx
+                dacc = mfma444(Lxc, zx, dacc);                  // += ∇L_x · Δx
+            }
         }
         double ut[m];
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-            double v = kt[i] * alpha;                                 // (:24-25)
-            v += ubt[i];                                              // (:26)
+            double v = o.k[i] * alpha;                                // (:24-25)
+            v += o.ub[i];                                             // (:26)
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                a1 += Kt[j * m + i] * xt[j];
-                a2 += Kt[j * m + i] * xbt[j];
+                a1 += o.K[j * m + i] * xin[j];
+                a2 += o.K[j * m + i] * o.xb[j];
             }
             v += a1;                                                  // (:27)
             v += -1.0 * a2;                                           // (:28)
             ut[i] = v;
         }
-        double y[n];
-        M::dyn_wave(I.lane, xt, ut, w, y);                            // (:29)
+        M::dyn_wave(I.lane, xin, ut, w, xout);                        // (:29)
         if (I.lane == 0) {
 #pragma unroll
             for (int i = 0; i < m; ++i) I.u[t * m + i] = ut[i];
 #pragma unroll
-            for (int i = 0; i < n; ++i) I.x[(t + 1) * n + i] = y[i];
+            for (int i = 0; i < n; ++i) I.x[(t + 1) * n + i] = xout[i];
         }
+        if constexpr (MF) {
+            if (with_delta) {                                          // second half of the recursion
+                dacc = mfma444(Luc, zu, dacc);                         // += ∇L_u · Δu
+                zx = mfma444(fuT, zu, fz);                             // Δx⁺ = fu Δu + fx Δx
+            }
+        }
+    };
+    Ops A, B;
+    double xo[n];
+    if (I.N > 0) fetch(A, 0);
+    int t = 0;
+    for (; t + 1 < I.N; t += 2) {
+        fetch(B, t + 1);
+        step(A, t, xt, xo);
+        if (t + 2 < I.N) fetch(A, t + 2);
+        step(B, t + 1, xo, xt);
+    }
+    if (t < I.N) {
+        step(A, t, xt, xo);
 #pragma unroll
-        for (int i = 0; i < n; ++i) xt[i] = y[i];
+        for (int i = 0; i < n; ++i) xt[i] = xo[i];
+    }
+    if constexpr (MF) {
+        if (with_delta) delta_out = lane_bcast(dacc, 0);               // element (0,0) of block 0
     }
     I.rollouts += 1;
     I.states_eq_nominal = 0;
@@ -824,51 +870,57 @@ __device__ void rollout_bang(Inst<M>& I, double alpha) {
 template <class M>
 __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrained) {
     constexpr int n = M::NX, m = M::NU;
+    constexpr bool MF = (n <= 4 && m <= 4);
     const double c1 = 1.0e-4;
     const int max_iterations = 25;
     I.status = 0;                                                     // (:10)
     const double J_prev = I.objective;                                // (:13)
     // lagrangian_gradient! (:16) was produced by the backward pass (Lx, Lu in LDS).
-    // trajectory_sensitivities (src/data/methods.jl:42-54) fused with the
-    // product gradientᵀ·Δz (:20).
+    // trajectory_sensitivities (src/data/methods.jl:42-54) fused with the product
+    // gradientᵀ·Δz (:20): on the MFMA path it rides along the first rollout below.
     double delta = 0.0;
-    ILQR_PROF_BEGIN();
-    if (opt.line_search == 1) {
-        double zx[n];
+    if constexpr (!MF) {
+        ILQR_PROF_BEGIN();
+        if (opt.line_search == 1) {
+            double zx[n];
 #pragma unroll
-        for (int i = 0; i < n; ++i) zx[i] = 0.0;
-        for (int t = 0; t < I.N; ++t) {
-            double zu[m], zy[n];
+            for (int i = 0; i < n; ++i) zx[i] = 0.0;
+            for (int t = 0; t < I.N; ++t) {
+                double zu[m], zy[n];
 #pragma unroll
-            for (int i = 0; i < m; ++i) {
-                double acc = 0.0;
+                for (int i = 0; i < m; ++i) {
+                    double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < n; ++j) acc += I.K[t * m * n + j * m + i] * zx[j];
-                zu[i] = I.k[t * m + i] + acc;
+                    for (int j = 0; j < n; ++j) acc += I.K[t * m * n + j * m + i] * zx[j];
+                    zu[i] = I.k[t * m + i] + acc;
+                }
+#pragma unroll
+                for (int i = 0; i < n; ++i) delta += I.Lx[t * n + i] * zx[i];
+#pragma unroll
+                for (int i = 0; i < m; ++i) delta += I.Lu[t * m + i] * zu[i];
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < m; ++j) a1 += I.fu[t * n * m + j * n + i] * zu[j];
+#pragma unroll
+                    for (int j = 0; j < n; ++j) a2 += I.fx[t * n * n + j * n + i] * zx[j];
+                    zy[i] = a1 + a2;
+                }
+#pragma unroll
+                for (int i = 0; i < n; ++i) zx[i] = zy[i];
             }
-#pragma unroll
-            for (int i = 0; i < n; ++i) delta += I.Lx[t * n + i] * zx[i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) delta += I.Lu[t * m + i] * zu[i];
-#pragma unroll
-            for (int i = 0; i < n; ++i) {
-                double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-                for (int j = 0; j < m; ++j) a1 += I.fu[t * n * m + j * n + i] * zu[j];
-#pragma unroll
-                for (int j = 0; j < n; ++j) a2 += I.fx[t * n * n + j * n + i] * zx[j];
-                zy[i] = a1 + a2;
-            }
-#pragma unroll
-            for (int i = 0; i < n; ++i) zx[i] = zy[i];
         }
+        ILQR_PROF_END(I, PROF_DELTA);
     }
-    ILQR_PROF_END(I, PROF_DELTA);
     I.step_size = 1.0;                                                // (:26)
     int iteration = 1;
     while (I.step_size >= opt.min_step_size) {                        // (:28)
         if (iteration > max_iterations) break;                        // (:29)
-        rollout_bang<M>(I, I.step_size);                              // (:34)
+        const bool want_delta = MF && iteration == 1 && opt.line_search == 1;
+        double d = 0.0;
+        rollout_bang<M>(I, I.step_size, want_delta, d);               // (:34)
+        if (want_delta) delta = d;
         cost_bang<M>(I, true, constrained);                           // (:36)
         const double J = I.objective;
         if (J <= J_prev + c1 * I.step_size * delta) {                 // (:44) NaN ⇒ reject
