@@ -124,6 +124,12 @@ def main():
                                      st["rollouts"].astype(np.float64)).sum())
     achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     value = world * B * args.steps / elapsed
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs, see profiles/)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        traffic = pmc.get("%s:%d" % (args.config, B), {}).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
 
     out = {
         "metric": "trajectories/sec (whole node), acrobot T=101 batch=1024/GPU",
@@ -139,7 +145,7 @@ def main():
                         "converged_frac": float((st["max_violation"] <= 5e-3).mean()),
                         "trajectory_iterations_per_s": float(world * st["iterations"].sum() * args.steps / elapsed)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "solve_kernel<Model_%s>" % model, "kernel_ms_avg": kernel_ms, "launches": launches,
                      "algorithmic_bytes_per_launch": abytes},
     }

@@ -965,7 +965,7 @@ __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
         if (ineq) lam = nanmax(0.0, lam);
         I.lam[i] = lam;
         const double r = opt.scaling_penalty * I.rho[i];
-        I.rho[i] = r < opt.max_penalty ? r : opt.max_penalty;
+        I.rho[i] = (r < opt.max_penalty || r != r) ? r : opt.max_penalty;      // Julia's min propagates NaN
     }
     __syncthreads();
 }

@@ -15,6 +15,10 @@
 #include <limits>
 #include <vector>
 
+// Julia's max/min propagate NaN (Base.max(NaN, x) == NaN), unlike C's fmax/fmin.
+static inline double jl_max(double a, double b) { return (a != a || b != b) ? std::numeric_limits<double>::quiet_NaN() : (a > b ? a : b); }
+static inline double jl_min(double a, double b) { return (a != a || b != b) ? std::numeric_limits<double>::quiet_NaN() : (a < b ? a : b); }
+
 struct OrcSolver {
     int T, n, m, nw;
     bool constrained;
@@ -234,8 +238,8 @@ static double constraint_violation(OrcSolver* s, const double* x, const double* 
         const OrcConstraint* con = s->cons[t];
         for (int i = 0; i < con->num_constraint; ++i) {
             double c = s->violations[s->coff[t] + i];
-            double cti = is_ineq(con, i) ? std::fmax(0.0, c) : std::fabs(c);
-            mv = std::fmax(mv, cti);
+            double cti = is_ineq(con, i) ? jl_max(0.0, c) : std::fabs(c);
+            mv = jl_max(mv, cti);
         }
     }
     return mv;
@@ -644,8 +648,8 @@ extern "C" void orc_augmented_lagrangian_update(OrcSolver* s) {
         int off = s->coff[t];
         for (int i = 0; i < con->num_constraint; ++i) {
             s->lambda[off + i] += s->rho[off + i] * s->violations[off + i];
-            if (is_ineq(con, i)) s->lambda[off + i] = std::fmax(0.0, s->lambda[off + i]);
-            s->rho[off + i] = std::fmin(s->opt.scaling_penalty * s->rho[off + i], s->opt.max_penalty);
+            if (is_ineq(con, i)) s->lambda[off + i] = jl_max(0.0, s->lambda[off + i]);
+            s->rho[off + i] = jl_min(s->opt.scaling_penalty * s->rho[off + i], s->opt.max_penalty);
         }
     }
 }
