@@ -44,6 +44,7 @@ def compile_model(name, dynamics, cost_stage, cost_term, con_stage=None, con_ter
         with open(hip, "w") as f:
             f.write('#include "ilqr_device.hpp"\n' + src + "ILQR_DEFINE_MODEL(%s)\n" % sname)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-mllvm", "-amdgpu-mfma-vgpr-form",   # MFMA results straight into VGPRs (no AGPR copies)
                                "-Wno-unused-parameter", "-I", _ffi.CSRC, hip, "-o", so,
                                "-L", _ffi.LIB_DIR, "-lilqr_hip", "-Wl,-rpath," + _ffi.LIB_DIR])
     return so

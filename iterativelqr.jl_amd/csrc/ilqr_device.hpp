@@ -79,6 +79,8 @@ struct Inst {
     static constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     double *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act;
     double *gxx, *guu, *gux, *P, *p, *scal;
+    double *zs;            // LDS: zs[0] == 0.0 always, zs[1] is a write-only trash slot
+    const double* gzero;   // HBM: a 0.0
     int T, N, C, lane;
     double objective, max_violation, step_size, gradient_norm;
     int status, iterations, outer_iterations, potrf_info, rollouts, states_eq_nominal;
@@ -608,18 +610,21 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {   // unif
 }
 // Cross-block moves inside a 16-lane row. Written as volatile asm: hipcc sinks the
 // update_dpp builtin into the divergent arm of a following select, where the source
-// lanes are masked off and DPP then reads 0. The s_nop covers the VALU->DPP and
-// EXEC->DPP wait states that hipcc does not insert around inline asm.
+// lanes are masked off and DPP then reads 0. hipcc inserts no hazard wait states around
+// inline asm: the leading s_nops cover MFMA(f64 4x4x4)->VALU-read (the operand often comes
+// straight out of an MFMA in VGPR form; with too few wait states the low dword arrives stale
+// and k loses ~2^-24 relative accuracy), VALU->DPP and EXEC->DPP; the trailing one covers
+// DPP result -> MFMA operand.
 __device__ __forceinline__ double row_from_next_quad(double v) {   // lane l <- lane l+4 (row_shl:4)
     int lo = __double2loint(v), hi = __double2hiint(v), olo, ohi;
-    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %2 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 7\n\ts_nop 7\n\tv_mov_b32_dpp %0, %2 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "v_mov_b32_dpp %1, %3 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
                  : "=&v"(olo), "=&v"(ohi) : "v"(lo), "v"(hi));
     return __hiloint2double(ohi, olo);
 }
 __device__ __forceinline__ double row_from_prev_quad(double v) {   // lane l <- lane l-4 (row_shr:4)
     int lo = __double2loint(v), hi = __double2hiint(v), olo, ohi;
-    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 7\n\ts_nop 7\n\tv_mov_b32_dpp %0, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "v_mov_b32_dpp %1, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
                  : "=&v"(olo), "=&v"(ohi) : "v"(lo), "v"(hi));
     return __hiloint2double(ohi, olo);
@@ -628,6 +633,12 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+#ifndef ILQR_BW_PTR_LOADS
+#define ILQR_BW_PTR_LOADS 1
+#endif
+#ifndef ILQR_BW_PTR_STORES
+#define ILQR_BW_PTR_STORES 0   // enabling BOTH pointer-walk loads and stores miscompiles (hipcc 7.2: GPU memory faults)
+#endif
 template <class M, bool STORE_VALUE>
 __device__ void backward_pass_mfma(Inst<M>& I) {
     constexpr int n = M::NX, m = M::NU;
@@ -635,36 +646,55 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
     const int lane = I.lane, r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
     const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n, vmm = r < m && c < m;
     const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m;
-    // every lane loads from a clamped (always valid) address and zeroes the padding by
-    // select: no divergent branches around the operand loads
-    const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
-    const int o_nn = cn * n + rn, o_nm = cm * n + rn, o_mn = cn * m + rm, o_mm = cm * m + rm;
     const int N = I.N;
-    double P = I.gxx[N * n * n + o_nn];                                // P[H] .= gxx[H]  (:39)
-    P = vnn ? P : 0.0;
-    double p = I.gx[N * n + rn];                                       // p[H] .= gx[H]   (:40)
-    p = vn1 ? p : 0.0;
-    if (STORE_VALUE && blk == 0) {
+    // Per-lane operand pointers that walk backwards in time. Lanes outside the real nx/nu
+    // extent of the zero-padded 4x4 operands aim at a slot holding 0.0 with stride 0, so the
+    // padding costs no selects and no divergent branches; the same trick with a trash slot
+    // makes the result stores unconditional inside block 0.
+    const double* pfx = vnn ? I.fx + (N - 1) * n * n + c * n + r : I.zs;   const int sfx = vnn ? n * n : 0;
+    const double* pfu = vnm ? I.fu + (N - 1) * n * m + c * n + r : I.zs;   const int sfu = vnm ? n * m : 0;
+    const double* pgx = vn1 ? I.gx + (N - 1) * n + r : I.zs;               const int sgx = vn1 ? n : 0;
+    const double* pgu = vm1 ? I.gu + (N - 1) * m + r : I.zs;               const int sgu = vm1 ? m : 0;
+    const double* pxx = vnn ? I.gxx + (N - 1) * n * n + c * n + r : I.gzero;
+    const double* puu = vmm ? I.guu + (N - 1) * m * m + c * m + r : I.gzero;
+    const double* pux = vmn ? I.gux + (N - 1) * m * n + c * m + r : I.gzero;
+    const bool b0 = blk == 0;
+    double* qK = (b0 && vmn) ? I.K + (N - 1) * m * n + c * m + r : I.zs + 1;   const int sK = (b0 && vmn) ? m * n : 0;
+    double* qk = (b0 && vm1) ? I.k + (N - 1) * m + r : I.zs + 1;               const int sk = (b0 && vm1) ? m : 0;
+    double* qLu = (b0 && vm1) ? I.Lu + (N - 1) * m + r : I.zs + 1;
+    double* qLx = (b0 && vn1) ? I.Lx + (N - 1) * n + r : I.zs + 1;             const int sLx = (b0 && vn1) ? n : 0;
+
+    double P = vnn ? I.gxx[N * n * n + c * n + r] : 0.0;               // P[H] .= gxx[H]  (:39)
+    double p = vn1 ? I.gx[N * n + r] : 0.0;                            // p[H] .= gx[H]   (:40)
+    if (STORE_VALUE && b0) {
         if (vnn) I.P[N * n * n + c * n + r] = P;
         if (vn1) I.p[N * n + r] = p;
     }
     double gmax = 0.0;
-    // accumulated Hessians live in HBM/L2: prefetch one step ahead
-    const int tl = N > 0 ? N - 1 : 0;
-    double nxx = I.gxx[tl * n * n + o_nn], nuu = I.guu[tl * m * m + o_mm], nux = I.gux[tl * m * n + o_mn];
+    // operands of step t are fetched one step ahead (accumulated Hessians from HBM/L2, the rest from LDS)
+    double nxx = 0.0, nuu = 0.0, nux = 0.0, nfx = 0.0, nfu = 0.0, ngx = 0.0, ngu = 0.0;
+    if (N > 0) {
+        nxx = *pxx; nuu = *puu; nux = *pux;
+        nfx = *pfx; nfu = *pfu; ngx = *pgx; ngu = *pgu;
+    }
     for (int t = N - 1; t >= 0; --t) {                                  // (:42)
-        const double gxx = vnn ? nxx : 0.0, guu = vmm ? nuu : 0.0, gux = vmn ? nux : 0.0;
-        {
-            const int tp = t > 0 ? t - 1 : 0;
-            nxx = I.gxx[tp * n * n + o_nn];
-            nuu = I.guu[tp * m * m + o_mm];
-            nux = I.gux[tp * m * n + o_mn];
+        const double gxx = nxx, guu = nuu, gux = nux, fx = nfx, fu = nfu, gx = ngx, gu = ngu;
+        if (t > 0) {
+#if ILQR_BW_PTR_LOADS
+            pxx -= vnn ? n * n : 0; puu -= vmm ? m * m : 0; pux -= vmn ? m * n : 0;
+            pfx -= sfx; pfu -= sfu; pgx -= sgx; pgu -= sgu;
+            nxx = *pxx; nuu = *puu; nux = *pux;
+            nfx = *pfx; nfu = *pfu; ngx = *pgx; ngu = *pgu;
+#else
+            const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
+            const int tp = t - 1;
+            nxx = I.gxx[tp * n * n + cn * n + rn]; nuu = I.guu[tp * m * m + cm * m + rm]; nux = I.gux[tp * m * n + cn * m + rm];
+            nfx = I.fx[tp * n * n + cn * n + rn]; nfu = I.fu[tp * n * m + cm * n + rn];
+            ngx = I.gx[tp * n + rn]; ngu = I.gu[tp * m + rm];
+            nxx = vnn ? nxx : 0.0; nuu = vmm ? nuu : 0.0; nux = vmn ? nux : 0.0;
+            nfx = vnn ? nfx : 0.0; nfu = vnm ? nfu : 0.0; ngx = vn1 ? ngx : 0.0; ngu = vm1 ? ngu : 0.0;
+#endif
         }
-        double fx = I.fx[t * n * n + o_nn], fu = I.fu[t * n * m + o_nm], gx = I.gx[t * n + rn], gu = I.gu[t * m + rm];
-        fx = vnn ? fx : 0.0;
-        fu = vnm ? fu : 0.0;
-        gx = vn1 ? gx : 0.0;
-        gu = vm1 ? gu : 0.0;
         // level 1: W = P'^T fx (= (fx^T P')^T), Wu = P'^T fu, Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49)
         const double W = mfma444(P, fx, 0.0);
         const double Wu = mfma444(P, fu, 0.0);
@@ -680,7 +710,9 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         for (int j = 0; j < m; ++j)
 #pragma unroll
             for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
-        const int info = potrf_U<m>(Uc);
+        int info = 0;
+        if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
+        else info = potrf_U<m>(Uc);
         if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
         // potrs('U') for K (block 0: m x n) and k (block 1, column 0) at once   (:70-75)
         const double Qu_b1 = row_from_prev_quad(Qu);                    // block 0 -> block 1
@@ -688,8 +720,9 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         if (m == 1 && info == 0) {
             // 1x1: (b / sqrt(q)) / sqrt(q) == b / q up to one rounding; saves a sqrt and a division
             // (~220 clk) on the serial chain. The literal path below still runs when potrf fails.
-            Y = Y / lane_bcast(Quu, 0);
+            Y = Y / Uc[0];
         } else {
+            if (m == 1) potrf_U<m>(Uc);
 #pragma unroll
             for (int i = 0; i < m; ++i) {                               // U^T y = b
 #pragma unroll
@@ -728,12 +761,20 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         pn = mfma444(K, Qu, pn);
         pn = mfma444(Qux, k, pn);
         pn += Qx;
-        // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81)
+        // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81). The padding of Lx and
+        // Qu is exactly zero, so the running ∞-norm needs no lane predicate (block 0 is picked at the end).
         const double Lx = Qx - pn;
-        if (blk == 0) {
-            if (vn1) { gmax = nanmax(gmax, fabs(Lx)); I.Lx[t * n + r] = Lx; }
-            if (vm1) { gmax = nanmax(gmax, fabs(Qu)); I.Lu[t * m + r] = Qu; I.k[t * m + r] = k; }
+        gmax = nanmax(gmax, fabs(Lx));
+        gmax = nanmax(gmax, fabs(Qu));
+        if (b0) {
+#if ILQR_BW_PTR_STORES
+            *qK = K; *qk = k; *qLu = Qu; *qLx = Lx;
+            qK -= sK; qk -= sk; qLu -= sk; qLx -= sLx;
+#else
+            if (vn1) I.Lx[t * n + r] = Lx;
+            if (vm1) { I.Lu[t * m + r] = Qu; I.k[t * m + r] = k; }
             if (vmn) I.K[t * m * n + c * m + r] = K;
+#endif
             if (STORE_VALUE) {
                 if (vnn) I.P[t * n * n + c * n + r] = Pn;
                 if (vn1) I.p[t * n + r] = pn;
@@ -742,7 +783,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         P = Pn;
         p = pn;
     }
-    I.gradient_norm = wave_max(gmax);
+    I.gradient_norm = wave_max((b0 && c == 0) ? gmax : 0.0);
     __syncthreads();
 }
 
@@ -1028,12 +1069,14 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.fx = smem + L.fx; I.fu = smem + L.fu; I.gx = smem + L.gx; I.gu = smem + L.gu;
     I.K = smem + L.K; I.k = smem + L.k; I.Lx = smem + L.Lx; I.Lu = smem + L.Lu;
     I.c = smem + L.c; I.lam = smem + L.lam; I.rho = smem + L.rho; I.act = smem + L.act;
+    I.zs = smem + L.zslot; I.gzero = g + L.gzero;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x;
     // LDS-resident set: one coalesced 16-B-per-lane stream from HBM
     const double2* src = reinterpret_cast<const double2*>(g);
     double2* dst = reinterpret_cast<double2*>(smem);
     for (int i = I.lane; i < L.lds_doubles / 2; i += 64) dst[i] = src[i];
+    if (I.lane == 0) { I.zs[0] = 0.0; I.zs[1] = 0.0; }
     I.objective = I.scal[S_OBJECTIVE]; I.max_violation = I.scal[S_MAX_VIOLATION];
     I.step_size = I.scal[S_STEP_SIZE]; I.gradient_norm = I.scal[S_GRADIENT_NORM];
     I.status = (int)I.scal[S_STATUS]; I.iterations = (int)I.scal[S_ITERATIONS];

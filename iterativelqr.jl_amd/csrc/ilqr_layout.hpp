@@ -20,8 +20,9 @@ struct Layout {
     int C;   // total number of constraints over the horizon
     // offsets (in doubles) inside one instance block
     int xb, ub, x, u, fx, fu, gx, gu, K, k, Lx, Lu, c, lam, rho, act;   // LDS-resident set
+    int zslot;                                                          // [0] always 0.0, [1] write-only trash
     int lds_doubles;                                                    // size of that set
-    int gxx, guu, gux, P, p, scal;                                      // HBM-only set
+    int gxx, guu, gux, P, p, scal, gzero;                               // HBM-only set (gzero: a 0.0)
     int stride;
 };
 
@@ -49,6 +50,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int ncs, int nct, 
     L.lam = o; o += pad2(L.C);
     L.rho = o; o += pad2(L.C);
     L.act = o; o += pad2(L.C);
+    L.zslot = o; o += 2;
     L.lds_doubles = o;
     L.gxx = o; o += pad2(T * nx * nx);
     L.guu = o; o += pad2(N * nu * nu);
@@ -56,6 +58,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int ncs, int nct, 
     L.P = o; o += pad2(T * nx * nx);
     L.p = o; o += pad2(T * nx);
     L.scal = o; o += S_COUNT;
+    L.gzero = o; o += 2;
     L.stride = (o + 15) & ~15;   // 128-B aligned instance blocks
     return L;
 }
