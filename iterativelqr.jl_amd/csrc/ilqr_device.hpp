@@ -637,7 +637,7 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
 #define ILQR_BW_PTR_LOADS 1
 #endif
 #ifndef ILQR_BW_PTR_STORES
-#define ILQR_BW_PTR_STORES 0   // enabling BOTH pointer-walk loads and stores miscompiles (hipcc 7.2: GPU memory faults)
+#define ILQR_BW_PTR_STORES 0
 #endif
 template <class M, bool STORE_VALUE>
 __device__ void backward_pass_mfma(Inst<M>& I) {

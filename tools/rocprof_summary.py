@@ -21,7 +21,8 @@ def main():
         print("# PMC pass:", path)
         for name, cname, tot, n in cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection "
                                                "group by kernel_name, counter_name"):
-            print("%-70s %-12s sum=%.1f dispatches=%d per_dispatch=%.1f (KB)" % (name, cname, tot, n, tot / n))
+            unit = "KB" if cname.endswith("_SIZE") else "count"
+            print("%-62s %-20s dispatches=%d per_dispatch=%.4g %s" % (name, cname, n, tot / n, unit))
 
 
 if __name__ == "__main__":
