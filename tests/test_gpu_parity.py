@@ -254,3 +254,68 @@ def test_unconstrained_solver_path(pkg, oracle):
     assert np.abs(x - ref["x"]).max() < 1e-8 and np.abs(u - ref["u"]).max() < 1e-8
     assert (st["outer_iterations"] == 0).all()
     sol.close()
+
+
+OPTION_SETS = [
+    dict(max_iterations=3),
+    dict(max_dual_updates=2),
+    dict(min_step_size=0.3),
+    dict(constraint_tolerance=1.0e-6),
+    dict(initial_constraint_penalty=10.0, scaling_penalty=2.0, max_penalty=50.0),
+    dict(objective_tolerance=1.0e-9, lagrangian_gradient_tolerance=1.0e-9, max_iterations=20),
+    dict(line_search=0, max_iterations=4),
+    dict(reset_cache=1),
+]
+
+
+@pytest.mark.parametrize("opts", OPTION_SETS, ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
+def test_options_control_flow(pkg, oracle, opts):
+    """Every Options field that steers the solve loops (src/options.jl:1-15, src/solve.jl) must steer
+    the device loops identically: same iteration / rollout / outer counts and the same trajectories."""
+    B, T = 12, 21
+    rng = np.random.default_rng(17)
+    x1 = np.zeros((B, 3)); x1[:, :2] = 0.05 * rng.standard_normal((B, 2))
+    ub = 1.0e-2 * np.array([1.0, 0.1]) * (1.0 + 0.5 * rng.uniform(-1, 1, (B, T - 1, 1)))
+    sol = pkg.Solver(model="car", horizon=T, batch=B, options=pkg.Options(verbose=0, **opts))
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    ref = oracle.solve_batch("car", T, x1, ub, options=oracle.default_options(**opts), nthreads=4)
+    rs = ref["stats"]
+    for f in ("iterations", "outer_iterations", "rollouts", "status"):
+        assert (st[f] == rs[f]).all(), (f, st[f], rs[f])
+    assert np.abs(x - ref["x"]).max() < 1e-7 and np.abs(u - ref["u"]).max() < 1e-7
+    assert np.allclose(st["step_size"], rs["step_size"]) and np.allclose(st["objective"], rs["objective"], rtol=1e-9)
+    sol.close()
+
+
+def test_warm_start_resolve_and_minimal_horizon(pkg, oracle):
+    """solve!(solver) twice on the same solver (the second call starts from the first solution and
+    keeps the `states` buffer, Appendix A Q2), and the smallest legal horizon T = 2."""
+    B, T = 6, 31
+    model, _, x1, ub = pkg.workloads.make_inputs("particle", B)
+    ub = np.concatenate([ub, ub, ub], axis=1)[:, :T - 1]
+    sol = pkg.Solver(model="particle", horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.initialize_rollout_(x1, ub); sol.solve_(); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    pr = oracle.Problem("particle", T)
+    for b in range(B):
+        s = oracle.Solver(pr); s.initialize_controls(ub[b]); s.initialize_states(pr.rollout(x1[b], ub[b]))
+        s.solve(); s.solve()
+        xo, uo = s.get_trajectory(); so = s.stats()
+        assert (st["iterations"][b], st["outer_iterations"][b]) == (so.iterations, so.outer_iterations)
+        assert np.abs(x[b] - xo).max() < 1e-9 and np.abs(u[b] - uo).max() < 1e-9
+    sol.close()
+    sol = pkg.Solver(model="car", horizon=2, batch=3, options=pkg.Options(verbose=0))
+    x1 = np.array([[0.0, 0.0, 0.0], [0.1, 0.0, 0.2], [0.9, 0.9, 0.0]]); ub = np.full((3, 1, 2), 0.05)
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    ref = oracle.solve_batch("car", 2, x1, ub, nthreads=1)
+    assert (st["iterations"] == ref["stats"]["iterations"]).all()
+    assert np.abs(x - ref["x"]).max() < 1e-8 and np.abs(u - ref["u"]).max() < 1e-8
+    sol.close()
+
+
+def test_lds_budget_error(pkg):
+    """A horizon whose working set exceeds the 160 KiB LDS is refused loudly (no silent fallback)."""
+    with pytest.raises(pkg._ffi.IlqrError, match="LDS"):
+        pkg.Solver(model="acrobot", horizon=600, batch=2)
