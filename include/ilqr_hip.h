@@ -95,6 +95,11 @@ int ilqr_set_options(ilqr_handle* h, const ilqr_options* opt);   /* solver.optio
 int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw,
                   int32_t* nc_stage, int32_t* nc_term, int32_t* horizon, int32_t* batch);
 
+/* Solver(...; parameters = θ) — src/solver.jl:12,29, src/data/problem.jl:25-30: per-instance,
+ * per-timestep parameter vectors w: [B][T][nw] (the terminal entry is used by the terminal cost /
+ * constraint). Only for models with num_parameter > 0; zero until set; ilqr_reset keeps them. */
+int ilqr_set_parameters(ilqr_handle* h, const double* w);
+
 /* Fresh-solver state (all buffers zero, objective = Inf) — what constructing a
  * new reference Solver gives (src/data/problem.jl:32-38, src/data/solver.jl:37). */
 int ilqr_reset(ilqr_handle* h);
@@ -141,7 +146,7 @@ int ilqr_get_stats(ilqr_handle* h, ilqr_stats* stats);
  * "jacobian_action","gradient_state","gradient_action","hessian_state_state",
  * "hessian_action_action","hessian_action_state","K","k","P","p",
  * "gradient_state_lagrangian"(Qx−p),"gradient_action_lagrangian"(Qu),
- * "violations","constraint_dual","constraint_penalty","active_set".
+ * "violations","constraint_dual","constraint_penalty","active_set","parameters".
  * Layout: [B][per-instance length]; ilqr_buffer_len gives the per-instance length. */
 int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len);
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out);

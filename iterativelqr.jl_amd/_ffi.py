@@ -44,6 +44,7 @@ SYMBOLS = {
     "ilqr_destroy": (C.c_int, [C.c_void_p]),
     "ilqr_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "ilqr_get_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 7),
+    "ilqr_set_parameters": (C.c_int, [C.c_void_p, c_double_p]),
     "ilqr_reset": (C.c_int, [C.c_void_p]),
     "ilqr_initialize_controls": (C.c_int, [C.c_void_p, c_double_p]),
     "ilqr_initialize_states": (C.c_int, [C.c_void_p, c_double_p]),

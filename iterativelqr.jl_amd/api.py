@@ -107,6 +107,11 @@ class Solver:
     def initialize_rollout_device_(self, d_x1_ptr, d_u_ptr):
         _ffi.check(_ffi.lib().ilqr_initialize_rollout_device(self._h, C.c_void_p(d_x1_ptr), C.c_void_p(d_u_ptr)))
 
+    def set_parameters_(self, w):
+        """Solver(...; parameters=θ): w[b, t] is the parameter vector of timestep t of instance b."""
+        w = np.ascontiguousarray(w, dtype=np.float64).reshape(self.B, self.T, self.nw)
+        _ffi.check(_ffi.lib().ilqr_set_parameters(self._h, _p(w)))
+
     def reset_(self):
         _ffi.check(_ffi.lib().ilqr_reset(self._h))
 

@@ -8,9 +8,11 @@
 #include "models/model_acrobot.h"
 #include "models/model_car.h"
 #include "models/model_car_goal.h"
+#include "models/model_car_obs.h"
 
 ILQR_DEFINE_MODEL(Model_particle)
 ILQR_DEFINE_MODEL(Model_pendulum_euler)
 ILQR_DEFINE_MODEL(Model_acrobot)
 ILQR_DEFINE_MODEL(Model_car)
 ILQR_DEFINE_MODEL(Model_car_goal)
+ILQR_DEFINE_MODEL(Model_car_obs)

@@ -98,6 +98,7 @@ void fill_buffers(ilqr_handle* h) {
         {"gradient_state_lagrangian", L.Lx, N * n}, {"gradient_action_lagrangian", L.Lu, N * m},
         {"violations", L.c, L.C}, {"constraint_dual", L.lam, L.C},
         {"constraint_penalty", L.rho, L.C}, {"active_set", L.act, L.C},
+        {"parameters", L.w, T * L.nw},
         {"_scalars", L.scal, ilqr::S_COUNT},
     };
 }
@@ -180,7 +181,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     if (d->device < 0 || d->device >= ndev) return fail(ILQR_ERR_INVALID, "device ordinal out of range");
     ilqr_handle* h = new ilqr_handle();
     h->vt = vt; h->B = d->batch; h->device = d->device; h->constrained = d->constrained ? 1 : 0;
-    h->L = ilqr::make_layout(vt->nx, vt->nu, vt->ncs, vt->nct, d->horizon);
+    h->L = ilqr::make_layout(vt->nx, vt->nu, vt->nw, vt->ncs, vt->nct, d->horizon);
     h->lds_bytes = (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
     ilqr_default_options(&h->opt);
@@ -194,6 +195,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->ws_bytes = (size_t)h->B * (size_t)h->L.stride * 8;
     HIP_TRY(hipMalloc((void**)&h->ws, h->ws_bytes));
+    HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
     *out = h;
     int rc = ilqr_reset(h);
     if (rc != ILQR_OK) { ilqr_destroy(h); *out = nullptr; return rc; }
@@ -235,7 +237,14 @@ int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw, i
 int ilqr_reset(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
+    if (h->vt->nw == 0) {
+        HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
+    } else {
+        // keep the parameters θ (they belong to the problem, not to the solver state)
+        const size_t pitch = (size_t)h->L.stride * 8, w0 = (size_t)h->L.w * 8, w1 = (size_t)h->L.zslot * 8;
+        HIP_TRY(hipMemset2DAsync(h->ws, pitch, 0, w0, (size_t)h->B, h->stream));
+        HIP_TRY(hipMemset2DAsync((char*)h->ws + w1, pitch, 0, pitch - w1, (size_t)h->B, h->stream));
+    }
     ilqr::KArgs a = make_args(h);
     hipLaunchKernelGGL(ilqr::defaults_kernel, dim3(h->B), dim3(64), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
@@ -249,6 +258,12 @@ int ilqr_initialize_controls(ilqr_handle* h, const double* u) {
 int ilqr_initialize_states(ilqr_handle* h, const double* x) {
     if (!h || !x) return fail(ILQR_ERR_INVALID, "null argument");
     return copy_in(h, find_buffer(h, "nominal_states"), x);
+}
+
+int ilqr_set_parameters(ilqr_handle* h, const double* w) {
+    if (!h || !w) return fail(ILQR_ERR_INVALID, "null argument");
+    if (h->vt->nw == 0) return fail(ILQR_ERR_INVALID, "this model has no parameters (num_parameter == 0)");
+    return copy_in(h, find_buffer(h, "parameters"), w);
 }
 
 int ilqr_initialize_rollout_device(ilqr_handle* h, const double* d_x1, const double* d_u) {

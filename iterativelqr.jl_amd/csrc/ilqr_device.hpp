@@ -60,6 +60,14 @@ __device__ __forceinline__ double nanmax(double a, double b) { return (b > a || 
 
 template <int N_> struct cdim { static constexpr int v = N_ > 0 ? N_ : 1; };
 
+// parameters of timestep t (empty when NW == 0)
+template <int NW>
+__device__ __forceinline__ void load_w(const double* W, int t, double (&w)[cdim<NW>::v]) {
+    w[0] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = W[t * NW + i];
+}
+
 // Optional per-phase cycle accounting (build with -DILQR_PROFILE): shader-clock
 // ticks (s_memtime) spent in each phase are accumulated per instance and written
 // to scalar slots S_PROF.. of the workspace (tools/phase_cycles.py prints them).
@@ -78,6 +86,7 @@ template <class M>
 struct Inst {
     static constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     double *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act;
+    const double* w;       // parameters θ_t (problem.parameters, src/data/problem.jl:25-30), T x NW
     double *gxx, *guu, *gux, *P, *p, *scal;
     double *zs;            // LDS: zs[0] == 0.0 always, zs[1] is a write-only trash slot
     const double* gzero;   // HBM: a 0.0
@@ -99,8 +108,9 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     ILQR_PROF_BEGIN();
     double Jp = 0.0, vp = 0.0;
-    const double w[cdim<M::NW>::v] = {0.0};
     for (int t = I.lane; t < I.T; t += 64) {
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(I.w, t, w);
         double xt[n];
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = X[t * n + i];
@@ -204,8 +214,9 @@ template <class M>
 __device__ void gradients(Inst<M>& I, bool constrained) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     ILQR_PROF_BEGIN();
-    const double w[cdim<M::NW>::v] = {0.0};
     for (int t = I.lane; t < I.T; t += 64) {
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(I.w, t, w);
         double xt[n];
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = I.xb[t * n + i];
@@ -808,7 +819,6 @@ __device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& 
     constexpr int n = M::NX, m = M::NU;
     constexpr bool MF = (n <= 4 && m <= 4);
     ILQR_PROF_BEGIN();
-    const double w[cdim<M::NW>::v] = {0.0};
     double xt[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) xt[i] = I.xb[i];                      // (:19)
@@ -869,6 +879,8 @@ __device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& 
             v += -1.0 * a2;                                           // (:28)
             ut[i] = v;
         }
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(I.w, t, w);
         M::dyn_wave(I.lane, xin, ut, w, xout);                        // (:29)
         if (I.lane == 0) {
 #pragma unroll
@@ -1069,7 +1081,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.fx = smem + L.fx; I.fu = smem + L.fu; I.gx = smem + L.gx; I.gu = smem + L.gu;
     I.K = smem + L.K; I.k = smem + L.k; I.Lx = smem + L.Lx; I.Lu = smem + L.Lu;
     I.c = smem + L.c; I.lam = smem + L.lam; I.rho = smem + L.rho; I.act = smem + L.act;
-    I.zs = smem + L.zslot; I.gzero = g + L.gzero;
+    I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x;
     // LDS-resident set: one coalesced 16-B-per-lane stream from HBM
@@ -1158,7 +1170,6 @@ __global__ __launch_bounds__(64) void init_rollout_kernel(KArgs a) {
     const Layout& L = a.L;
     double* g = a.ws + (size_t)b * (size_t)L.stride;
     const int N = L.T - 1;
-    const double w[cdim<M::NW>::v] = {0.0};
     double xt[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) { xt[i] = a.x1[(size_t)b * n + i]; g[L.xb + i] = xt[i]; }
@@ -1166,6 +1177,8 @@ __global__ __launch_bounds__(64) void init_rollout_kernel(KArgs a) {
         double ut[m], y[n];
 #pragma unroll
         for (int i = 0; i < m; ++i) { ut[i] = a.u_in[((size_t)b * N + t) * m + i]; g[L.ub + t * m + i] = ut[i]; }
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(g + L.w, t, w);
         M::dyn(xt, ut, w, y);
 #pragma unroll
         for (int i = 0; i < n; ++i) { xt[i] = y[i]; g[L.xb + (t + 1) * n + i] = y[i]; }

@@ -16,10 +16,10 @@ enum {
 };
 
 struct Layout {
-    int T, nx, nu, ncs, nct;
+    int T, nx, nu, nw, ncs, nct;
     int C;   // total number of constraints over the horizon
     // offsets (in doubles) inside one instance block
-    int xb, ub, x, u, fx, fu, gx, gu, K, k, Lx, Lu, c, lam, rho, act;   // LDS-resident set
+    int xb, ub, x, u, fx, fu, gx, gu, K, k, Lx, Lu, c, lam, rho, act, w;   // LDS-resident set (w: parameters θ_t)
     int zslot;                                                          // [0] always 0.0, [1] write-only trash
     int lds_doubles;                                                    // size of that set
     int gxx, guu, gux, P, p, scal, gzero;                               // HBM-only set (gzero: a 0.0)
@@ -28,10 +28,10 @@ struct Layout {
 
 inline __host__ __device__ int pad2(int v) { return (v + 1) & ~1; }   // keep 16-B alignment
 
-inline __host__ __device__ Layout make_layout(int nx, int nu, int ncs, int nct, int T) {
+inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, int nct, int T) {
     Layout L;
     const int N = T - 1;
-    L.T = T; L.nx = nx; L.nu = nu; L.ncs = ncs; L.nct = nct;
+    L.T = T; L.nx = nx; L.nu = nu; L.nw = nw; L.ncs = ncs; L.nct = nct;
     L.C = N * ncs + nct;
     int o = 0;
     L.xb = o; o += pad2(T * nx);
@@ -50,6 +50,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int ncs, int nct, 
     L.lam = o; o += pad2(L.C);
     L.rho = o; o += pad2(L.C);
     L.act = o; o += pad2(L.C);
+    L.w = o; o += pad2(T * nw);
     L.zslot = o; o += 2;
     L.lds_doubles = o;
     L.gxx = o; o += pad2(T * nx * nx);

@@ -10,7 +10,7 @@
 # are passed as (nx, T, B) / (nu, T-1, B) column-major views of the same memory).
 module IterativeLQRAMD
 
-export Options, Solver, initialize_controls!, initialize_states!, initialize_rollout!,
+export Options, Solver, initialize_controls!, initialize_states!, initialize_rollout!, set_parameters!,
        solve!, get_trajectory, get_policy, stats
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "lib", "libilqr_hip.so"))
@@ -107,6 +107,11 @@ end
 function initialize_rollout!(s::Solver, x1::Matrix{Float64}, u::Array{Float64,3})
     @assert size(x1) == (s.nx, s.B) && size(u) == (s.nu, s.T - 1, s.B)
     check(ccall((:ilqr_initialize_rollout, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), s.handle, x1, u))
+end
+
+# Solver(...; parameters = θ) — src/solver.jl:12,29; θ :: (nw, T, B)
+function set_parameters!(s::Solver, w::Array{Float64,3})
+    check(ccall((:ilqr_set_parameters, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}), s.handle, w))
 end
 
 # solve!(solver[, states, actions]) — src/solve.jl:137-143, 131-135

@@ -130,12 +130,42 @@ def car(goal_only=False):
     return d
 
 
+def car_obs():
+    """car with the obstacle centre as a per-timestep parameter θ_t = (p_x, p_y) (README.md:19,28 of the
+    reference: "parameters"); everything else as test/car.jl."""
+    xT = [1.0, 1.0, 0.0]
+    ul, uu, r_obs = [-5.0, -5.0], [5.0, 5.0], 0.1
+
+    def e(x, w):
+        return [x[0] - w[0], x[1] - w[1]]
+
+    def stage(x, u, w):
+        ee = e(x, w)
+        return [ul[0] - u[0], ul[1] - u[1], u[0] - uu[0], u[1] - uu[1], r_obs ** 2.0 - _dot(ee, ee)]
+
+    def term(x, u, w):
+        ee = e(x, w)
+        return [x[0] - xT[0], x[1] - xT[1], x[2] - xT[2], r_obs ** 2.0 - _dot(ee, ee)]
+
+    fm = _midpoint(car_continuous, 3, 0.1)
+    return dict(
+        dynamics=Dynamics(lambda x, u, w: fm(x, u), 3, 2, num_parameter=2),
+        cost_stage=Cost(lambda x, u, w: 1.0 * _dot([x[i] - xT[i] for i in range(3)], [x[i] - xT[i] for i in range(3)])
+                        + 1.0e-2 * _dot(u, u), 3, 2, num_parameter=2),
+        cost_term=Cost(lambda x, u, w: 1000.0 * _dot([x[i] - xT[i] for i in range(3)], [x[i] - xT[i] for i in range(3)]),
+                       3, 0, num_parameter=2),
+        con_stage=Constraint(stage, 3, 2, indices_inequality=[1, 2, 3, 4, 5], num_parameter=2),
+        con_term=Constraint(term, 3, 0, indices_inequality=[4], num_parameter=2),
+    )
+
+
 BUILTIN = {
     "particle": particle,
     "pendulum_euler": pendulum_euler,
     "acrobot": acrobot,
     "car": car,
     "car_goal": lambda: car(goal_only=True),
+    "car_obs": car_obs,
 }
 
 

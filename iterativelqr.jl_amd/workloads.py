@@ -11,8 +11,10 @@ CONFIGS = {
     "acrobot51": ("acrobot", 51, True),
     "car": ("car", 51, True),
     "car_goal": ("car_goal", 51, True),
+    "car_obs": ("car_obs", 51, True),
 }
-DIMS = {"particle": (2, 1), "acrobot": (4, 1), "car": (3, 2), "car_goal": (3, 2), "pendulum_euler": (2, 1)}
+DIMS = {"particle": (2, 1), "acrobot": (4, 1), "car": (3, 2), "car_goal": (3, 2), "car_obs": (3, 2),
+        "pendulum_euler": (2, 1)}
 
 
 def make_inputs(config, batch, seed=SEED, offset=0):
@@ -28,9 +30,23 @@ def make_inputs(config, batch, seed=SEED, offset=0):
             ub[b] = 0.1 * rng.standard_normal((T - 1, m))          # examples/particle.jl:30
         elif model == "acrobot":
             ub[b] = 1.0 * rng.standard_normal((T - 1, m))          # test/acrobot.jl:88
-        elif model in ("car", "car_goal"):
+        elif model in ("car", "car_goal", "car_obs"):
             ub[b] = 1.0e-2 * np.array([1.0, 0.1])                  # test/car.jl:28
             if offset + b > 0:
                 ub[b] *= 1.0 + 0.5 * rng.uniform(-1.0, 1.0)
                 x1[b, :2] = 0.05 * rng.standard_normal(2)
     return model, T, x1, ub
+
+
+def make_parameters(config, batch, seed=SEED, offset=0):
+    """Per-instance parameter trajectories θ[b, t, :] for parametrised models (car_obs: obstacle centre,
+    drifting slowly along the horizon)."""
+    model, T, _ = CONFIGS[config]
+    assert model == "car_obs"
+    w = np.zeros((batch, T, 2))
+    for b in range(batch):
+        rng = np.random.default_rng([seed, 7, offset + b])
+        c0 = np.array([0.5, 0.5]) + 0.1 * rng.uniform(-1, 1, 2)
+        drift = 0.05 * rng.uniform(-1, 1, 2)
+        w[b] = c0 + np.linspace(0.0, 1.0, T)[:, None] * drift
+    return w

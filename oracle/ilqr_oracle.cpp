@@ -714,10 +714,23 @@ extern "C" double* orc_buffer(OrcSolver* s, const char* name, int* len) {
 }
 
 // ------------------------------------------------------------- batch driver
+extern "C" int orc_solve_batch_w(const char* model, int T, int B, const double* x1,
+                                 const double* ubar, const double* w, const OrcOptions* opts, int nthreads,
+                                 double* x_out, double* u_out, double* K_out, double* k_out,
+                                 OrcStats* stats_out);
+
 extern "C" int orc_solve_batch(const char* model, int T, int B, const double* x1,
                                const double* ubar, const OrcOptions* opts, int nthreads,
                                double* x_out, double* u_out, double* K_out, double* k_out,
                                OrcStats* stats_out) {
+    return orc_solve_batch_w(model, T, B, x1, ubar, nullptr, opts, nthreads, x_out, u_out, K_out, k_out, stats_out);
+}
+
+// same with per-instance parameters w: [B][T][nw] (Solver(...; parameters=θ), src/solver.jl:12,29)
+extern "C" int orc_solve_batch_w(const char* model, int T, int B, const double* x1,
+                                 const double* ubar, const double* w, const OrcOptions* opts, int nthreads,
+                                 double* x_out, double* u_out, double* K_out, double* k_out,
+                                 OrcStats* stats_out) {
     OrcProblem prob;
     if (orc_problem_builtin(model, T, &prob) != 0) return -1;
     const int n = prob.nx, m = prob.nu, N = T - 1;
@@ -725,14 +738,15 @@ extern "C" int orc_solve_batch(const char* model, int T, int B, const double* x1
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int b = 0; b < B; ++b) {
-        OrcSolver* s = orc_solver_create(T, prob.dynamics, prob.costs, prob.constraints, nullptr, opts);
+        const double* wb = (w && prob.nw > 0) ? w + (size_t)b * T * prob.nw : nullptr;
+        OrcSolver* s = orc_solver_create(T, prob.dynamics, prob.costs, prob.constraints, wb, opts);
         if (!s) {
 #pragma omp atomic write
             fail = 1;
             continue;
         }
         std::vector<double> xbar(T * n);
-        orc_rollout(T, prob.dynamics, x1 + (size_t)b * n, ubar + (size_t)b * N * m, nullptr, xbar.data());
+        orc_rollout(T, prob.dynamics, x1 + (size_t)b * n, ubar + (size_t)b * N * m, wb, xbar.data());
         orc_initialize_controls(s, ubar + (size_t)b * N * m);
         orc_initialize_states(s, xbar.data());
         orc_solve(s);

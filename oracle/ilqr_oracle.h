@@ -149,7 +149,7 @@ typedef struct {
     void* owner;                             /* internal */
 } OrcProblem;
 
-/* name: "particle","acrobot","car","car_goal","synth32","pendulum_euler",
+/* name: "particle","acrobot","car","car_goal","car_obs"(nw=2),"synth32","pendulum_euler",
  * "kat_objective","kat_constraints","acrobot_unconstrained".
  * Returns 0 on success. The arrays live until orc_problem_free. */
 int orc_problem_builtin(const char* name, int T, OrcProblem* out);
@@ -162,6 +162,12 @@ int orc_solve_batch(const char* model, int T, int B, const double* x1,
                     const double* ubar, const OrcOptions* opts, int nthreads,
                     double* x_out, double* u_out, double* K_out, double* k_out,
                     OrcStats* stats_out);
+
+/* same with per-instance parameters w: [B][T][nw] (Solver(...; parameters = θ), src/solver.jl:12,29) */
+int orc_solve_batch_w(const char* model, int T, int B, const double* x1,
+                      const double* ubar, const double* w, const OrcOptions* opts, int nthreads,
+                      double* x_out, double* u_out, double* K_out, double* k_out,
+                      OrcStats* stats_out);
 
 #ifdef __cplusplus
 }

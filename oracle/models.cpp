@@ -286,6 +286,27 @@ void car_term_jx(double* out, const double* x, const double*, const double*, con
     out[0 * 4 + 3] = -2.0 * (x[0] - CAR_PX);
     out[1 * 4 + 3] = -2.0 * (x[1] - CAR_PY);
 }
+// car_obs: the obstacle centre is the per-timestep parameter w = (p_x, p_y)
+void carobs_stage_eval(double* out, const double* x, const double* u, const double* w, const void*) {
+    double e0 = x[0] - w[0], e1 = x[1] - w[1];
+    out[0] = CAR_UL - u[0]; out[1] = CAR_UL - u[1];
+    out[2] = u[0] - CAR_UU; out[3] = u[1] - CAR_UU;
+    out[4] = CAR_R * CAR_R - (e0 * e0 + e1 * e1);
+}
+void carobs_stage_jx(double* out, const double* x, const double*, const double* w, const void*) {
+    out[0 * 5 + 4] = -2.0 * (x[0] - w[0]);
+    out[1 * 5 + 4] = -2.0 * (x[1] - w[1]);
+}
+void carobs_term_eval(double* out, const double* x, const double*, const double* w, const void*) {
+    double e0 = x[0] - w[0], e1 = x[1] - w[1];
+    for (int i = 0; i < 3; ++i) out[i] = x[i] - CAR_XT[i];
+    out[3] = CAR_R * CAR_R - (e0 * e0 + e1 * e1);
+}
+void carobs_term_jx(double* out, const double* x, const double*, const double* w, const void*) {
+    out[0 * 4 + 0] = 1.0; out[1 * 4 + 1] = 1.0; out[2 * 4 + 2] = 1.0;
+    out[0 * 4 + 3] = -2.0 * (x[0] - w[0]);
+    out[1 * 4 + 3] = -2.0 * (x[1] - w[1]);
+}
 // state box [−1 − x; x − 1] (test/constraints.jl:13), all inequality
 struct BoxCtx { int n; };
 void xbox_eval(double* out, const double* x, const double*, const double*, const void* ctx) {
@@ -360,8 +381,9 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
         z->kt.evaluate = goal_eval; z->kt.jacobian_state = goal_jx; z->kt.num_constraint = 4;
         z->kt.num_state = 4; z->kt.ctx = &z->goal;
         if (!std::strcmp(name, "acrobot_unconstrained")) constrained = false;
-    } else if (!std::strcmp(name, "car") || !std::strcmp(name, "car_goal")) {
+    } else if (!std::strcmp(name, "car") || !std::strcmp(name, "car_goal") || !std::strcmp(name, "car_obs")) {
         z->dyn = make_dynamics<3, 2, CarF>();
+        if (!std::strcmp(name, "car_obs")) z->dyn.num_parameter = 2;
         quad_init(&z->qs, 3, 2); quad_init(&z->qt, 3, 0);
         for (int i = 0; i < 3; ++i) { z->qs.q[i] = 1.0; z->qt.q[i] = 1000.0; z->qs.xg[i] = CAR_XT[i]; z->qt.xg[i] = CAR_XT[i]; }
         z->qs.r[0] = z->qs.r[1] = 1.0e-2;
@@ -370,6 +392,13 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
             z->ks.num_constraint = 5; z->ks.num_state = 3; z->ks.num_action = 2;
             z->ks.num_inequality = 5; for (int i = 0; i < 5; ++i) z->ks.indices_inequality[i] = i;
             z->kt.evaluate = car_term_eval; z->kt.jacobian_state = car_term_jx;
+            z->kt.num_constraint = 4; z->kt.num_state = 3;
+            z->kt.num_inequality = 1; z->kt.indices_inequality[0] = 3;
+        } else if (!std::strcmp(name, "car_obs")) {
+            z->ks.evaluate = carobs_stage_eval; z->ks.jacobian_state = carobs_stage_jx; z->ks.jacobian_action = car_stage_ju;
+            z->ks.num_constraint = 5; z->ks.num_state = 3; z->ks.num_action = 2;
+            z->ks.num_inequality = 5; for (int i = 0; i < 5; ++i) z->ks.indices_inequality[i] = i;
+            z->kt.evaluate = carobs_term_eval; z->kt.jacobian_state = carobs_term_jx;
             z->kt.num_constraint = 4; z->kt.num_state = 3;
             z->kt.num_inequality = 1; z->kt.indices_inequality[0] = 3;
         } else {   // goal-only variant (BASELINE.json configs[2])
@@ -411,7 +440,7 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
     z->ct = make_quad_cost(&z->qt);
     for (int t = 0; t < T - 1; ++t) { z->dptr.push_back(&z->dyn); z->cptr.push_back(&z->cs); z->kptr.push_back(&z->ks); }
     z->cptr.push_back(&z->ct); z->kptr.push_back(&z->kt);
-    out->T = T; out->nx = z->dyn.num_state; out->nu = z->dyn.num_action; out->nw = 0;
+    out->T = T; out->nx = z->dyn.num_state; out->nu = z->dyn.num_action; out->nw = z->dyn.num_parameter;
     out->dynamics = z->dptr.data(); out->costs = z->cptr.data();
     out->constraints = constrained ? z->kptr.data() : nullptr;
     out->owner = z;

@@ -89,6 +89,10 @@ def lib():
         L.orc_solve_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(OrcOptions),
                                       C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(OrcStats)]
         L.orc_solve_batch.restype = C.c_int
+        L.orc_solve_batch_w.argtypes = [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p,
+                                        C.POINTER(OrcOptions), C.c_int, c_double_p, c_double_p, c_double_p,
+                                        c_double_p, C.POINTER(OrcStats)]
+        L.orc_solve_batch_w.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -115,12 +119,13 @@ class Problem:
             raise ValueError("unknown oracle model %r" % name)
         self.nx, self.nu = self.c.nx, self.c.nu
 
-    def rollout(self, x1, u):
-        """rollout(dynamics, x1, ū) — src/rollout.jl:33-42."""
+    def rollout(self, x1, u, w=None):
+        """rollout(dynamics, x1, ū[, parameters]) — src/rollout.jl:33-42."""
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
         u = np.ascontiguousarray(u, dtype=np.float64)
+        w = np.ascontiguousarray(w, dtype=np.float64) if w is not None else None
         x = np.zeros((self.T, self.nx))
-        lib().orc_rollout(self.T, self.c.dynamics, _p(x1), _p(u), None, _p(x))
+        lib().orc_rollout(self.T, self.c.dynamics, _p(x1), _p(u), _p(w), _p(x))
         return x
 
     def __del__(self):
@@ -133,11 +138,12 @@ class Problem:
 class Solver:
     """Solver(dynamics, costs, constraints) of the oracle — src/solver.jl:28-46."""
 
-    def __init__(self, problem, options=None):
+    def __init__(self, problem, options=None, w=None):
         self.problem = problem
         self.opt = options if options is not None else default_options()
+        w = np.ascontiguousarray(w, dtype=np.float64) if w is not None else None
         self.h = lib().orc_solver_create(problem.T, problem.c.dynamics, problem.c.costs, problem.c.constraints,
-                                         None, C.byref(self.opt))
+                                         _p(w), C.byref(self.opt))
         if not self.h:
             raise RuntimeError("orc_solver_create failed")
         self._trace = None
@@ -196,7 +202,7 @@ class Solver:
             pass
 
 
-def solve_batch(model, T, x1, ubar, options=None, nthreads=1, want_policy=True):
+def solve_batch(model, T, x1, ubar, options=None, nthreads=1, want_policy=True, w=None):
     """CPU baseline / batch oracle: returns dict(x,u,K,k,stats)."""
     pr = Problem(model, T)
     n, m = pr.nx, pr.nu
@@ -208,8 +214,10 @@ def solve_batch(model, T, x1, ubar, options=None, nthreads=1, want_policy=True):
     K = np.zeros((B, T - 1, n, m)) if want_policy else None   # column-major m×n per step → [n][m]
     k = np.zeros((B, T - 1, m)) if want_policy else None
     st = (OrcStats * B)()
-    rc = lib().orc_solve_batch(model.encode(), T, B, _p(x1), _p(ubar), C.byref(opt), nthreads,
-                               _p(x), _p(u), _p(K), _p(k), st)
+    if w is not None:
+        w = np.ascontiguousarray(w, dtype=np.float64).reshape(B, T, pr.c.nw)
+    rc = lib().orc_solve_batch_w(model.encode(), T, B, _p(x1), _p(ubar), _p(w), C.byref(opt), nthreads,
+                                 _p(x), _p(u), _p(K), _p(k), st)
     if rc != 0:
         raise RuntimeError("orc_solve_batch rc=%d" % rc)
     stats = {f: np.array([getattr(s, f) for s in st]) for f, _ in OrcStats._fields_}

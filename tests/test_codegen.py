@@ -22,42 +22,38 @@ using std::sin; using std::cos; using std::fma; using std::fabs; using std::rint
 #include "%(header)s"
 typedef %(struct)s M;
 template <int N> struct cd { static const int v = N > 0 ? N : 1; };
+static double g_w[16] = {0};
+#define LOADXU double xx[M::NX], uu[cd<M::NU>::v], w[cd<M::NW>::v]; \
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i]; for (int i=0;i<cd<M::NW>::v;++i) w[i]=g_w[i];
+#define LOADX double xx[M::NX], w[cd<M::NW>::v]; \
+  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<cd<M::NW>::v;++i) w[i]=g_w[i];
 extern "C" {
-int dims(int* o) { o[0]=M::NX; o[1]=M::NU; o[2]=M::NCS; o[3]=M::NCT; return 0; }
+void set_w(const double* w, int n) { for (int i = 0; i < n; ++i) g_w[i] = w[i]; }
+int dims(int* o) { o[0]=M::NX; o[1]=M::NU; o[2]=M::NCS; o[3]=M::NCT; o[4]=M::NW; return 0; }
 unsigned long long ineq(int term) { return term ? M::INEQ_T : M::INEQ_S; }
-void dyn(const double* x, const double* u, double* y) {
-  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, yy[M::NX];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
-  M::dyn(xx,uu,w,yy); for (int i=0;i<M::NX;++i) y[i]=yy[i]; }
-void dyn_jac(const double* x, const double* u, double* fx, double* fu) {
-  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[M::NX*M::NX], b[M::NX*cd<M::NU>::v];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+void dyn(const double* x, const double* u, double* y) { LOADXU
+  double yy[M::NX]; M::dyn(xx,uu,w,yy); for (int i=0;i<M::NX;++i) y[i]=yy[i]; }
+void dyn_jac(const double* x, const double* u, double* fx, double* fu) { LOADXU
+  double a[M::NX*M::NX], b[M::NX*cd<M::NU>::v];
   M::dyn_jac(xx,uu,w,a,b); for (int i=0;i<M::NX*M::NX;++i) fx[i]=a[i]; for (int i=0;i<M::NX*M::NU;++i) fu[i]=b[i]; }
-double cost_s(const double* x, const double* u) {
-  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0};
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i]; return M::cost_s(xx,uu,w); }
-double cost_t(const double* x) { double xx[M::NX], w[1]={0}; for (int i=0;i<M::NX;++i) xx[i]=x[i]; return M::cost_t(xx,w); }
-void cost_s_grad(const double* x, const double* u, double* gx, double* gu) {
-  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[M::NX], b[cd<M::NU>::v];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+double cost_s(const double* x, const double* u) { LOADXU return M::cost_s(xx,uu,w); }
+double cost_t(const double* x) { LOADX return M::cost_t(xx,w); }
+void cost_s_grad(const double* x, const double* u, double* gx, double* gu) { LOADXU
+  double a[M::NX], b[cd<M::NU>::v];
   M::cost_s_grad(xx,uu,w,a,b); for (int i=0;i<M::NX;++i) gx[i]=a[i]; for (int i=0;i<M::NU;++i) gu[i]=b[i]; }
-void cost_s_hess(const double* x, const double* u, double* gxx, double* guu, double* gux) {
-  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[M::NX*M::NX], b[cd<M::NU*M::NU>::v], c[cd<M::NU*M::NX>::v];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+void cost_s_hess(const double* x, const double* u, double* gxx, double* guu, double* gux) { LOADXU
+  double a[M::NX*M::NX], b[cd<M::NU*M::NU>::v], c[cd<M::NU*M::NX>::v];
   M::cost_s_hess(xx,uu,w,a,b,c); for (int i=0;i<M::NX*M::NX;++i) gxx[i]=a[i];
   for (int i=0;i<M::NU*M::NU;++i) guu[i]=b[i]; for (int i=0;i<M::NU*M::NX;++i) gux[i]=c[i]; }
-void con_s(const double* x, const double* u, double* c) {
-  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, cc[cd<M::NCS>::v];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
-  M::con_s(xx,uu,w,cc); for (int i=0;i<M::NCS;++i) c[i]=cc[i]; }
-void con_s_jac(const double* x, const double* u, double* cx, double* cu) {
-  double xx[M::NX], uu[cd<M::NU>::v], w[1] = {0}, a[cd<M::NCS*M::NX>::v], b[cd<M::NCS*M::NU>::v];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; for (int i=0;i<M::NU;++i) uu[i]=u[i];
+void con_s(const double* x, const double* u, double* c) { LOADXU
+  double cc[cd<M::NCS>::v]; M::con_s(xx,uu,w,cc); for (int i=0;i<M::NCS;++i) c[i]=cc[i]; }
+void con_s_jac(const double* x, const double* u, double* cx, double* cu) { LOADXU
+  double a[cd<M::NCS*M::NX>::v], b[cd<M::NCS*M::NU>::v];
   M::con_s_jac(xx,uu,w,a,b); for (int i=0;i<M::NCS*M::NX;++i) cx[i]=a[i]; for (int i=0;i<M::NCS*M::NU;++i) cu[i]=b[i]; }
-void con_t(const double* x, double* c) { double xx[M::NX], w[1]={0}, cc[cd<M::NCT>::v];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; M::con_t(xx,w,cc); for (int i=0;i<M::NCT;++i) c[i]=cc[i]; }
-void con_t_jac(const double* x, double* cx) { double xx[M::NX], w[1]={0}, a[cd<M::NCT*M::NX>::v];
-  for (int i=0;i<M::NX;++i) xx[i]=x[i]; M::con_t_jac(xx,w,a); for (int i=0;i<M::NCT*M::NX;++i) cx[i]=a[i]; }
+void con_t(const double* x, double* c) { LOADX
+  double cc[cd<M::NCT>::v]; M::con_t(xx,w,cc); for (int i=0;i<M::NCT;++i) c[i]=cc[i]; }
+void con_t_jac(const double* x, double* cx) { LOADX
+  double a[cd<M::NCT*M::NX>::v]; M::con_t_jac(xx,w,a); for (int i=0;i<M::NCT*M::NX;++i) cx[i]=a[i]; }
 }
 '''
 
@@ -79,24 +75,27 @@ def _p(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
-@pytest.mark.parametrize("model", ["particle", "pendulum_euler", "acrobot", "car", "car_goal"])
+@pytest.mark.parametrize("model", ["particle", "pendulum_euler", "acrobot", "car", "car_goal", "car_obs"])
 def test_generated_builtin_matches_oracle(tmp_path, oracle, model):
     hdr = os.path.join(ROOT, "iterativelqr.jl_amd", "csrc", "models", "model_%s.h" % model)
     L = _build(tmp_path, hdr, "Model_" + model)
-    d = (ctypes.c_int * 4)(); L.dims(d)
-    n, m, ncs, nct = list(d)
+    d = (ctypes.c_int * 5)(); L.dims(d)
+    n, m, ncs, nct, nw = list(d)
     T = 3
     pr = oracle.Problem(model, T)
-    assert (pr.nx, pr.nu) == (n, m)
+    assert (pr.nx, pr.nu, pr.c.nw) == (n, m, nw)
     rng = np.random.default_rng(2)
     for trial in range(5):
         x = rng.standard_normal((T, n)) * (1.0 if trial else 3.0); u = rng.standard_normal((T - 1, m))
-        s = oracle.Solver(pr); s.initialize_states(x); s.initialize_controls(u)
+        w = np.tile(rng.standard_normal((1, nw)), (T, 1)) if nw else None     # same θ at every step for this check
+        if nw:
+            L.set_w(_p(np.ascontiguousarray(w[0])), nw)
+        s = oracle.Solver(pr, w=w); s.initialize_states(x); s.initialize_controls(u)
         s.set_buffer("states", x); s.set_buffer("actions", u)
         s.call("reset_model_objective"); s.call("cost_bang", 0); s.call("gradients")
         # dynamics value and Jacobians
         y = np.zeros(n); L.dyn(_p(x[0]), _p(u[0]), _p(y))
-        assert np.allclose(y, pr.rollout(x[0], u)[1], rtol=1e-13, atol=1e-14)
+        assert np.allclose(y, pr.rollout(x[0], u, w)[1], rtol=1e-13, atol=1e-14)
         fx = np.zeros(n * n); fu = np.zeros(n * m); L.dyn_jac(_p(x[0]), _p(u[0]), _p(fx), _p(fu))
         assert np.allclose(fx, s.buffer("jacobian_state")[:n * n], rtol=1e-11, atol=1e-12)
         assert np.allclose(fu, s.buffer("jacobian_action")[:n * m], rtol=1e-11, atol=1e-12)

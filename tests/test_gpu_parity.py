@@ -319,3 +319,29 @@ def test_lds_budget_error(pkg):
     """A horizon whose working set exceeds the 160 KiB LDS is refused loudly (no silent fallback)."""
     with pytest.raises(pkg._ffi.IlqrError, match="LDS"):
         pkg.Solver(model="acrobot", horizon=600, batch=2)
+
+
+def test_parameters_car_obs(pkg, oracle):
+    """Solver(...; parameters = θ) (src/solver.jl:12,29): per-instance, per-timestep obstacle centres."""
+    B = 128
+    model, T, x1, ub = pkg.workloads.make_inputs("car_obs", B)
+    w = pkg.workloads.make_parameters("car_obs", B)
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    assert sol.nw == 2
+    sol.set_parameters_(w)
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    ref = oracle.solve_batch(model, T, x1, ub, w=w, nthreads=8)
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.9
+    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    # the obstacle constraint is met w.r.t. each instance's own (moving) obstacle
+    e = x[:, :-1, :2] - w[:, :-1, :]
+    assert ((0.01 - (e * e).sum(-1)) <= 5e-3)[st["max_violation"] <= 5e-3].all()
+    # parameters survive a fresh-solver reset; a second solve reproduces the first bit for bit
+    sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()
+    x2, _ = sol.get_trajectory()
+    assert np.array_equal(x, x2)
+    with pytest.raises(pkg._ffi.IlqrError, match="no parameters"):
+        s2 = pkg.Solver(model="car", horizon=T, batch=2); s2.set_parameters_(np.zeros((2, T, 0)))
+    sol.close()
