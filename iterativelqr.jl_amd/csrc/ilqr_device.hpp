@@ -670,10 +670,12 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
     const double* puu = vmm ? I.guu + (N - 1) * m * m + c * m + r : I.gzero;
     const double* pux = vmn ? I.gux + (N - 1) * m * n + c * m + r : I.gzero;
     const bool b0 = blk == 0;
+#if ILQR_BW_PTR_STORES
     double* qK = (b0 && vmn) ? I.K + (N - 1) * m * n + c * m + r : I.zs + 1;   const int sK = (b0 && vmn) ? m * n : 0;
     double* qk = (b0 && vm1) ? I.k + (N - 1) * m + r : I.zs + 1;               const int sk = (b0 && vm1) ? m : 0;
     double* qLu = (b0 && vm1) ? I.Lu + (N - 1) * m + r : I.zs + 1;
     double* qLx = (b0 && vn1) ? I.Lx + (N - 1) * n + r : I.zs + 1;             const int sLx = (b0 && vn1) ? n : 0;
+#endif
 
     double P = vnn ? I.gxx[N * n * n + c * n + r] : 0.0;               // P[H] .= gxx[H]  (:39)
     double p = vn1 ? I.gx[N * n + r] : 0.0;                            // p[H] .= gx[H]   (:40)
@@ -828,11 +830,10 @@ __device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& 
     }
     // sensitivity state (MFMA layout: element (r, c) on lane c + 4*blk + 16*r, vectors in column 0)
     const int lane = I.lane, r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
-    const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
     const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n;
     const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m;
     double zx = 0.0, dacc = 0.0;
-    (void)blk; (void)rn; (void)cn; (void)rm; (void)cm; (void)vnn; (void)vnm; (void)vmn; (void)vn1; (void)vm1;
+    (void)blk;
     // policy operands of step t are fetched from LDS one step ahead so that their latency
     // hides under the previous step's dynamics chain; the loop is unrolled by two with
     // ping-pong operand sets so that no register copies are needed
@@ -845,23 +846,21 @@ __device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& 
 #pragma unroll
         for (int i = 0; i < n; ++i) o.xb[i] = I.xb[t * n + i];
     };
+    // Sensitivity operands, transposed straight from LDS (mfma(A<-X^T, B<-v, C) = X v + C), through
+    // per-lane pointers that walk forward in time; padding lanes aim at the zero slot with stride 0.
+    const double* pKT = (MF && vnm) ? I.K + r * m + c : I.zs;     const int sKT = (MF && vnm) ? m * n : 0;   // K^T(r,c) = K(c,r)
+    const double* pfxT = (MF && vnn) ? I.fx + r * n + c : I.zs;   const int sfxT = (MF && vnn) ? n * n : 0;  // fx^T(r,c) = fx(c,r)
+    const double* pfuT = (MF && vmn) ? I.fu + r * n + c : I.zs;   const int sfuT = (MF && vmn) ? n * m : 0;  // fu^T(r,c) = fu(c,r)
+    const double* pkc = (MF && vm1) ? I.k + r : I.zs;             const int skc = (MF && vm1) ? m : 0;
+    const double* pLx = (MF && vn1) ? I.Lx + r : I.zs;            const int sLx = (MF && vn1) ? n : 0;
+    const double* pLu = (MF && vm1) ? I.Lu + r : I.zs;
     auto step = [&](const Ops& o, int t, const double (&xin)[n], double (&xout)[n]) {
-        // sensitivity recursion, first half: issued before the VALU dynamics chain so that the
-        // matrix pipe works underneath it (operands are transposed straight from LDS:
-        // mfma(A<-X^T, B<-v, C) = X v + C; the dot product ∇Lᵀ·Δz accumulates in element (0,0))
-        double zu = 0.0, fz = 0.0, fuT = 0.0, Luc = 0.0;
+        // sensitivity recursion: operand loads first (their latency hides under the policy evaluation)
+        double KT = 0.0, fxT = 0.0, fuT = 0.0, kc = 0.0, Lxc = 0.0, Luc = 0.0;
         if constexpr (MF) {
             if (with_delta) {
-                double KT = I.K[t * m * n + rn * m + cm];      // K^T(r,c) = K(c,r), r<n, c<m
-                double fxT = I.fx[t * n * n + rn * n + cn];    // fx^T(r,c) = fx(c,r)
-                fuT = I.fu[t * n * m + rm * n + cn];           // fu^T(r,c) = fu(c,r), r<m, c<n
-                double kc = I.k[t * m + rm], Lxc = I.Lx[t * n + rn];
-                Luc = I.Lu[t * m + rm];
-                KT = vnm ? KT : 0.0; fxT = vnn ? fxT : 0.0; fuT = vmn ? fuT : 0.0;
-                kc = vm1 ? kc : 0.0; Lxc = vn1 ? Lxc : 0.0; Luc = vm1 ? Luc : 0.0;
-                zu = mfma444(KT, zx, kc);                       // Δu = k + K Δx
-                fz = mfma444(fxT, zx, 0.0);                     // fx Δx
-                dacc = mfma444(Lxc, zx, dacc);                  // += ∇L_x · Δx
+                KT = *pKT; fxT = *pfxT; fuT = *pfuT; kc = *pkc; Lxc = *pLx; Luc = *pLu;
+                pKT += sKT; pfxT += sfxT; pfuT += sfuT; pkc += skc; pLx += sLx; pLu += skc;
             }
         }
         double ut[m];
@@ -879,6 +878,16 @@ __device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& 
             v += -1.0 * a2;                                           // (:28)
             ut[i] = v;
         }
+        // first half of the recursion goes to the matrix pipe before the long VALU dynamics chain,
+        // the dependent second half is issued after it: Δ costs issue slots only
+        double zu = 0.0, fz = 0.0;
+        if constexpr (MF) {
+            if (with_delta) {
+                zu = mfma444(KT, zx, kc);                       // Δu = k + K Δx
+                fz = mfma444(fxT, zx, 0.0);                     // fx Δx
+                dacc = mfma444(Lxc, zx, dacc);                  // += ∇L_x · Δx
+            }
+        }
         double w[cdim<M::NW>::v];
         load_w<M::NW>(I.w, t, w);
         M::dyn_wave(I.lane, xin, ut, w, xout);                        // (:29)
@@ -889,7 +898,7 @@ __device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& 
             for (int i = 0; i < n; ++i) I.x[(t + 1) * n + i] = xout[i];
         }
         if constexpr (MF) {
-            if (with_delta) {                                          // second half of the recursion
+            if (with_delta) {
                 dacc = mfma444(Luc, zu, dacc);                         // += ∇L_u · Δu
                 zx = mfma444(fuT, zu, fz);                             // Δx⁺ = fu Δu + fx Δx
             }

@@ -39,9 +39,7 @@ ILQR_HD void sincos_reduced(double r, double& s, double& c) {
     pc = fma(z, pc, C3);
     pc = fma(z, pc, C2);
     pc = fma(z, pc, C1);
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    c = w + (((1.0 - w) - hz) + z * (z * pc));
+    c = fma(z * z, pc, fma(-0.5, z, 1.0));   // 1 - z/2 + z^2 * pc (3 ops instead of fdlibm's 6; +0.3 ulp)
 }
 
 // |x| < 2^30: exact-product FMA reduction keeps the ABSOLUTE error of r below ~2e-16, so
