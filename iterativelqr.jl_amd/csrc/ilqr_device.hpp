@@ -648,7 +648,7 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
 #define ILQR_BW_PTR_LOADS 1
 #endif
 #ifndef ILQR_BW_PTR_STORES
-#define ILQR_BW_PTR_STORES 0
+#define ILQR_BW_PTR_STORES 1
 #endif
 template <class M, bool STORE_VALUE>
 __device__ void backward_pass_mfma(Inst<M>& I) {
@@ -666,9 +666,12 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
     const double* pfu = vnm ? I.fu + (N - 1) * n * m + c * n + r : I.zs;   const int sfu = vnm ? n * m : 0;
     const double* pgx = vn1 ? I.gx + (N - 1) * n + r : I.zs;               const int sgx = vn1 ? n : 0;
     const double* pgu = vm1 ? I.gu + (N - 1) * m + r : I.zs;               const int sgu = vm1 ? m : 0;
-    const double* pxx = vnn ? I.gxx + (N - 1) * n * n + c * n + r : I.gzero;
-    const double* puu = vmm ? I.guu + (N - 1) * m * m + c * m + r : I.gzero;
-    const double* pux = vmn ? I.gux + (N - 1) * m * n + c * m + r : I.gzero;
+    // HBM-resident accumulated Hessians: base + t * stride with a NON-NEGATIVE offset (walking a global
+    // pointer backwards made hipcc 7.2 emit saddr-form loads whose 32-bit offset went negative ->
+    // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION)
+    const double* bxx = vnn ? I.gxx + c * n + r : I.gzero;   const int sxx = vnn ? n * n : 0;
+    const double* buu = vmm ? I.guu + c * m + r : I.gzero;   const int suu = vmm ? m * m : 0;
+    const double* bux = vmn ? I.gux + c * m + r : I.gzero;   const int sux = vmn ? m * n : 0;
     const bool b0 = blk == 0;
 #if ILQR_BW_PTR_STORES
     double* qK = (b0 && vmn) ? I.K + (N - 1) * m * n + c * m + r : I.zs + 1;   const int sK = (b0 && vmn) ? m * n : 0;
@@ -684,30 +687,28 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         if (vn1) I.p[N * n + r] = p;
     }
     double gmax = 0.0;
-    // operands of step t are fetched one step ahead (accumulated Hessians from HBM/L2, the rest from LDS)
-    double nxx = 0.0, nuu = 0.0, nux = 0.0, nfx = 0.0, nfu = 0.0, ngx = 0.0, ngu = 0.0;
-    if (N > 0) {
-        nxx = *pxx; nuu = *puu; nux = *pux;
-        nfx = *pfx; nfu = *pfu; ngx = *pgx; ngu = *pgu;
-    }
-    for (int t = N - 1; t >= 0; --t) {                                  // (:42)
-        const double gxx = nxx, guu = nuu, gux = nux, fx = nfx, fu = nfu, gx = ngx, gu = ngu;
-        if (t > 0) {
+    // operands of step t are fetched one step ahead (accumulated Hessians from HBM/L2, the rest from
+    // LDS); the time loop is unrolled by two with ping-pong operand sets so no register copies are needed
+    struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
+    auto fetch_first = [&](Opnd& o, int tp) {
+        o.gxx = bxx[tp * sxx]; o.guu = buu[tp * suu]; o.gux = bux[tp * sux];
+        o.fx = *pfx; o.fu = *pfu; o.gx = *pgx; o.gu = *pgu;
+    };
+    auto fetch_prev = [&](Opnd& o, int tp) {     // operands of step tp = (previously fetched step) - 1
 #if ILQR_BW_PTR_LOADS
-            pxx -= vnn ? n * n : 0; puu -= vmm ? m * m : 0; pux -= vmn ? m * n : 0;
-            pfx -= sfx; pfu -= sfu; pgx -= sgx; pgu -= sgu;
-            nxx = *pxx; nuu = *puu; nux = *pux;
-            nfx = *pfx; nfu = *pfu; ngx = *pgx; ngu = *pgu;
+        pfx -= sfx; pfu -= sfu; pgx -= sgx; pgu -= sgu;
+        fetch_first(o, tp);
 #else
-            const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
-            const int tp = t - 1;
-            nxx = I.gxx[tp * n * n + cn * n + rn]; nuu = I.guu[tp * m * m + cm * m + rm]; nux = I.gux[tp * m * n + cn * m + rm];
-            nfx = I.fx[tp * n * n + cn * n + rn]; nfu = I.fu[tp * n * m + cm * n + rn];
-            ngx = I.gx[tp * n + rn]; ngu = I.gu[tp * m + rm];
-            nxx = vnn ? nxx : 0.0; nuu = vmm ? nuu : 0.0; nux = vmn ? nux : 0.0;
-            nfx = vnn ? nfx : 0.0; nfu = vnm ? nfu : 0.0; ngx = vn1 ? ngx : 0.0; ngu = vm1 ? ngu : 0.0;
+        const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
+        o.gxx = I.gxx[tp * n * n + cn * n + rn]; o.guu = I.guu[tp * m * m + cm * m + rm]; o.gux = I.gux[tp * m * n + cn * m + rm];
+        o.fx = I.fx[tp * n * n + cn * n + rn]; o.fu = I.fu[tp * n * m + cm * n + rn];
+        o.gx = I.gx[tp * n + rn]; o.gu = I.gu[tp * m + rm];
+        o.gxx = vnn ? o.gxx : 0.0; o.guu = vmm ? o.guu : 0.0; o.gux = vmn ? o.gux : 0.0;
+        o.fx = vnn ? o.fx : 0.0; o.fu = vnm ? o.fu : 0.0; o.gx = vn1 ? o.gx : 0.0; o.gu = vm1 ? o.gu : 0.0;
 #endif
-        }
+    };
+    auto riccati_step = [&](const Opnd& o, int t) {
+        const double gxx = o.gxx, guu = o.guu, gux = o.gux, fx = o.fx, fu = o.fu, gx = o.gx, gu = o.gu;
         // level 1: W = P'^T fx (= (fx^T P')^T), Wu = P'^T fu, Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49)
         const double W = mfma444(P, fx, 0.0);
         const double Wu = mfma444(P, fu, 0.0);
@@ -795,7 +796,17 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         }
         P = Pn;
         p = pn;
+    };
+    Opnd A, B;
+    if (N > 0) fetch_first(A, N - 1);
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {                                            // (:42)
+        fetch_prev(B, t - 1);
+        riccati_step(A, t);
+        if (t >= 2) fetch_prev(A, t - 2);
+        riccati_step(B, t - 1);
     }
+    if (t == 0) riccati_step(A, 0);
     I.gradient_norm = wave_max((b0 && c == 0) ? gmax : 0.0);
     __syncthreads();
 }
