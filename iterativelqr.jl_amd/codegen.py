@@ -180,23 +180,27 @@ def _emit_block(outputs, prefix, coop=False):
         batch_id = 0
         for r in sorted(rounds):
             items = rounds[r]
-            for b0 in range(0, len(items), 4):
-                chunk = items[b0:b0 + 4]
+            # up to 4 arguments: one per lane of every quad, results handed back by DPP quad broadcasts
+            # (stay in VGPRs); 5..64 arguments: one per lane of the wave, results by v_readlane (SGPRs).
+            chunks = [items] if len(items) <= 64 else [items[i:i + 64] for i in range(0, len(items), 64)]
+            for chunk in chunks:
                 if len(chunk) == 1:
                     continue   # a lone argument: plain (wave-uniform) sincos below
+                quad = len(chunk) <= 4
+                sel, bc = ("ql", "ilqr::quad_bcast") if quad else ("lane", "ilqr::wave_bcast")
                 j = batch_id
                 batch_id += 1
                 txt = ["double ta%d = %s;" % (j, _P.doprint(chunk[0][1]))]
                 for qi, (_, e) in enumerate(chunk[1:], start=1):
-                    txt.append("ta%d = (ql == %d) ? (%s) : ta%d;" % (j, qi, _P.doprint(e), j))
+                    txt.append("ta%d = (%s == %d) ? (%s) : ta%d;" % (j, sel, qi, _P.doprint(e), j))
                 txt.append("double ts%d, tc%d; ilqr::sincos_fast(ta%d, ts%d, tc%d);" % (j, j, j, j, j))
                 defined, dep = set(), sp.Tuple(*[e for _, e in chunk])
                 for qi, (d, _) in enumerate(chunk):
                     _, s_sym, c_sym, need_s, need_c, _ = d
                     if need_s:
-                        txt.append("const double %s = ilqr::quad_bcast<%d>(ts%d);" % (s_sym, qi, j))
+                        txt.append("const double %s = %s<%d>(ts%d);" % (s_sym, bc, qi, j))
                     if need_c:
-                        txt.append("const double %s = ilqr::quad_bcast<%d>(tc%d);" % (c_sym, qi, j))
+                        txt.append("const double %s = %s<%d>(tc%d);" % (c_sym, bc, qi, j))
                     defined |= {s_sym, c_sym}
                     d.append("done")
                 nodes.append((defined, dep, "\n".join(txt)))

@@ -81,6 +81,14 @@ __device__ __forceinline__ double quad_bcast(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, I * 0x55, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// wave-uniform broadcast of lane I (result lives in SGPRs: any number of sources per batch)
+template <int I>
+__device__ __forceinline__ double wave_bcast(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, I);
+    hi = __builtin_amdgcn_readlane(hi, I);
+    return __hiloint2double(hi, lo);
+}
 #endif
 
 }  // namespace ilqr
