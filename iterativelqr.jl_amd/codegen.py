@@ -161,6 +161,8 @@ def _emit_block(outputs, prefix, coop=False):
     hold the same values, so up to four trig arguments of one dependency level are
     evaluated by a single sincos (lane&3 picks the argument) and handed back to every
     lane with DPP quad broadcasts. Needs `const int ql = lane & 3;` in scope."""
+    ops_ = [o[2] if len(o) > 2 else "=" for o in outputs]
+    outputs = [(o[0], o[1]) for o in outputs]
     exprs = [sp.sympify(e) for _, e in outputs]
     if not exprs:
         return []
@@ -225,8 +227,8 @@ def _emit_block(outputs, prefix, coop=False):
         else:
             txt = "const double %s = ilqr::cos_fast(%s);" % (c_sym, a)
         nodes.append(({s_sym, c_sym}, e, txt))
-    for (lhs, _), e in zip(outputs, red[:nout]):
-        nodes.append((set(), e, "%s = %s;" % (lhs, _P.doprint(e))))
+    for (lhs, _), e, op in zip(outputs, red[:nout], ops_):
+        nodes.append((set(), e, "%s %s %s;" % (lhs, op, _P.doprint(e))))
     defined_by = {}
     for i, (ds, _, _) in enumerate(nodes):
         for s in ds:
@@ -376,6 +378,58 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         [("c[%d]" % i, e) for i, e in enumerate(con_term.evaluate)], with_u=False)
     add("void", "con_t_jac", sig_x + [_arr("cx", nct * n, False)], con_term if nct else dynamics,
         [("cx[%d]" % (j * nct + i), con_term.jacobian_state[i][j]) for j in range(n) for i in range(nct)], with_u=False)
+    # ---- memory-streaming variants for large models (HBM-resident workspace): Jacobians are
+    # written straight to memory, Hessians are ACCUMULATED (`.+=`, src/costs.jl:74) skipping
+    # structural zeros, and the Gauss-Newton AL terms of src/gradients.jl:54-80 are derived
+    # symbolically so that sparse constraint Jacobians cost nothing.
+    def nz(pairs):
+        return [(l, e, "+=") for l, e in pairs if sp.sympify(e) != 0]
+
+    outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
+    outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
+    add("void", "dyn_jac_mem", sig_xu + ["double* fx", "double* fu"], dynamics, outs)
+    outs = nz([("gxx[%d]" % (j * n + i), cost_stage.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
+    outs += nz([("guu[%d]" % (j * m + i), cost_stage.hessian_action_action[i][j]) for j in range(m) for i in range(m)])
+    outs += nz([("gux[%d]" % (j * m + i), cost_stage.hessian_action_state[i][j]) for j in range(n) for i in range(m)])
+    add("void", "cost_s_hess_acc", sig_xu + ["double* gxx", "double* guu", "double* gux"], cost_stage, outs)
+    outs = nz([("gxx[%d]" % (j * n + i), cost_term.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
+    add("void", "cost_t_hess_acc", sig_x + ["double* gxx"], cost_term, outs, with_u=False)
+
+    def al_terms(con, nc, stage):
+        ct = [sp.Symbol("ct%d" % i, real=True) for i in range(nc)]     # λ + Iρ c
+        ir = [sp.Symbol("ir%d" % i, real=True) for i in range(nc)]     # ρ ∘ a
+        cx, cu = con.jacobian_state, con.jacobian_action
+        o = []
+        for j in range(n):
+            o.append(("gx[%d]" % j, sum(cx[i][j] * ct[i] for i in range(nc))))
+        for j in range(n):
+            for i2 in range(n):
+                o.append(("gxx[%d]" % (j * n + i2), sum(cx[i][i2] * ir[i] * cx[i][j] for i in range(nc))))
+        if stage:
+            for j in range(m):
+                o.append(("gu[%d]" % j, sum(cu[i][j] * ct[i] for i in range(nc))))
+            for j in range(m):
+                for i2 in range(m):
+                    o.append(("guu[%d]" % (j * m + i2), sum(cu[i][i2] * ir[i] * cu[i][j] for i in range(nc))))
+            for j in range(n):
+                for i2 in range(m):
+                    o.append(("gux[%d]" % (j * m + i2), sum(cu[i][i2] * ir[i] * cx[i][j] for i in range(nc))))
+        unp = ["const double ct%d = ct[%d];" % (i, i) for i in range(nc)] + ["const double ir%d = ir[%d];" % (i, i) for i in range(nc)]
+        return nz(o), unp
+
+    def add_al(fname, sig, obj, con, nc, stage, with_u):
+        if nc == 0:
+            L.extend(_fn("void", fname, sig, []))
+            return
+        outs_, unp = al_terms(con, nc, stage)
+        body = _emit_block(outs_, "t")
+        un = _prune_unpack(unpack_xu(obj, with_u) + unp, body)
+        L.extend(_fn("void", fname, sig, un + body))
+
+    add_al("al_s", sig_xu + [_arr("ct", ncs), _arr("ir", ncs), _arr("gx", n, False), _arr("gu", m, False),
+                             "double* gxx", "double* guu", "double* gux"], con_stage if ncs else dynamics, con_stage, ncs, True, True)
+    add_al("al_t", sig_x + [_arr("ct", nct), _arr("ir", nct), _arr("gx", n, False), "double* gxx"],
+           con_term if nct else dynamics, con_term, nct, False, False)
     L.append("};")
     src = "\n".join(L) + "\n"
     return sname, src

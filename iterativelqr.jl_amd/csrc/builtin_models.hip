@@ -9,6 +9,7 @@
 #include "models/model_car.h"
 #include "models/model_car_goal.h"
 #include "models/model_car_obs.h"
+#include "models/model_synth32.h"
 
 ILQR_DEFINE_MODEL(Model_particle)
 ILQR_DEFINE_MODEL(Model_pendulum_euler)
@@ -16,3 +17,4 @@ ILQR_DEFINE_MODEL(Model_acrobot)
 ILQR_DEFINE_MODEL(Model_car)
 ILQR_DEFINE_MODEL(Model_car_goal)
 ILQR_DEFINE_MODEL(Model_car_obs)
+ILQR_DEFINE_MODEL(Model_synth32)

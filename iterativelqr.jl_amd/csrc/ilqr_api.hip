@@ -182,7 +182,8 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     ilqr_handle* h = new ilqr_handle();
     h->vt = vt; h->B = d->batch; h->device = d->device; h->constrained = d->constrained ? 1 : 0;
     h->L = ilqr::make_layout(vt->nx, vt->nu, vt->nw, vt->ncs, vt->nct, d->horizon);
-    h->lds_bytes = (size_t)h->L.lds_doubles * 8;
+    h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu) * 8
+                                                          : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
     ilqr_default_options(&h->opt);
     fill_buffers(h);

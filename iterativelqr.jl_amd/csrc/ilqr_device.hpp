@@ -58,7 +58,18 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 __device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
 
+// out[i] = value held by lane i (i < N), made wave-uniform
+template <int N>
+__device__ __forceinline__ void bcast_array(double v, double (&out)[N]) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        out[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
+}
+
 template <int N_> struct cdim { static constexpr int v = N_ > 0 ? N_ : 1; };
+
+template <class M> struct is_large { static constexpr bool value = (M::NX > 4 || M::NU > 4); };
 
 // parameters of timestep t (empty when NW == 0)
 template <int NW>
@@ -89,6 +100,7 @@ struct Inst {
     const double* w;       // parameters θ_t (problem.parameters, src/data/problem.jl:25-30), T x NW
     double *gxx, *guu, *gux, *P, *p, *scal;
     double *zs;            // LDS: zs[0] == 0.0 always, zs[1] is a write-only trash slot
+    double *lds;           // large path: LDS staging area (the workspace itself stays in HBM)
     const double* gzero;   // HBM: a 0.0
     int T, N, C, lane;
     double objective, max_violation, step_size, gradient_norm;
@@ -97,6 +109,12 @@ struct Inst {
     double prof[PROF_N];
 #endif
 };
+
+// large-model path (ilqr_device_large.hpp)
+template <class M> __device__ void gradients_large(Inst<M>& I, bool constrained);
+template <class M, bool STORE_VALUE> __device__ void backward_pass_large(Inst<M>& I);
+template <class M> __device__ void rollout_large(Inst<M>& I, double alpha);
+template <class M> __device__ double delta_large(Inst<M>& I);
 
 // ------------------------------------------------------------------ cost!
 // One timestep per lane. upd_J: evaluate J and the active set at (X,U)
@@ -211,7 +229,7 @@ __device__ void cost_bang(Inst<M>& I, bool mode_current, bool constrained) {
 // cost Hessians (`.+=` — accumulate, Appendix A Q1) and the Gauss-Newton AL
 // terms of src/gradients.jl:54-80 using the violations BUFFER (Q2).
 template <class M>
-__device__ void gradients(Inst<M>& I, bool constrained) {
+__device__ void gradients_small(Inst<M>& I, bool constrained) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     ILQR_PROF_BEGIN();
     for (int t = I.lane; t < I.T; t += 64) {
@@ -814,8 +832,8 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
 template <class M, bool STORE_VALUE>
 __device__ __forceinline__ void backward_pass(Inst<M>& I) {
     ILQR_PROF_BEGIN();
-    if constexpr (M::NX <= 4 && M::NU <= 4) backward_pass_mfma<M, STORE_VALUE>(I);
-    else backward_pass_valu<M, STORE_VALUE>(I);
+    if constexpr (is_large<M>::value) backward_pass_large<M, STORE_VALUE>(I);
+    else backward_pass_mfma<M, STORE_VALUE>(I);
     ILQR_PROF_END(I, PROF_BACKWARD);
 }
 
@@ -828,7 +846,7 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
 // the MFMA lane layout: the matrix pipe works asynchronously beside the VALU dynamics
 // chain, so Δ costs issue slots only (it used to be a separate 54 k-cycle serial loop).
 template <class M>
-__device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
+__device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
     constexpr int n = M::NX, m = M::NU;
     constexpr bool MF = (n <= 4 && m <= 4);
     ILQR_PROF_BEGIN();
@@ -939,6 +957,22 @@ __device__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& 
     ILQR_PROF_END(I, PROF_ROLLOUT);
 }
 
+}  // namespace ilqr
+#include "ilqr_device_large.hpp"
+namespace ilqr {
+
+// ---- dispatch between the LDS-resident small path and the HBM-resident large path
+template <class M>
+__device__ __forceinline__ void gradients(Inst<M>& I, bool constrained) {
+    if constexpr (is_large<M>::value) gradients_large<M>(I, constrained);
+    else gradients_small<M>(I, constrained);
+}
+template <class M>
+__device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
+    if constexpr (is_large<M>::value) rollout_large<M>(I, alpha);
+    else rollout_small<M>(I, alpha, with_delta, delta_out);
+}
+
 // --------------------------------------------------------- forward_pass!
 template <class M>
 __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrained) {
@@ -952,7 +986,9 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     // trajectory_sensitivities (src/data/methods.jl:42-54) fused with the product
     // gradientᵀ·Δz (:20): on the MFMA path it rides along the first rollout below.
     double delta = 0.0;
-    if constexpr (!MF) {
+    if constexpr (is_large<M>::value) {
+        if (opt.line_search == 1) delta = delta_large<M>(I);
+    } else if constexpr (!MF) {
         ILQR_PROF_BEGIN();
         if (opt.line_search == 1) {
             double zx[n];
@@ -1104,11 +1140,21 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x;
-    // LDS-resident set: one coalesced 16-B-per-lane stream from HBM
-    const double2* src = reinterpret_cast<const double2*>(g);
-    double2* dst = reinterpret_cast<double2*>(smem);
-    for (int i = I.lane; i < L.lds_doubles / 2; i += 64) dst[i] = src[i];
-    if (I.lane == 0) { I.zs[0] = 0.0; I.zs[1] = 0.0; }
+    I.lds = smem;
+    if constexpr (is_large<M>::value) {
+        // large path: every buffer stays in the HBM workspace, LDS is staging only
+        I.xb = g + L.xb; I.ub = g + L.ub; I.x = g + L.x; I.u = g + L.u;
+        I.fx = g + L.fx; I.fu = g + L.fu; I.gx = g + L.gx; I.gu = g + L.gu;
+        I.K = g + L.K; I.k = g + L.k; I.Lx = g + L.Lx; I.Lu = g + L.Lu;
+        I.c = g + L.c; I.lam = g + L.lam; I.rho = g + L.rho; I.act = g + L.act;
+        I.zs = g + L.zslot; I.w = g + L.w;
+    } else {
+        // LDS-resident set: one coalesced 16-B-per-lane stream from HBM
+        const double2* src = reinterpret_cast<const double2*>(g);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int i = I.lane; i < L.lds_doubles / 2; i += 64) dst[i] = src[i];
+        if (I.lane == 0) { I.zs[0] = 0.0; I.zs[1] = 0.0; }
+    }
     I.objective = I.scal[S_OBJECTIVE]; I.max_violation = I.scal[S_MAX_VIOLATION];
     I.step_size = I.scal[S_STEP_SIZE]; I.gradient_norm = I.scal[S_GRADIENT_NORM];
     I.status = (int)I.scal[S_STATUS]; I.iterations = (int)I.scal[S_ITERATIONS];
@@ -1125,9 +1171,11 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
     __syncthreads();
     const Layout& L = a.L;
     double* g = a.ws + (size_t)b * (size_t)L.stride;
-    double2* dst = reinterpret_cast<double2*>(g);
-    const double2* src = reinterpret_cast<const double2*>(smem);
-    for (int i = I.lane; i < L.lds_doubles / 2; i += 64) dst[i] = src[i];
+    if constexpr (!is_large<M>::value) {
+        double2* dst = reinterpret_cast<double2*>(g);
+        const double2* src = reinterpret_cast<const double2*>(smem);
+        for (int i = I.lane; i < L.lds_doubles / 2; i += 64) dst[i] = src[i];
+    }
     if (I.lane == 0) {
         I.scal[S_OBJECTIVE] = I.objective; I.scal[S_MAX_VIOLATION] = I.max_violation;
         I.scal[S_STEP_SIZE] = I.step_size; I.scal[S_GRADIENT_NORM] = I.gradient_norm;

@@ -159,6 +159,36 @@ def car_obs():
     )
 
 
+# ---------------------------------------------------------------- synth32
+def synth32():
+    """x⁺ = x + h(Ax + Bu + 0.1 sin x), nx = 32, nu = 8, action box as 16 stage inequalities."""
+    n, m, h = 32, 8, 0.05
+    A = [[(-1.0 if i == j else 0.0) + 0.3 * math.cos(float((i + 1) + 2 * (j + 1))) / 32.0 for j in range(n)] for i in range(n)]
+    Bm = [[math.sin(float(3 * (i + 1) + (j + 1))) / math.sqrt(32.0) for j in range(m)] for i in range(n)]
+
+    def f(x, u):
+        out = []
+        for i in range(n):
+            acc = 0.0
+            for j in range(n):
+                acc = acc + A[i][j] * x[j]
+            for j in range(m):
+                acc = acc + Bm[i][j] * u[j]
+            acc = acc + 0.1 * sp.sin(x[i])
+            out.append(x[i] + h * acc)
+        return out
+
+    xg = 0.5
+    return dict(
+        dynamics=Dynamics(f, n, m),
+        cost_stage=Cost(lambda x, u: 0.1 * sum((xi - xg) * (xi - xg) for xi in x) + 0.01 * _dot(u, u), n, m),
+        cost_term=Cost(lambda x, u: 10.0 * sum((xi - xg) * (xi - xg) for xi in x), n, 0),
+        con_stage=Constraint(lambda x, u: [-1.0 - u[j] for j in range(m)] + [u[j] - 1.0 for j in range(m)], n, m,
+                             indices_inequality=list(range(1, 2 * m + 1))),
+        con_term=Constraint(),
+    )
+
+
 BUILTIN = {
     "particle": particle,
     "pendulum_euler": pendulum_euler,
@@ -166,6 +196,7 @@ BUILTIN = {
     "car": car,
     "car_goal": lambda: car(goal_only=True),
     "car_obs": car_obs,
+    "synth32": synth32,
 }
 
 

@@ -12,9 +12,10 @@ CONFIGS = {
     "car": ("car", 51, True),
     "car_goal": ("car_goal", 51, True),
     "car_obs": ("car_obs", 51, True),
+    "synth32": ("synth32", 101, True),
 }
 DIMS = {"particle": (2, 1), "acrobot": (4, 1), "car": (3, 2), "car_goal": (3, 2), "car_obs": (3, 2),
-        "pendulum_euler": (2, 1)}
+        "pendulum_euler": (2, 1), "synth32": (32, 8)}
 
 
 def make_inputs(config, batch, seed=SEED, offset=0):
@@ -30,6 +31,8 @@ def make_inputs(config, batch, seed=SEED, offset=0):
             ub[b] = 0.1 * rng.standard_normal((T - 1, m))          # examples/particle.jl:30
         elif model == "acrobot":
             ub[b] = 1.0 * rng.standard_normal((T - 1, m))          # test/acrobot.jl:88
+        elif model == "synth32":
+            x1[b] = 0.5 * rng.standard_normal(n)                   # SURVEY.md §8(d) C5; ū = 0
         elif model in ("car", "car_goal", "car_obs"):
             ub[b] = 1.0e-2 * np.array([1.0, 0.1])                  # test/car.jl:28
             if offset + b > 0:

@@ -54,13 +54,15 @@ def _sync_from_oracle(sol, refs, T):
     sol.set_buffer("_scalars", sc)
 
 
-@pytest.mark.parametrize("config", ["particle", "acrobot", "car", "car_goal"])
+@pytest.mark.parametrize("config", ["particle", "acrobot", "car", "car_goal", "synth32"])
 def test_stagewise_parity(pkg, oracle, config):
     """Each stage kernel against the oracle's function on IDENTICAL inputs (state copied from the
     oracle before every stage), over three inner iterations — the later ones exercise Hessian
     accumulation (Q1), active sets and non-zero duals after an AL update."""
-    B = 5
+    B = 5 if config != "synth32" else 2
     model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+    if config == "synth32":   # push the controls into the action box so that the inequality set is exercised
+        ub = ub + 1.2 * np.sin(np.arange(ub.size).reshape(ub.shape))
     sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
     sol.initialize_rollout_(x1, ub)
     triples = [_oracle_solver(oracle, model, T, x1[b], ub[b]) for b in range(B)]
@@ -376,3 +378,23 @@ def test_user_defined_model_plugin_path(pkg, oracle):
     xb, ub_ = builtin.get_trajectory()
     assert np.abs(x - xb).max() < 1e-9
     sol.close(); builtin.close()
+
+
+def test_synth32_whole_solve(pkg, oracle):
+    """BASELINE configs[4]: synthetic nx=32, nu=8, T=101 with 16 stage inequalities (large-model path:
+    HBM-resident workspace, 16x16x4 fp64 MFMA tiles in the Riccati step)."""
+    B = 8
+    model, T, x1, ub = pkg.workloads.make_inputs("synth32", B)
+    ub = ub + 1.5 * np.sin(0.37 * np.arange(ub.size).reshape(ub.shape))     # start outside the action box
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    assert (sol.nx, sol.nu, sol.nc_stage, sol.nc_term) == (32, 8, 16, 0)
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=8)
+    rs = ref["stats"]
+    same = (st["iterations"] == rs["iterations"]) & (st["outer_iterations"] == rs["outer_iterations"]) & (st["rollouts"] == rs["rollouts"])
+    assert same.mean() >= 0.75, (st["iterations"], rs["iterations"])
+    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    assert (np.abs(K - ref["K"])[same].max() / np.abs(ref["K"]).max()) < 1e-5
+    assert (np.abs(u[same]) <= 1.0 + 5e-3).all()          # the action box holds at the solution
+    sol.close()
