@@ -75,7 +75,7 @@ def _p(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
-@pytest.mark.parametrize("model", ["particle", "pendulum_euler", "acrobot", "car", "car_goal", "car_obs"])
+@pytest.mark.parametrize("model", ["particle", "pendulum_euler", "acrobot", "car", "car_goal", "car_obs", "synth32"])
 def test_generated_builtin_matches_oracle(tmp_path, oracle, model):
     hdr = os.path.join(ROOT, "iterativelqr.jl_amd", "csrc", "models", "model_%s.h" % model)
     L = _build(tmp_path, hdr, "Model_" + model)

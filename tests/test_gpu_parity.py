@@ -398,3 +398,23 @@ def test_synth32_whole_solve(pkg, oracle):
     assert (np.abs(K - ref["K"])[same].max() / np.abs(ref["K"]).max()) < 1e-5
     assert (np.abs(u[same]) <= 1.0 + 5e-3).all()          # the action box holds at the solution
     sol.close()
+
+
+def test_synth32_shard_of_4096(pkg, oracle):
+    """BASELINE configs[4] at full per-GPU size: 4096 instances over 8 GPUs = a 512-instance shard
+    (rank 5 here). Oracle comparison on every 8th instance, box feasibility on all of them."""
+    B = 512
+    lo, _ = pkg.distributed.shard_range(5, B)
+    model, T, x1, ub = pkg.workloads.make_inputs("synth32", B, offset=lo)
+    ub = ub + 1.5 * np.sin(0.37 * np.arange(ub[0].size).reshape(ub[0].shape))[None] * np.linspace(0.5, 1.5, B)[:, None, None]
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    assert np.isfinite(x).all() and (st["potrf_info"] == 0).all()
+    assert (st["max_violation"] <= 5e-3).mean() > 0.99 and (np.abs(u) <= 1.0 + 5e-3)[st["max_violation"] <= 5e-3].all()
+    idx = np.arange(0, B, 8)
+    ref = oracle.solve_batch(model, T, x1[idx], ub[idx], nthreads=8)
+    same = (st["iterations"][idx] == ref["stats"]["iterations"]) & (st["rollouts"][idx] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.9
+    assert np.abs(x[idx] - ref["x"])[same].max() < 1e-6
+    sol.close()
