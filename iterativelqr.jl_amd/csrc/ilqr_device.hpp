@@ -4,8 +4,9 @@
 //   * the per-instance working set (trajectories, Jacobians, gradients, gains)
 //     lives in LDS for the whole solve; HBM sees one load and one store of it;
 //   * time-parallel stages (cost, linearisation) put one timestep on each lane;
-//   * time-sequential stages (Riccati recursion, closed-loop rollout) run the
-//     recursion wave-uniformly out of registers, reading LDS by broadcast;
+//   * time-sequential stages: the Riccati recursion runs on the fp64 matrix cores
+//     (v_mfma_f64_4x4x4, every 4x4 operand in the MFMA lane layout), the closed-loop
+//     rollout wave-cooperatively (one fused sincos per step for all trig arguments);
 //   * the accumulated cost Hessians (reference quirk Q1) stay in HBM/L2 and are
 //     prefetched one step ahead by the backward pass.
 // All control flow of the reference's solve loops is replicated per instance on
@@ -411,213 +412,6 @@ __device__ __forceinline__ void potrs_U(const double (&U)[m * m], double (&B)[m 
     }
 }
 
-// ---------------------------------------------------------- backward_pass!
-// Sequential Riccati recursion, wave-uniform, value function in registers.
-// Also produces the Lagrangian gradient (src/solve.jl:67-83) and its ∞-norm.
-template <class M, bool STORE_VALUE>
-__device__ void backward_pass_valu(Inst<M>& I) {
-    constexpr int n = M::NX, m = M::NU;
-    const int N = I.N;
-    double P[n * n], p[n];
-#pragma unroll
-    for (int i = 0; i < n * n; ++i) P[i] = I.gxx[N * n * n + i];       // P[H] .= gxx[H]  (:39)
-#pragma unroll
-    for (int i = 0; i < n; ++i) p[i] = I.gx[N * n + i];                // p[H] .= gx[H]   (:40)
-    if (STORE_VALUE && I.lane == 0) {
-#pragma unroll
-        for (int i = 0; i < n * n; ++i) I.P[N * n * n + i] = P[i];
-#pragma unroll
-        for (int i = 0; i < n; ++i) I.p[N * n + i] = p[i];
-    }
-    double gnorm = 0.0;
-    // software prefetch of the HBM-resident accumulated Hessians, one step ahead
-    double nxx[n * n], nuu[m * m], nux[m * n];
-    if (N > 0) {
-#pragma unroll
-        for (int i = 0; i < n * n; ++i) nxx[i] = I.gxx[(N - 1) * n * n + i];
-#pragma unroll
-        for (int i = 0; i < m * m; ++i) nuu[i] = I.guu[(N - 1) * m * m + i];
-#pragma unroll
-        for (int i = 0; i < m * n; ++i) nux[i] = I.gux[(N - 1) * m * n + i];
-    }
-    for (int t = N - 1; t >= 0; --t) {                                  // (:42)
-        double gxx[n * n], guu[m * m], gux[m * n];
-#pragma unroll
-        for (int i = 0; i < n * n; ++i) gxx[i] = nxx[i];
-#pragma unroll
-        for (int i = 0; i < m * m; ++i) guu[i] = nuu[i];
-#pragma unroll
-        for (int i = 0; i < m * n; ++i) gux[i] = nux[i];
-        if (t > 0) {
-#pragma unroll
-            for (int i = 0; i < n * n; ++i) nxx[i] = I.gxx[(t - 1) * n * n + i];
-#pragma unroll
-            for (int i = 0; i < m * m; ++i) nuu[i] = I.guu[(t - 1) * m * m + i];
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) nux[i] = I.gux[(t - 1) * m * n + i];
-        }
-        double fx[n * n], fu[n * m], gx[n], gu[m];
-#pragma unroll
-        for (int i = 0; i < n * n; ++i) fx[i] = I.fx[t * n * n + i];
-#pragma unroll
-        for (int i = 0; i < n * m; ++i) fu[i] = I.fu[t * n * m + i];
-#pragma unroll
-        for (int i = 0; i < n; ++i) gx[i] = I.gx[t * n + i];
-#pragma unroll
-        for (int i = 0; i < m; ++i) gu[i] = I.gu[t * m + i];
-
-        double Qx[n], Qu[m], Qxx[n * n], Quu[m * m], Qux[m * n];
-        // Qx = fxᵀp' + gx   (:44-45) ; Qu = fuᵀp' + gu   (:48-49)
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < n; ++l) acc += fx[i * n + l] * p[l];
-            Qx[i] = acc + gx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < n; ++l) acc += fu[i * n + l] * p[l];
-            Qu[i] = acc + gu[i];
-        }
-        // Qxx = (fxᵀP')fx + gxx   (:52-54)
-        {
-            double tmp[n * n];
-#pragma unroll
-            for (int j = 0; j < n; ++j)
-#pragma unroll
-                for (int i = 0; i < n; ++i) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < n; ++l) acc += fx[i * n + l] * P[j * n + l];
-                    tmp[j * n + i] = acc;
-                }
-#pragma unroll
-            for (int j = 0; j < n; ++j)
-#pragma unroll
-                for (int i = 0; i < n; ++i) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < n; ++l) acc += tmp[l * n + i] * fx[j * n + l];
-                    Qxx[j * n + i] = acc + gxx[j * n + i];
-                }
-        }
-        // Quu = (fuᵀP')fu + guu (:57-59) ; Qux = (fuᵀP')fx + gux (:62-64)
-        {
-            double uh[m * n];
-#pragma unroll
-            for (int j = 0; j < n; ++j)
-#pragma unroll
-                for (int i = 0; i < m; ++i) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < n; ++l) acc += fu[i * n + l] * P[j * n + l];
-                    uh[j * m + i] = acc;
-                }
-#pragma unroll
-            for (int j = 0; j < m; ++j)
-#pragma unroll
-                for (int i = 0; i < m; ++i) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < n; ++l) acc += uh[l * m + i] * fu[j * n + l];
-                    Quu[j * m + i] = acc + guu[j * m + i];
-                }
-#pragma unroll
-            for (int j = 0; j < n; ++j)
-#pragma unroll
-                for (int i = 0; i < m; ++i) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < n; ++l) acc += uh[l * m + i] * fx[j * n + l];
-                    Qux[j * m + i] = acc + gux[j * m + i];
-                }
-        }
-        // K = −Quu⁻¹Qux, k = −Quu⁻¹Qu via potrf/potrs ('U'), info ignored   (:68-75)
-        double K[m * n], k[m];
-        {
-            double Uc[m * m];
-#pragma unroll
-            for (int i = 0; i < m * m; ++i) Uc[i] = Quu[i];
-            const int info = potrf_U<m>(Uc);
-            if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) K[i] = Qux[i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) k[i] = Qu[i];
-            potrs_U<m, n>(Uc, K);
-            potrs_U<m, 1>(Uc, k);
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) K[i] *= -1.0;
-#pragma unroll
-            for (int i = 0; i < m; ++i) k[i] *= -1.0;
-        }
-        // ux_tmp = Quu K   (:79)
-        double uxt[m * n];
-#pragma unroll
-        for (int j = 0; j < n; ++j)
-#pragma unroll
-            for (int i = 0; i < m; ++i) {
-                double acc = 0.0;
-#pragma unroll
-                for (int l = 0; l < m; ++l) acc += Quu[l * m + i] * K[j * m + l];
-                uxt[j * m + i] = acc;
-            }
-        // P = Kᵀ ux_tmp + Kᵀ Qux + Quxᵀ K + Qxx   (:81-84)
-#pragma unroll
-        for (int j = 0; j < n; ++j)
-#pragma unroll
-            for (int i = 0; i < n; ++i) {
-                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-                for (int l = 0; l < m; ++l) {
-                    a1 += K[i * m + l] * uxt[j * m + l];
-                    a2 += K[i * m + l] * Qux[j * m + l];
-                    a3 += Qux[i * m + l] * K[j * m + l];
-                }
-                P[j * n + i] = ((a1 + a2) + a3) + Qxx[j * n + i];
-            }
-        // p = ux_tmpᵀ k + Kᵀ Qu + Quxᵀ k + Qx   (:86-89)
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-            for (int l = 0; l < m; ++l) {
-                a1 += uxt[i * m + l] * k[l];
-                a2 += K[i * m + l] * Qu[l];
-                a3 += Qux[i * m + l] * k[l];
-            }
-            p[i] = ((a1 + a2) + a3) + Qx[i];
-        }
-        // lagrangian_gradient!: Lx = Qx − p[t], Lu = Qu   (src/solve.jl:73-81)
-        double Lx[n];
-#pragma unroll
-        for (int i = 0; i < n; ++i) { Lx[i] = Qx[i] - p[i]; gnorm = nanmax(gnorm, fabs(Lx[i])); }
-#pragma unroll
-        for (int i = 0; i < m; ++i) gnorm = nanmax(gnorm, fabs(Qu[i]));
-        if (I.lane == 0) {
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) I.K[t * m * n + i] = K[i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) I.k[t * m + i] = k[i];
-#pragma unroll
-            for (int i = 0; i < n; ++i) I.Lx[t * n + i] = Lx[i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) I.Lu[t * m + i] = Qu[i];
-            if (STORE_VALUE) {
-#pragma unroll
-                for (int i = 0; i < n * n; ++i) I.P[t * n * n + i] = P[i];
-#pragma unroll
-                for (int i = 0; i < n; ++i) I.p[t * n + i] = p[i];
-            }
-        }
-    }
-    I.gradient_norm = gnorm;
-    __syncthreads();
-}
-
 // ------------------------------------------------- backward_pass! on the matrix cores
 // For nx <= 4, nu <= 4 the whole Riccati step runs on v_mfma_f64_4x4x4 (4 blocks).
 // Measured on gfx950 (tools/probes/probe_mfma.hip): with one wave per SIMD a fp64
@@ -988,39 +782,6 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     double delta = 0.0;
     if constexpr (is_large<M>::value) {
         if (opt.line_search == 1) delta = delta_large<M>(I);
-    } else if constexpr (!MF) {
-        ILQR_PROF_BEGIN();
-        if (opt.line_search == 1) {
-            double zx[n];
-#pragma unroll
-            for (int i = 0; i < n; ++i) zx[i] = 0.0;
-            for (int t = 0; t < I.N; ++t) {
-                double zu[m], zy[n];
-#pragma unroll
-                for (int i = 0; i < m; ++i) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int j = 0; j < n; ++j) acc += I.K[t * m * n + j * m + i] * zx[j];
-                    zu[i] = I.k[t * m + i] + acc;
-                }
-#pragma unroll
-                for (int i = 0; i < n; ++i) delta += I.Lx[t * n + i] * zx[i];
-#pragma unroll
-                for (int i = 0; i < m; ++i) delta += I.Lu[t * m + i] * zu[i];
-#pragma unroll
-                for (int i = 0; i < n; ++i) {
-                    double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-                    for (int j = 0; j < m; ++j) a1 += I.fu[t * n * m + j * n + i] * zu[j];
-#pragma unroll
-                    for (int j = 0; j < n; ++j) a2 += I.fx[t * n * n + j * n + i] * zx[j];
-                    zy[i] = a1 + a2;
-                }
-#pragma unroll
-                for (int i = 0; i < n; ++i) zx[i] = zy[i];
-            }
-        }
-        ILQR_PROF_END(I, PROF_DELTA);
     }
     I.step_size = 1.0;                                                // (:26)
     int iteration = 1;
