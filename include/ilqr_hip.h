@@ -152,6 +152,12 @@ int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len);
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out);
 int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in);
 
+/* Per-iteration record of what the reference prints when `verbose` (src/solve.jl:40-45): for every
+ * instance up to `capacity` rows of 8 doubles {outer, inner, objective, gradient_norm, max_violation,
+ * step_size, status, rollouts-so-far} written by ilqr_solve. capacity 0 disables (default). */
+int ilqr_enable_trace(ilqr_handle* h, int32_t capacity);
+int ilqr_get_trace(ilqr_handle* h, double* out /* [B][capacity][8] */);
+
 /* Device-side handles for callers that time or chain work themselves. */
 int ilqr_get_stream(ilqr_handle* h, void** hip_stream);
 /* Average device time (ms) of the solve kernel over the ilqr_solve calls since

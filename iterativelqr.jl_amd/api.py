@@ -161,6 +161,17 @@ class Solver:
         if n.value:
             _ffi.check(_ffi.lib().ilqr_set_buffer(self._h, name.encode(), _p(v)))
 
+    def enable_trace_(self, capacity):
+        """Record per-iteration rows (what `verbose` prints in the reference) during solve_."""
+        self._trace_cap = int(capacity)
+        _ffi.check(_ffi.lib().ilqr_enable_trace(self._h, self._trace_cap))
+
+    def trace(self):
+        """[B, capacity, 8]: outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts."""
+        out = np.zeros((self.B, self._trace_cap, 8))
+        _ffi.check(_ffi.lib().ilqr_get_trace(self._h, _p(out)))
+        return out
+
     def timing(self):
         ms = C.c_double(0); nl = C.c_int32(0)
         _ffi.check(_ffi.lib().ilqr_timing_get(self._h, C.byref(ms), C.byref(nl)))

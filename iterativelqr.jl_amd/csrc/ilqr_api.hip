@@ -72,6 +72,8 @@ struct ilqr_handle {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
     double* d_x1;
     double* d_u;   // staging for host-pointer initialize_rollout
+    double* trace;
+    int trace_cap;
     std::vector<BufferDesc> buffers;
 };
 
@@ -81,6 +83,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     ilqr::KArgs a;
     a.ws = h->ws; a.L = h->L; a.B = h->B; a.constrained = h->constrained; a.stage = 0; a.opt = h->opt;
     a.x1 = nullptr; a.u_in = nullptr;
+    a.trace = h->trace; a.trace_cap = h->trace_cap;
     return a;
 }
 
@@ -185,6 +188,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu) * 8
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
+    h->trace = nullptr; h->trace_cap = 0;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
     if (h->lds_bytes > 160 * 1024) {
@@ -211,6 +215,7 @@ int ilqr_destroy(ilqr_handle* h) {
     if (h->ws) hipFree(h->ws);
     if (h->d_x1) hipFree(h->d_x1);
     if (h->d_u) hipFree(h->d_u);
+    if (h->trace) hipFree(h->trace);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return ILQR_OK;
@@ -371,6 +376,29 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
     const BufferDesc* bd = find_buffer(h, name);
     if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
     return copy_in(h, bd, in);
+}
+
+int ilqr_enable_trace(ilqr_handle* h, int32_t capacity) {
+    if (!h || capacity < 0) return fail(ILQR_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->trace) { HIP_TRY(hipFree(h->trace)); h->trace = nullptr; }
+    h->trace_cap = capacity;
+    if (capacity > 0) {
+        const size_t bytes = (size_t)h->B * capacity * ilqr::TRACE_W * 8;
+        HIP_TRY(hipMalloc((void**)&h->trace, bytes));
+        HIP_TRY(hipMemset(h->trace, 0, bytes));
+    }
+    return ILQR_OK;
+}
+
+int ilqr_get_trace(ilqr_handle* h, double* out) {
+    if (!h || !out) return fail(ILQR_ERR_INVALID, "null argument");
+    if (!h->trace) return fail(ILQR_ERR_INVALID, "trace not enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->trace, (size_t)h->B * h->trace_cap * ilqr::TRACE_W * 8, hipMemcpyDeviceToHost));
+    return ILQR_OK;
 }
 
 int ilqr_get_stream(ilqr_handle* h, void** s) {

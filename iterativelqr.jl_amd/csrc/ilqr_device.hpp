@@ -42,7 +42,10 @@ struct KArgs {
     ilqr_options opt;
     const double* x1;    // init kernel only (device pointers)
     const double* u_in;
+    double* trace;       // optional per-iteration trace [B][trace_cap][TRACE_W] (null = off)
+    int trace_cap;
 };
+enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -102,6 +105,8 @@ struct Inst {
     double *gxx, *guu, *gux, *P, *p, *scal;
     double *zs;            // LDS: zs[0] == 0.0 always, zs[1] is a write-only trash slot
     double *lds;           // large path: LDS staging area (the workspace itself stays in HBM)
+    double *trace;         // per-iteration trace rows of this instance (what `verbose` prints, src/solve.jl:40-45)
+    int trace_cap, trace_len;
     const double* gzero;   // HBM: a 0.0
     int T, N, C, lane;
     double objective, max_violation, step_size, gradient_norm;
@@ -877,6 +882,12 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
             }
             if (it == 0) { obj_prev = I.objective; continue; }        // (:21)
             I.iterations += 1;                                        // (:39)
+            if (I.trace != nullptr && I.trace_len < I.trace_cap && I.lane == 0) {     // verbose record (:40-45)
+                double* r = I.trace + (size_t)I.trace_len * TRACE_W;
+                r[0] = (double)(al_outer ? o : 0); r[1] = (double)it; r[2] = I.objective; r[3] = I.gradient_norm;
+                r[4] = I.max_violation; r[5] = I.step_size; r[6] = (double)I.status; r[7] = (double)I.rollouts;
+            }
+            I.trace_len += 1;
             if (I.gradient_norm < opt.lagrangian_gradient_tolerance) break;          // (:48)
             if (fabs(I.objective - obj_prev) < opt.objective_tolerance) break;       // (:49)
             obj_prev = I.objective;
@@ -902,6 +913,8 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x;
     I.lds = smem;
+    I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
+    I.trace_cap = a.trace_cap; I.trace_len = 0;
     if constexpr (is_large<M>::value) {
         // large path: every buffer stays in the HBM workspace, LDS is staging only
         I.xb = g + L.xb; I.ub = g + L.ub; I.x = g + L.x; I.u = g + L.u;
