@@ -306,6 +306,10 @@ int ilqr_solve(ilqr_handle* h) {
     if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "solve launch failed");
     HIP_TRY(hipEventRecord(e1, h->stream));
     h->timing.emplace_back(e0, e1);
+    if (h->timing.size() > 4096) {     // long-running callers that never read the timing: keep the newest half
+        for (size_t i = 0; i < 2048; ++i) { hipEventDestroy(h->timing[i].first); hipEventDestroy(h->timing[i].second); }
+        h->timing.erase(h->timing.begin(), h->timing.begin() + 2048);
+    }
     return ILQR_OK;
 }
 

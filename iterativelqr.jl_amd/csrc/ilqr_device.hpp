@@ -1045,22 +1045,18 @@ namespace ilqr {
 template <class M>
 struct ModelModule {
     static int launch_solve(const KArgs* a, size_t lds, void* stream) {
-        static size_t configured = 0;
-        if (lds > configured) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<M>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-            configured = lds;
-        }
+        // dynamic LDS above the 64 KiB default needs the per-device function attribute
+        // (set on every such launch: handles may live on different devices of one process)
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<M>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         hipLaunchKernelGGL(solve_kernel<M>, dim3(a->B), dim3(64), lds, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     static int launch_stage(const KArgs* a, size_t lds, void* stream) {
-        static size_t configured = 0;
-        if (lds > configured) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<M>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-            configured = lds;
-        }
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<M>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         hipLaunchKernelGGL(stage_kernel<M>, dim3(a->B), dim3(64), lds, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }

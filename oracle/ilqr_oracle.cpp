@@ -137,7 +137,8 @@ extern "C" OrcSolver* orc_solver_create(int T, const OrcDynamics* const* dynamic
     s->cx.assign(s->cxoff[T] + 1, 0.0); s->cu.assign(s->cuoff[T] + 1, 0.0);
     s->cx_tmp.assign(maxnc * n + 1, 0.0); s->cu_tmp.assign(maxnc * m + 1, 0.0);
     int cs = n * n; if (n * m > cs) cs = n * m; if (m * m > cs) cs = m * m;
-    if (maxnc * n > cs) cs = maxnc * n; if (maxnc * m > cs) cs = maxnc * m;
+    if (maxnc * n > cs) cs = maxnc * n;
+    if (maxnc * m > cs) cs = maxnc * m;
     s->cache.assign(cs + 1, 0.0);
     s->outer_iterations = 0; s->potrf_info = 0; s->rollouts = 0; s->gradient_norm = 0.0;
     s->trace = nullptr; s->trace_cap = 0; s->trace_len = 0; s->cur_outer = 0;
@@ -707,7 +708,8 @@ extern "C" double* orc_buffer(OrcSolver* s, const char* name, int* len) {
     if (!std::strcmp(name, "constraint_penalty")) { if (len) *len = C; return s->rho.data(); }
     if (!std::strcmp(name, "active_set")) {
         for (int i = 0; i < C; ++i) s->active_d[i] = (double)s->active[i];
-        if (len) *len = C; return s->active_d.data();
+        if (len) *len = C;
+        return s->active_d.data();
     }
     if (len) *len = 0;
     return nullptr;

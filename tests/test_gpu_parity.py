@@ -446,3 +446,19 @@ def test_iteration_trace_matches_oracle(pkg, oracle, config, B):
         assert np.allclose(g[:, 4], mv, rtol=1e-6, atol=1e-10)
     assert sum(st["iterations"][b] > 0 for b in range(B)) == B
     sol.close()
+
+
+def test_long_horizon_above_64k_lds(pkg, oracle):
+    """acrobot T = 301: a 107 KB LDS working set (above the 64 KiB default dynamic-LDS limit, below the
+    160 KiB of a gfx950 CU) — one instance per CU."""
+    B, T = 6, 301
+    rng = np.random.default_rng(23)
+    x1 = np.zeros((B, 4)); ub = 0.3 * rng.standard_normal((B, T - 1, 1))
+    sol = pkg.Solver(model="acrobot", horizon=T, batch=B, options=pkg.Options(verbose=0, max_dual_updates=2, max_iterations=15))
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    ref = oracle.solve_batch("acrobot", T, x1, ub, options=oracle.default_options(max_dual_updates=2, max_iterations=15), nthreads=6)
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.8
+    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    sol.close()
