@@ -152,6 +152,12 @@ int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len);
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out);
 int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in);
 
+/* Kernel variant of ilqr_solve: 0 = auto (default: the latency kernel while the batch fits one wave per
+ * SIMD, the throughput kernel — two waves per SIMD, Jacobians in HBM/L2 — for larger batches),
+ * 1 = latency kernel, 2 = throughput kernel. Results are identical up to rounding-free reordering: both
+ * run the same arithmetic. */
+int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);
+
 /* Per-iteration record of what the reference prints when `verbose` (src/solve.jl:40-45): for every
  * instance up to `capacity` rows of 8 doubles {outer, inner, objective, gradient_norm, max_violation,
  * step_size, status, rollouts-so-far} written by ilqr_solve. capacity 0 disables (default). */

@@ -161,6 +161,11 @@ class Solver:
         if n.value:
             _ffi.check(_ffi.lib().ilqr_set_buffer(self._h, name.encode(), _p(v)))
 
+    def set_kernel_variant_(self, variant):
+        """"auto" | "latency" | "throughput" (see ilqr_set_kernel_variant)."""
+        v = {"auto": 0, "latency": 1, "throughput": 2}.get(variant, variant)
+        _ffi.check(_ffi.lib().ilqr_set_kernel_variant(self._h, int(v)))
+
     def enable_trace_(self, capacity):
         """Record per-iteration rows (what `verbose` prints in the reference) during solve_."""
         self._trace_cap = int(capacity)

@@ -74,6 +74,8 @@ struct ilqr_handle {
     double* d_u;   // staging for host-pointer initialize_rollout
     double* trace;
     int trace_cap;
+    int variant;          // 0 auto, 1 latency kernel (1 wave/SIMD, all-LDS), 2 throughput kernel (slim)
+    int num_simds;
     std::vector<BufferDesc> buffers;
 };
 
@@ -188,7 +190,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu) * 8
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
-    h->trace = nullptr; h->trace_cap = 0;
+    h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
     if (h->lds_bytes > 160 * 1024) {
@@ -198,6 +200,10 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     }
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) h->num_simds = 4 * prop.multiProcessorCount;
+    }
     h->ws_bytes = (size_t)h->B * (size_t)h->L.stride * 8;
     HIP_TRY(hipMalloc((void**)&h->ws, h->ws_bytes));
     HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
@@ -303,7 +309,13 @@ int ilqr_solve(ilqr_handle* h) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, h->stream));
-    if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "solve launch failed");
+    // batches that do not fit one wave per SIMD take the throughput kernel (two waves per SIMD)
+    const bool slim = h->vt->launch_solve_slim != nullptr &&
+                      (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
+    if (slim) {
+        if (h->vt->launch_solve_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
+            return fail(ILQR_ERR_HIP, "solve (throughput variant) launch failed");
+    } else if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "solve launch failed");
     HIP_TRY(hipEventRecord(e1, h->stream));
     h->timing.emplace_back(e0, e1);
     if (h->timing.size() > 4096) {     // long-running callers that never read the timing: keep the newest half
@@ -380,6 +392,14 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
     const BufferDesc* bd = find_buffer(h, name);
     if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
     return copy_in(h, bd, in);
+}
+
+int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
+    if (!h || variant < 0 || variant > 2) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency) or 2 (throughput)");
+    if (variant == 2 && h->vt->launch_solve_slim == nullptr)
+        return fail(ILQR_ERR_INVALID, "the throughput variant exists for small models (nx, nu <= 4) only");
+    h->variant = variant;
+    return ILQR_OK;
 }
 
 int ilqr_enable_trace(ilqr_handle* h, int32_t capacity) {

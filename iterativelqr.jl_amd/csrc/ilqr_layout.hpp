@@ -22,6 +22,7 @@ struct Layout {
     int xb, ub, x, u, fx, fu, gx, gu, K, k, Lx, Lu, c, lam, rho, act, w;   // LDS-resident set (w: parameters θ_t)
     int zslot;                                                          // [0] always 0.0, [1] write-only trash
     int lds_doubles;                                                    // size of that set
+    int lds_doubles_slim;                                               // ... without fx, fu (throughput variant)
     int gxx, guu, gux, P, p, scal, gzero;                               // HBM-only set (gzero: a 0.0)
     int stride;
 };
@@ -46,8 +47,6 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.ub = o; o += pad2(N * nu);
     L.x = o; o += pad2(T * nx);
     L.u = o; o += pad2(N * nu);
-    L.fx = o; o += pad2(N * nx * nx);
-    L.fu = o; o += pad2(N * nx * nu);
     L.gx = o; o += pad2(T * nx);
     L.gu = o; o += pad2(N * nu);
     L.K = o; o += pad2(N * nu * nx);
@@ -60,6 +59,9 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.act = o; o += pad2(L.C);
     L.w = o; o += pad2(T * nw);
     L.zslot = o; o += 2;
+    L.lds_doubles_slim = o;            // the throughput variant keeps the Jacobians in HBM/L2
+    L.fx = o; o += pad2(N * nx * nx);
+    L.fu = o; o += pad2(N * nx * nu);
     L.lds_doubles = o;
     L.gxx = o; o += pad2(T * nx * nx);
     L.guu = o; o += pad2(N * nu * nu);

@@ -462,3 +462,36 @@ def test_long_horizon_above_64k_lds(pkg, oracle):
     assert same.mean() >= 0.8
     assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
     sol.close()
+
+
+@pytest.mark.parametrize("config,B", [("acrobot51", 96), ("car", 96), ("particle", 32), ("car_obs", 48)])
+def test_throughput_kernel_variant(pkg, oracle, config, B):
+    """The two-waves-per-SIMD kernel (Jacobians in HBM/L2, 20 KB of LDS per instance) against the oracle
+    and against the latency kernel."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+    w = pkg.workloads.make_parameters(config, B) if config == "car_obs" else None
+    outs = []
+    for variant in ("throughput", "latency"):
+        sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+        sol.set_kernel_variant_(variant)
+        if w is not None:
+            sol.set_parameters_(w)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        outs.append(sol.get_trajectory() + sol.get_policy() + (sol.stats(),))
+        sol.close()
+    (x, u, K, k, st), (x2, u2, K2, k2, st2) = outs
+    ref = oracle.solve_batch(model, T, x1, ub, w=w, nthreads=8)
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    fin = same & np.isfinite(ref["x"]).reshape(B, -1).all(1)
+    assert same.mean() >= 0.9
+    assert np.abs(x - ref["x"])[fin].max() < 1e-6 and np.abs(u - ref["u"])[fin].max() < 1e-6
+    agree = st["iterations"] == st2["iterations"]
+    assert agree.mean() >= 0.95
+    assert np.abs(x - x2)[agree & fin].max() < 1e-7
+
+
+def test_throughput_variant_refused_for_large_models(pkg):
+    sol = pkg.Solver(model="synth32", horizon=11, batch=2)
+    with pytest.raises(pkg._ffi.IlqrError, match="small models"):
+        sol.set_kernel_variant_("throughput")
+    sol.close()

@@ -9,6 +9,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "acrobot"
 for B in [int(b) for b in (sys.argv[2:] or ["128", "256", "512", "768", "1024", "2048", "4096"])]:
     model, T, x1, ub = pkg.workloads.make_inputs(cfg, B)
     sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.set_kernel_variant_(os.environ.get("ILQR_VARIANT", "auto"))
     for _ in range(2):
         sol.reset_(); sol.initialize_rollout_(x1, ub); sol.timing_reset(); sol.solve_()
     ms, n = sol.timing()
