@@ -75,15 +75,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hook: ILQR_BENCH_SHARE_DEVICE=1 lets several ranks share GPU 0 over gloo, to exercise the
+    # multi-rank code path on a one-GPU box; the real runs use one GPU per rank over RCCL
+    share = os.environ.get("ILQR_BENCH_SHARE_DEVICE") == "1"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    gpu = 0 if share else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(gpu)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    local_rank = gpu
 
     B = args.batch
     model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=rank * B)
@@ -127,7 +135,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
