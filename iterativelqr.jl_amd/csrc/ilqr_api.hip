@@ -198,15 +198,22 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
         return fail(ILQR_ERR_LDS, "per-instance working set exceeds the 160 KiB LDS of a gfx950 CU "
                                   "(LDS-resident wave-per-instance kernel); reduce the horizon");
     }
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // from here on every failure must release the handle
+    auto bail = [&](hipError_t e, const char* what) {
+        const int rc = fail(ILQR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        ilqr_destroy(h);
+        return rc;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(h->device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) h->num_simds = 4 * prop.multiProcessorCount;
     }
     h->ws_bytes = (size_t)h->B * (size_t)h->L.stride * 8;
-    HIP_TRY(hipMalloc((void**)&h->ws, h->ws_bytes));
-    HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
+    if ((e = hipMalloc((void**)&h->ws, h->ws_bytes)) != hipSuccess) return bail(e, "hipMalloc(workspace)");
+    if ((e = hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     *out = h;
     int rc = ilqr_reset(h);
     if (rc != ILQR_OK) { ilqr_destroy(h); *out = nullptr; return rc; }
