@@ -129,7 +129,12 @@ enum {
     ILQR_STAGE_FORWARD_PASS = 3,   /* forward_pass!                       — src/forward_pass.jl:1-56 */
     ILQR_STAGE_RESET_MODEL_OBJECTIVE = 4, /* reset!(model); reset!(objective) — src/solve.jl:9-10 */
     ILQR_STAGE_ILQR_SOLVE = 5,     /* ilqr_solve!                         — src/solve.jl:1-54       */
-    ILQR_STAGE_AL_UPDATE = 6       /* augmented_lagrangian_update!        — src/augmented_lagrangian.jl:87-110 */
+    ILQR_STAGE_AL_UPDATE = 6,      /* augmented_lagrangian_update!        — src/augmented_lagrangian.jl:87-110 */
+    /* host-stepped outer loop, for solve!(solver; augmented_lagrangian_callback!) — src/solve.jl:88,125:
+     * AL_BEGIN once (:93-103), then AL_OUTER per outer iteration (:105-122, skipping instances that already
+     * met the constraint tolerance); the caller runs its callback between AL_OUTER launches. */
+    ILQR_STAGE_AL_BEGIN = 7,
+    ILQR_STAGE_AL_OUTER = 8
 };
 int ilqr_run_stage(ilqr_handle* h, int32_t stage);
 

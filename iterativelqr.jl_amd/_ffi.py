@@ -71,7 +71,7 @@ SYMBOLS = {
 }
 
 STAGES = dict(cost_nominal=0, gradients=1, backward_pass=2, forward_pass=3, reset_model_objective=4,
-              ilqr_solve=5, al_update=6)
+              ilqr_solve=5, al_update=6, al_begin=7, al_outer=8)
 
 _lib = None
 

@@ -116,11 +116,25 @@ class Solver:
         _ffi.check(_ffi.lib().ilqr_reset(self._h))
 
     # -- src/solve.jl:137-143
-    def solve_(self, sync=True):
+    def solve_(self, sync=True, augmented_lagrangian_callback_=None):
+        """solve!(solver; augmented_lagrangian_callback!) — src/solve.jl:88-129,137-143.
+
+        Without a callback the whole AL/iLQR solve is ONE kernel launch. With a callback the outer AL
+        loop is stepped from the host (one launch per outer iteration) and `callback(solver)` runs after
+        each dual update exactly where the reference calls it (src/solve.jl:125), e.g. for continuation
+        on the parameters."""
         _ffi.check(_ffi.lib().ilqr_set_options(self._h, C.byref(self.options)))
-        _ffi.check(_ffi.lib().ilqr_solve(self._h))
-        if sync:
-            self.synchronize()
+        if augmented_lagrangian_callback_ is None:
+            _ffi.check(_ffi.lib().ilqr_solve(self._h))
+            if sync:
+                self.synchronize()
+            return
+        self.run_stage_("al_begin")
+        for _ in range(int(self.options.max_dual_updates)):
+            self.run_stage_("al_outer")
+            if bool((self.buffer("_scalars")[:, 15] != 0.0).all()):     # every instance met the tolerance
+                break
+            augmented_lagrangian_callback_(self)
 
     def synchronize(self):
         _ffi.check(_ffi.lib().ilqr_synchronize(self._h))
@@ -206,13 +220,13 @@ def initialize_states_(solver, x):
     solver.initialize_states_(x)
 
 
-def solve_(solver, *args):
-    """solve!(solver[, states, actions]) — src/solve.jl:56-60,131-135."""
+def solve_(solver, *args, augmented_lagrangian_callback_=None):
+    """solve!(solver[, states, actions]; augmented_lagrangian_callback!) — src/solve.jl:56-60,88,131-135."""
     if args:
         states, actions = args
         solver.initialize_controls_(actions)
         solver.initialize_states_(states)
-    solver.solve_()
+    solver.solve_(augmented_lagrangian_callback_=augmented_lagrangian_callback_)
 
 
 def get_trajectory(solver):

@@ -875,8 +875,8 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
             I.rho[i] = opt.initial_constraint_penalty;
         }
         __syncthreads();
+        I.outer_iterations = 0;
     }
-    I.outer_iterations = 0;
     const int outer_max = al_outer ? opt.max_dual_updates : 1;
     for (int o = 1; o <= outer_max; ++o) {                            // src/solve.jl:105
         if (al_outer) I.outer_iterations = o;
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
     if (b >= a.B) return;
     Inst<M> I;
     inst_setup<M>(I, a, smem, b);
-    I.potrf_info = 0; I.rollouts = 0;
+    I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0;
     {
         ILQR_PROF_BEGIN();
         solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0);
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_slim(KArgs a) {
     typedef Slim<M> MS;
     Inst<MS> I;
     inst_setup<MS>(I, a, smem, b);
-    I.potrf_info = 0; I.rollouts = 0;
+    I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0;
     solve_loops<MS, false>(I, a.opt, a.constrained != 0, a.constrained != 0);
     inst_writeback<MS>(I, a, smem, b);
 }
@@ -1018,7 +1018,10 @@ __global__ __launch_bounds__(64) void stage_kernel(KArgs a) {
     Inst<M> I;
     inst_setup<M>(I, a, smem, b);
     const bool con = a.constrained != 0;
-    switch (a.stage) {
+    // host-stepped AL loop (solve! with augmented_lagrangian_callback!, src/solve.jl:88,125): instances that
+    // already met the constraint tolerance sit out the remaining outer iterations
+    const bool done = I.scal[S_DONE] != 0.0 && a.stage >= ILQR_STAGE_AL_BEGIN;
+    if (!done) switch (a.stage) {
         case ILQR_STAGE_COST_NOMINAL: cost_bang<M>(I, false, con); break;
         case ILQR_STAGE_GRADIENTS: gradients<M>(I, con); break;
         case ILQR_STAGE_BACKWARD_PASS: backward_pass<M, true>(I); break;
@@ -1026,6 +1029,25 @@ __global__ __launch_bounds__(64) void stage_kernel(KArgs a) {
         case ILQR_STAGE_RESET_MODEL_OBJECTIVE: reset_model_objective<M>(I); break;
         case ILQR_STAGE_ILQR_SOLVE: solve_loops<M, true>(I, a.opt, con, false); break;
         case ILQR_STAGE_AL_UPDATE: al_update<M>(I, a.opt); break;
+        case ILQR_STAGE_AL_BEGIN: {      // src/solve.jl:93-103: reset!(data), λ ← 0, ρ ← ρ0
+            I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
+            I.outer_iterations = 0; I.potrf_info = 0; I.rollouts = 0;
+            for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
+            for (int i = I.lane; i < I.N * M::NU; i += 64) I.Lu[i] = 0.0;
+            for (int i = I.lane; i < I.C; i += 64) { I.lam[i] = 0.0; I.rho[i] = a.opt.initial_constraint_penalty; }
+            if (I.lane == 0) I.scal[S_DONE] = 0.0;
+            __syncthreads();
+        } break;
+        case ILQR_STAGE_AL_OUTER: {      // one pass of the loop body src/solve.jl:105-122 (callback runs on the host)
+            I.outer_iterations += 1;
+            solve_loops<M, false>(I, a.opt, true, false);             // ilqr_solve!            (:109)
+            cost_bang<M>(I, false, true);                             // cost!(mode = :nominal) (:113)
+            if (I.max_violation <= a.opt.constraint_tolerance) {      // (:117)
+                if (I.lane == 0) I.scal[S_DONE] = 1.0;
+            } else {
+                al_update<M>(I, a.opt);                               // (:120-122)
+            }
+        } break;
         default: break;
     }
     inst_writeback<M>(I, a, smem, b);

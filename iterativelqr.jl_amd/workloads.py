@@ -49,7 +49,7 @@ def make_parameters(config, batch, seed=SEED, offset=0):
     w = np.zeros((batch, T, 2))
     for b in range(batch):
         rng = np.random.default_rng([seed, 7, offset + b])
-        c0 = np.array([0.5, 0.5]) + 0.1 * rng.uniform(-1, 1, 2)
+        c0 = np.array([0.8, 0.5]) + 0.08 * rng.uniform(-1, 1, 2)       # on the car's way: the constraint binds
         drift = 0.05 * rng.uniform(-1, 1, 2)
         w[b] = c0 + np.linspace(0.0, 1.0, T)[:, None] * drift
     return w

@@ -339,6 +339,8 @@ def test_parameters_car_obs(pkg, oracle):
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
     assert same.mean() >= 0.9
     assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    far = oracle.solve_batch(model, T, x1, ub, w=np.full_like(w, 9.0), nthreads=8)
+    assert (np.abs(far["x"] - ref["x"]).reshape(B, -1).max(1) > 1e-6).mean() > 0.5   # the parameters matter
     # the obstacle constraint is met w.r.t. each instance's own (moving) obstacle
     e = x[:, :-1, :2] - w[:, :-1, :]
     assert ((0.01 - (e * e).sum(-1)) <= 5e-3)[st["max_violation"] <= 5e-3].all()
@@ -495,3 +497,36 @@ def test_throughput_variant_refused_for_large_models(pkg):
     with pytest.raises(pkg._ffi.IlqrError, match="small models"):
         sol.set_kernel_variant_("throughput")
     sol.close()
+
+
+def test_host_stepped_al_loop_with_callback(pkg):
+    """solve!(solver; augmented_lagrangian_callback! = cb) (src/solve.jl:88,125): the host-stepped outer loop
+    with a no-op callback reproduces the fused single-launch solve, the callback is invoked once
+    per dual update, and a callback that edits the parameters changes the result."""
+    B = 24
+    model, T, x1, ub = pkg.workloads.make_inputs("car_obs", B)
+    w = pkg.workloads.make_parameters("car_obs", B)
+    fused = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    fused.set_parameters_(w); fused.initialize_rollout_(x1, ub); fused.solve_()
+    xf, uf = fused.get_trajectory(); sf = fused.stats()
+    calls = []
+    stepped = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    stepped.set_parameters_(w); stepped.initialize_rollout_(x1, ub)
+    stepped.solve_(augmented_lagrangian_callback_=lambda s: calls.append(1))
+    xs, us = stepped.get_trajectory(); ss = stepped.stats()
+    # the stepped loop runs the same device functions from another kernel: same results up to the
+    # compiler's FMA-contraction choices in the two inlining contexts
+    same = (sf["iterations"] == ss["iterations"]) & (sf["rollouts"] == ss["rollouts"])
+    assert same.mean() >= 0.9 and (sf["outer_iterations"] == ss["outer_iterations"])[same].all()
+    assert np.abs(xf - xs)[same].max() < 1e-7 and np.abs(uf - us)[same].max() < 1e-7
+    assert len(calls) == ss["outer_iterations"].max() - 1        # no callback after the final (converged) pass
+    moved = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    moved.set_parameters_(w); moved.initialize_rollout_(x1, ub)
+
+    def shift_obstacle(s):                                        # continuation on the model parameters
+        s.set_parameters_(s.buffer("parameters").reshape(B, T, 2) + 0.03)
+    moved.solve_(augmented_lagrangian_callback_=shift_obstacle)
+    xm, _ = moved.get_trajectory()
+    assert np.abs(xm - xf).max() > 1e-6
+    for s in (fused, stepped, moved):
+        s.close()
