@@ -4,6 +4,8 @@ Tolerances (fp64): stage level 1e-11 relative (rounding only: FMA contraction,
 device libm, reduction order); whole solve |Δx|,|Δu| ≤ 1e-6, |ΔK| ≤ 1e-5·max|K|
 for instances whose control flow (iteration counts) matches the oracle's.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -530,3 +532,16 @@ def test_host_stepped_al_loop_with_callback(pkg):
     assert np.abs(xm - xf).max() > 1e-6
     for s in (fused, stepped, moved):
         s.close()
+
+
+def test_plain_c_caller_of_the_abi(pkg, tmp_path):
+    """examples/acrobot_batch.c: the C-ABI used from plain C (no Python, no torch types)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "acrobot_batch")
+    libdir = os.path.join(root, "iterativelqr.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "acrobot_batch.c"),
+                           "-o", exe, "-L" + libdir, "-lilqr_hip", "-Wl,-rpath," + libdir, "-lm"])
+    out = subprocess.run([exe, "192"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "reached the goal" in out.stdout
