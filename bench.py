@@ -141,6 +141,20 @@ def main():
 
     kernel_ms, launches = sol.timing()
     st = sol.stats()
+
+    # the same step with the boundary fed HOST buffers: x1, ū over PCIe in, x, u, K, k over PCIe out
+    # (reported beside `value`, never as `value`)
+    h0 = time.perf_counter()
+    host_steps = 3
+    for _ in range(host_steps):
+        sol.reset_()
+        sol.initialize_rollout_(x1, ub)
+        sol.solve_(sync=True)
+        sol.get_trajectory()
+        sol.get_policy()
+    host_elapsed = (time.perf_counter() - h0) / host_steps
+    n_, m_ = sol.nx, sol.nu
+    io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))
     C = (T - 1) * sol.nc_stage + sol.nc_term
     abytes = float(algorithmic_bytes(sol.nx, sol.nu, T, C, st["iterations"].astype(np.float64),
                                      st["rollouts"].astype(np.float64)).sum())
@@ -170,7 +184,13 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "solve_kernel<Model_%s>" % model, "kernel_ms_avg": kernel_ms, "launches": launches,
-                     "algorithmic_bytes_per_launch": abytes},
+                     "algorithmic_bytes_per_launch": abytes,
+                     # pure I/O of a fully fused solve (x1, ū in; x, u, K, k out): how far below the
+                     # stage-materialised model a resident solve sits
+                     "io_lower_bound_bytes_per_launch": io_bytes,
+                     "io_lower_bound_GBs": io_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0},
+        "host_boundary": {"value": B / host_elapsed, "unit": "trajectories/s",
+                          "note": "one rank, inputs from host memory and x, u, K, k copied back (PCIe-inclusive)"},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -180,7 +200,12 @@ def main():
         c0 = time.perf_counter()
         O.solve_batch(model, T, x1[:sample], ub[:sample], nthreads=threads, want_policy=False)
         c1 = time.perf_counter() - c0
+        one = min(sample, 48)
+        c0 = time.perf_counter()
+        O.solve_batch(model, T, x1[:one], ub[:one], nthreads=1, want_policy=False)
+        c_one = time.perf_counter() - c0
         out["cpu_baseline"] = {"value": sample / c1, "unit": "trajectories/s", "cores": threads, "kind": "port",
+                               "single_thread_value": one / c_one,
                                "sample": "first %d of the %d instances of this workload, C++ oracle "
                                          "(literal restatement of the Julia reference, which cannot run here), "
                                          "OpenMP over instances, %.1f s wall" % (sample, B, c1)}
