@@ -11,7 +11,7 @@ import subprocess
 
 import numpy as np
 
-from . import _ffi, codegen
+from . import _ffi, lowering, codegen
 from ._ffi import Options as _COptions
 
 
@@ -62,17 +62,15 @@ class Solver:
                  options=None, device=0, name="user"):
         L = _ffi.lib()
         model_library = None
+        self._selectors = None
         if model is None:
             T = len(costs)
-            assert len(dynamics) == T - 1, "need T-1 dynamics and T costs"          # src/data/problem.jl:30
-            assert all(d is dynamics[0] for d in dynamics), "time-varying dynamics are not supported yet"
-            assert all(c is costs[0] for c in costs[:-1]), "stage costs must be one shared object"
-            cs = ct = None
-            if constraints is not None:
-                assert len(constraints) == T
-                assert all(c is constraints[0] for c in constraints[:-1]), "stage constraints must be one shared object"
-                cs, ct = constraints[0], constraints[-1]
-            model_library = compile_model(name, dynamics[0], costs[0], costs[-1], cs, ct)
+            low = lowering.lower(dynamics, costs, constraints)       # distinct per-step objects -> one stage template
+            self._selectors = low["selectors"]
+            self.num_user_parameter = low["num_user_parameter"]
+            self.constraint_rows = low["constraint_rows"]
+            model_library = compile_model(name, low["dynamics"], low["cost_stage"], low["cost_term"],
+                                          low["con_stage"], low["con_term"])
             model, horizon = name, T
             constrained = constraints is not None
         else:
@@ -88,6 +86,10 @@ class Solver:
         self.nx, self.nu, self.nw, self.nc_stage, self.nc_term = [v.value for v in d[:5]]
         self.options = options if options is not None else Options()
         _ffi.check(L.ilqr_set_options(self._h, C.byref(self.options)))
+        if self._selectors is None or self._selectors.shape[1] == 0:
+            self._selectors, self.num_user_parameter = None, self.nw
+        else:                                   # time-varying stage objects: the selectors are part of θ_t
+            self.set_parameters_(np.zeros((self.B, self.T, self.num_user_parameter)))
 
     # -- src/solver.jl:56-66
     def initialize_controls_(self, u):
@@ -109,7 +111,10 @@ class Solver:
 
     def set_parameters_(self, w):
         """Solver(...; parameters=θ): w[b, t] is the parameter vector of timestep t of instance b."""
-        w = np.ascontiguousarray(w, dtype=np.float64).reshape(self.B, self.T, self.nw)
+        w = np.ascontiguousarray(w, dtype=np.float64).reshape(self.B, self.T, self.num_user_parameter)
+        if self._selectors is not None:
+            w = np.concatenate([w, np.broadcast_to(self._selectors, (self.B,) + self._selectors.shape)], axis=2)
+            w = np.ascontiguousarray(w)
         _ffi.check(_ffi.lib().ilqr_set_parameters(self._h, _p(w)))
 
     def reset_(self):

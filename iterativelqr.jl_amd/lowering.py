@@ -1,0 +1,108 @@
+"""Time-varying stage objects (README.md:26 of the reference: "costs, constraints and dynamics can differ
+at every timestep") on a kernel that is compiled for ONE stage template.
+
+The reference keeps a Vector of objects over t (src/solver.jl:11-46, src/data/*.jl) and simply calls object t at
+step t. The device kernel is specialised at compile time on one Dynamics / stage Cost / stage Constraint, so
+distinct objects are LOWERED here, exactly, onto that template:
+
+  * the K distinct stage objects of a category (by identity, in order of first appearance) become one
+    combined object that takes K extra per-timestep parameters s_k(t) ∈ {0, 1} (one-hot "selectors"):
+        ℓ(x,u,w)  = Σ_k s_k ℓ_k(x,u,w)            f(x,u,w) = Σ_k s_k f_k(x,u,w)
+        c(x,u,w)  = [s_1 c_1(x,u,w); …; s_K c_K(x,u,w)]   (rows concatenated, inequality indices shifted)
+  * products with 0/1 and sums with 0 are exact in IEEE arithmetic, derivatives are taken after the
+    combination, so values, gradients, Jacobians and Hessians of step t are those of object t;
+  * the rows of constraint kinds that are switched off at step t read c = 0 with zero Jacobian: their
+    multipliers stay 0 (λ ← max(0, λ + ρ·0) or λ + ρ·0, src/augmented_lagrangian.jl:100-108), they add nothing
+    to the AL cost, its gradient and Gauss-Newton Hessian (src/augmented_lagrangian.jl:39-66,
+    src/gradients.jl:23-81) and nothing to max_violation (src/data/constraints.jl:23-46).
+
+The selectors ride in the parameter trajectory θ_t behind the user's own parameters. All objects must share
+(num_state, num_action): time-varying DIMENSIONS are not lowered.
+"""
+import numpy as np
+
+from .codegen import Constraint, Cost, Dynamics
+
+
+def _kinds(objs):
+    kinds, index = [], []
+    for o in objs:
+        for k, q in enumerate(kinds):
+            if q is o:
+                index.append(k)
+                break
+        else:
+            kinds.append(o)
+            index.append(len(kinds) - 1)
+    return kinds, index
+
+
+def lower(dynamics, costs, constraints=None):
+    """-> dict(dynamics, cost_stage, cost_term, con_stage, con_term, num_user_parameter, selectors[T, S],
+    constraint_rows[t] = device rows of the stage constraint that belong to step t)."""
+    T = len(costs)
+    assert len(dynamics) == T - 1, "need T-1 dynamics and T costs"                    # src/data/problem.jl:30
+    assert constraints is None or len(constraints) == T
+    dk, di = _kinds(dynamics)
+    ck, ci = _kinds(costs[:-1])
+    kk, ki = _kinds(constraints[:-1]) if constraints is not None else ([], [])
+    cost_term = costs[-1]
+    con_term = constraints[-1] if constraints is not None else None
+    n, m = dk[0].num_state, dk[0].num_action
+    for d in dk:
+        assert (d.num_state, d.num_action, d.num_next_state) == (n, m, n), "time-varying dimensions are not supported"
+    for c in ck:
+        assert (c.num_state, c.num_action) == (n, m)
+    for c in kk:
+        assert c.num_constraint == 0 or (c.num_state, c.num_action) == (n, m)
+    everything = dk + ck + kk + [cost_term] + ([con_term] if con_term is not None else [])
+    nwu = max(o.num_parameter for o in everything)
+    if len(dk) == 1 and len(ck) == 1 and len(kk) <= 1:
+        return dict(dynamics=dk[0], cost_stage=ck[0], cost_term=cost_term, con_stage=kk[0] if kk else None,
+                    con_term=con_term, num_user_parameter=nwu, selectors=np.zeros((T, 0)),
+                    constraint_rows=[list(range(kk[0].num_constraint if kk else 0))] * (T - 1))
+    # selector columns: one block per category that really varies
+    off, blocks = nwu, {}
+    for name, kinds in (("dynamics", dk), ("cost", ck), ("constraint", kk)):
+        if len(kinds) > 1:
+            blocks[name] = off
+            off += len(kinds)
+    nw = off
+    sel = np.zeros((T, nw - nwu))
+    for t in range(T - 1):
+        for name, idx in (("dynamics", di), ("cost", ci), ("constraint", ki)):
+            if name in blocks:
+                sel[t, blocks[name] - nwu + idx[t]] = 1.0
+
+    def gate(name, k, w):
+        return w[blocks[name] + k] if name in blocks else 1
+
+    # the traced objects all use the same symbols x0.., u0.., w0.. (codegen._variables), so their expressions can be
+    # combined directly; the lambdas only pick up the selector symbols
+    dyn = Dynamics(lambda x, u, w: [sum(gate("dynamics", k, w) * d.evaluate[i] for k, d in enumerate(dk)) for i in range(n)],
+                   n, m, nw)
+    cost_stage = Cost(lambda x, u, w: sum(gate("cost", k, w) * c.evaluate for k, c in enumerate(ck)), n, m, nw)
+    cost_term_l = Cost(lambda x, u, w: cost_term.evaluate, n, 0, nw)
+    con_stage = con_term_l = None
+    rows = [[] for _ in range(T - 1)]
+    if constraints is not None:
+        row0, ineq = [], []
+        for k, c in enumerate(kk):
+            row0.append(sum(q.num_constraint for q in kk[:k]))
+            ineq += [row0[k] + i for i in c.indices_inequality]
+        total = sum(q.num_constraint for q in kk)
+        assert total <= 64, "at most 64 stage constraint rows over all kinds"
+        if total:
+            con_stage = Constraint(lambda x, u, w: [gate("constraint", k, w) * e for k, c in enumerate(kk) for e in c.evaluate],
+                                   n, m, indices_inequality=ineq, num_parameter=nw)
+        else:
+            con_stage = Constraint()
+        for t in range(T - 1):
+            rows[t] = [row0[ki[t]] + i for i in range(kk[ki[t]].num_constraint)]
+        if con_term.num_constraint:
+            con_term_l = Constraint(lambda x, u, w: list(con_term.evaluate), n, 0,
+                                    indices_inequality=con_term.indices_inequality, num_parameter=nw)
+        else:
+            con_term_l = Constraint()
+    return dict(dynamics=dyn, cost_stage=cost_stage, cost_term=cost_term_l, con_stage=con_stage, con_term=con_term_l,
+                num_user_parameter=nwu, selectors=sel, constraint_rows=rows)

@@ -159,6 +159,27 @@ def car_obs():
     )
 
 
+def car_tv(T):
+    """Time-varying stage objects over the car (uniform dimensions), the way the reference is given Vectors of
+    objects (README.md:26): dynamics kind by t % 3 (midpoint h = 0.1 / explicit Euler h = 0.05), stage cost by
+    halves of the horizon, stage constraint by t % 4 (test/car.jl's five inequalities / none / one equality / none).
+    Returns (dynamics[T-1], costs[T], constraints[T]) for Solver(dynamics, costs, constraints)."""
+    base = car()
+    xT = [1.0, 1.0, 0.0]
+    dyn_a = base["dynamics"]
+    dyn_b = Dynamics(lambda x, u: [x[i] + 0.05 * car_continuous(x, u)[i] for i in range(3)], 3, 2)
+    cost_a = base["cost_stage"]
+    q, xg, r = [5.0, 2.0, 0.5], [0.9, 1.1, 0.2], [0.05, 0.02]
+    cost_b = Cost(lambda x, u: sum(q[i] * (x[i] - xg[i]) ** 2 for i in range(3)) + sum(r[j] * u[j] ** 2 for j in range(2)), 3, 2)
+    con_a = base["con_stage"]
+    con_none = Constraint()
+    con_eq = Constraint(lambda x, u: [u[1] - 0.3 * x[2] - 0.05], 3, 2)
+    dynamics = [dyn_b if t % 3 == 2 else dyn_a for t in range(T - 1)]
+    costs = [cost_b if 2 * t >= T - 1 else cost_a for t in range(T - 1)] + [base["cost_term"]]
+    constraints = [con_a if t % 4 == 0 else (con_eq if t % 4 == 2 else con_none) for t in range(T - 1)] + [base["con_term"]]
+    return dynamics, costs, constraints
+
+
 # ---------------------------------------------------------------- synth32 (SURVEY.md §8(d) C5)
 def synth32():
     """x⁺ = x + h(Ax + Bu + 0.1 sin x), nx = 32, nu = 8, action box as 16 stage inequalities."""

@@ -156,6 +156,16 @@ struct CarF {
     }
 };
 
+// car_tv (time-varying objects, README.md:26 of the reference): explicit Euler with h = 0.05 on some steps
+struct CarEulerF {
+    template <class S> void operator()(const S* x, const S* u, S* y) const {
+        const double h = 0.05;
+        S k1[3];
+        car_continuous(x, u, k1);
+        for (int i = 0; i < 3; ++i) y[i] = x[i] + h * k1[i];
+    }
+};
+
 // ----------------------------------------------------------------- synth32
 // x⁺ = x + h(Ax + Bu + 0.1 sin(x)), h = 0.05
 struct Synth32Tables {
@@ -273,6 +283,12 @@ void car_stage_ju(double* out, const double*, const double*, const double*, cons
     out[0 * 5 + 0] = -1.0; out[1 * 5 + 1] = -1.0;
     out[0 * 5 + 2] = 1.0;  out[1 * 5 + 3] = 1.0;
 }
+// car_tv: on some steps a single equality on the steering rate, c = u₂ − 0.3·x₃ − 0.05
+void cartv_eq_eval(double* out, const double* x, const double* u, const double*, const void*) {
+    out[0] = u[1] - 0.3 * x[2] - 0.05;
+}
+void cartv_eq_jx(double* out, const double*, const double*, const double*, const void*) { out[2] = -0.3; }
+void cartv_eq_ju(double* out, const double*, const double*, const double*, const void*) { out[1] = 1.0; }
 // car terminal: [x − xT; obstacle], inequality index 4 (1-based) (test/car.jl:54-60)
 const double CAR_XT[3] = {1.0, 1.0, 0.0};
 void car_term_eval(double* out, const double* x, const double*, const double*, const void*) {
@@ -343,6 +359,7 @@ struct Zoo {
     OrcCost cs, ct;
     GoalCtx goal; BoxCtx box;
     OrcConstraint ks, kt;
+    OrcDynamics dyn2; QuadCtx qs2; OrcCost cs2; OrcConstraint ks2, ks3;   // car_tv: further stage kinds
     std::vector<const OrcDynamics*> dptr;
     std::vector<const OrcCost*> cptr;
     std::vector<const OrcConstraint*> kptr;
@@ -406,6 +423,27 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
             z->kt.evaluate = goal_eval; z->kt.jacobian_state = goal_jx; z->kt.num_constraint = 3;
             z->kt.num_state = 3; z->kt.ctx = &z->goal;
         }
+    } else if (!std::strcmp(name, "car_tv")) {
+        // time-varying stage objects over the car (uniform dimensions): dynamics kind by t % 3, cost kind by
+        // halves of the horizon, constraint kind by t % 4 (5 inequalities / none / 1 equality / none)
+        z->dyn = make_dynamics<3, 2, CarF>();
+        z->dyn2 = make_dynamics<3, 2, CarEulerF>();
+        quad_init(&z->qs, 3, 2); quad_init(&z->qt, 3, 0); quad_init(&z->qs2, 3, 2);
+        for (int i = 0; i < 3; ++i) { z->qs.q[i] = 1.0; z->qt.q[i] = 1000.0; z->qs.xg[i] = CAR_XT[i]; z->qt.xg[i] = CAR_XT[i]; }
+        z->qs.r[0] = z->qs.r[1] = 1.0e-2;
+        z->qs2.q[0] = 5.0; z->qs2.q[1] = 2.0; z->qs2.q[2] = 0.5;
+        z->qs2.xg[0] = 0.9; z->qs2.xg[1] = 1.1; z->qs2.xg[2] = 0.2;
+        z->qs2.r[0] = 0.05; z->qs2.r[1] = 0.02;
+        z->ks.evaluate = car_stage_eval; z->ks.jacobian_state = car_stage_jx; z->ks.jacobian_action = car_stage_ju;
+        z->ks.num_constraint = 5; z->ks.num_state = 3; z->ks.num_action = 2;
+        z->ks.num_inequality = 5; for (int i = 0; i < 5; ++i) z->ks.indices_inequality[i] = i;
+        z->ks2 = make_empty_constraint();
+        z->ks3 = make_empty_constraint();
+        z->ks3.evaluate = cartv_eq_eval; z->ks3.jacobian_state = cartv_eq_jx; z->ks3.jacobian_action = cartv_eq_ju;
+        z->ks3.num_constraint = 1; z->ks3.num_state = 3; z->ks3.num_action = 2;
+        z->kt.evaluate = car_term_eval; z->kt.jacobian_state = car_term_jx;
+        z->kt.num_constraint = 4; z->kt.num_state = 3;
+        z->kt.num_inequality = 1; z->kt.indices_inequality[0] = 3;
     } else if (!std::strcmp(name, "synth32")) {
         z->dyn = make_dynamics<32, 8, Synth32F>();
         quad_init(&z->qs, 32, 8); quad_init(&z->qt, 32, 0);
@@ -438,6 +476,14 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
     }
     z->cs = make_quad_cost(&z->qs);
     z->ct = make_quad_cost(&z->qt);
+    if (!std::strcmp(name, "car_tv")) {
+        z->cs2 = make_quad_cost(&z->qs2);
+        for (int t = 0; t < T - 1; ++t) {
+            z->dptr.push_back(t % 3 == 2 ? &z->dyn2 : &z->dyn);
+            z->cptr.push_back(2 * t >= T - 1 ? &z->cs2 : &z->cs);
+            z->kptr.push_back(t % 4 == 0 ? &z->ks : (t % 4 == 2 ? &z->ks3 : &z->ks2));
+        }
+    } else
     for (int t = 0; t < T - 1; ++t) { z->dptr.push_back(&z->dyn); z->cptr.push_back(&z->cs); z->kptr.push_back(&z->ks); }
     z->cptr.push_back(&z->ct); z->kptr.push_back(&z->kt);
     out->T = T; out->nx = z->dyn.num_state; out->nu = z->dyn.num_action; out->nw = z->dyn.num_parameter;

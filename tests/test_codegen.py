@@ -166,3 +166,35 @@ def test_user_model_codegen_roundtrip(tmp_path):
         c = np.zeros(3); L.con_s(_p(np.ascontiguousarray(z[:2])), _p(np.ascontiguousarray(z[2:])), _p(c)); return c
     cx = np.zeros(6); cu = np.zeros(6); L.con_s_jac(_p(x), _p(u), _p(cx), _p(cu))
     assert np.allclose(np.c_[cx.reshape(2, 3).T, cu.reshape(2, 3).T], fd(Cn, np.r_[x, u], 3), atol=1e-7)
+
+
+def test_time_varying_objects_lowering():
+    """lowering.lower: with the selectors of step t substituted, the combined stage objects ARE object t."""
+    import sympy as sp
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
+    T = 13
+    dynamics, costs, constraints = pkg.models.car_tv(T)
+    low = pkg.lowering.lower(dynamics, costs, constraints)
+    sel, nwu = low["selectors"], low["num_user_parameter"]
+    assert nwu == 0 and sel.shape == (T, 2 + 2 + 3) and (sel[-1] == 0).all()
+    assert (sel[:-1].sum(axis=1) == 3).all()                         # one-hot per category
+    D, Cs, Ks = low["dynamics"], low["cost_stage"], low["con_stage"]
+    assert Ks.num_constraint == 6 and sorted(Ks.indices_inequality) == [1, 2, 3, 4, 5]
+    for t in range(T - 1):
+        sub = {D.w[nwu + j]: sel[t, j] for j in range(sel.shape[1])}
+        same = lambda a, b: sp.simplify(sp.sympify(a).subs(sub) - b) == 0
+        assert all(same(a, b) for a, b in zip(D.evaluate, dynamics[t].evaluate))
+        assert all(same(a, b) for ra, rb in zip(D.jacobian_state, dynamics[t].jacobian_state) for a, b in zip(ra, rb))
+        assert same(Cs.evaluate, costs[t].evaluate)
+        assert all(same(a, b) for ra, rb in zip(Cs.hessian_state_state, costs[t].hessian_state_state) for a, b in zip(ra, rb))
+        rows = low["constraint_rows"][t]
+        assert len(rows) == constraints[t].num_constraint
+        for i in range(Ks.num_constraint):
+            want = constraints[t].evaluate[rows.index(i)] if i in rows else 0
+            assert same(Ks.evaluate[i], want)
+    # uniform objects pass through untouched
+    one = pkg.models.car()
+    low1 = pkg.lowering.lower([one["dynamics"]] * 4, [one["cost_stage"]] * 4 + [one["cost_term"]],
+                              [one["con_stage"]] * 4 + [one["con_term"]])
+    assert low1["dynamics"] is one["dynamics"] and low1["selectors"].shape[1] == 0

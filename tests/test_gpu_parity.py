@@ -545,3 +545,34 @@ def test_plain_c_caller_of_the_abi(pkg, tmp_path):
     out = subprocess.run([exe, "192"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "reached the goal" in out.stdout
+
+
+def test_time_varying_stage_objects(pkg, oracle):
+    """Vectors of DISTINCT per-step objects (README.md:26 of the reference): two dynamics, two stage costs and three
+    stage constraints (5 inequalities / none / 1 equality) alternating along the horizon, lowered exactly onto
+    the one-template kernel by selectors in θ_t (lowering.py). The oracle evaluates the genuinely per-step objects
+    (oracle/models.cpp "car_tv")."""
+    T, B = 51, 48
+    _, _, x1, ub = pkg.workloads.make_inputs("car", B)
+    dynamics, costs, constraints = pkg.models.car_tv(T)
+    sol = pkg.Solver(dynamics, costs, constraints, batch=B, options=pkg.Options(verbose=0), name="car_tv")
+    assert (sol.nx, sol.nu, sol.nc_stage, sol.nc_term, sol.num_user_parameter) == (3, 2, 6, 4, 0)
+    sol.initialize_rollout_(x1, ub)
+    ref = oracle.solve_batch("car_tv", T, x1, ub, nthreads=4)
+    xb0 = np.stack([oracle.Problem("car_tv", T).rollout(x1[b], ub[b]) for b in range(4)])
+    assert np.abs(sol.buffer("nominal_states").reshape(B, T, 3)[:4] - xb0).max() < 1e-12     # time-varying dynamics
+    sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.9, same.mean()
+    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    assert np.abs(K - ref["K"])[same].max() <= 1e-5 * np.abs(ref["K"]).max()
+    assert np.allclose(st["objective"][same], ref["stats"]["objective"][same], rtol=1e-8)
+    assert np.allclose(st["max_violation"][same], ref["stats"]["max_violation"][same], atol=1e-8)
+    # rows of the switched-off constraint kinds: zero violation, zero multiplier
+    c = sol.buffer("violations").reshape(B, -1)[:, :(T - 1) * 6].reshape(B, T - 1, 6)
+    lam = sol.buffer("constraint_dual").reshape(B, -1)[:, :(T - 1) * 6].reshape(B, T - 1, 6)
+    for t in range(T - 1):
+        off = [i for i in range(6) if i not in sol.constraint_rows[t]]
+        assert (c[:, t, off] == 0).all() and (lam[:, t, off] == 0).all()
+    sol.close()

@@ -7,7 +7,7 @@ from collections import Counter
 
 src = open(sys.argv[1]).read()
 for kname in sys.argv[2:]:
-    m = re.search(r"^(_Z[0-9]+" + kname + r"[A-Za-z0-9_]*):[^\n]*\n(.*?)s_endpgm", src, re.S | re.M)
+    m = re.search(r"^(_Z\w*" + kname + r"\w*):[^\n]*\n(.*?)s_endpgm", src, re.S | re.M)
     if not m:
         print("kernel not found:", kname)
         continue
