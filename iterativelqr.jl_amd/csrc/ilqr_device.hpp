@@ -94,10 +94,20 @@ __device__ __forceinline__ void load_w(const double* W, int t, double (&w)[cdim<
 // Optional per-phase cycle accounting (build with -DILQR_PROFILE): shader-clock
 // ticks (s_memtime) spent in each phase are accumulated per instance and written
 // to scalar slots S_PROF.. of the workspace (tools/phase_cycles.py prints them).
-#ifdef ILQR_PROFILE
+// -DILQR_PROFILE -DILQR_PROFILE_SUB instead splits ONE phase into up to six sub-phases (ILQR_SUB_MARK).
+#if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
+#define ILQR_PROF_BEGIN() do {} while (0)
+#define ILQR_PROF_END(I, slot) do {} while (0)
+#define ILQR_SUB_BEGIN() long long sub_t0_ = clock64()
+#define ILQR_SUB_MARK(I, slot) do { const long long t1_ = clock64(); (I).prof[slot] += (double)(t1_ - sub_t0_); sub_t0_ = t1_; } while (0)
+#elif defined(ILQR_PROFILE)
 #define ILQR_PROF_BEGIN() const long long prof_t0_ = clock64()
 #define ILQR_PROF_END(I, slot) (I).prof[slot] += (double)(clock64() - prof_t0_)
+#define ILQR_SUB_BEGIN() do {} while (0)
+#define ILQR_SUB_MARK(I, slot) do {} while (0)
 #else
+#define ILQR_SUB_BEGIN() do {} while (0)
+#define ILQR_SUB_MARK(I, slot) do {} while (0)
 #define ILQR_PROF_BEGIN() do {} while (0)
 #define ILQR_PROF_END(I, slot) do {} while (0)
 #endif
@@ -384,25 +394,62 @@ __device__ void gradients_small(Inst<M>& I, bool constrained) {
 // ------------------------------------------------ LAPACK potrf('U') / potrs('U')
 // Unblocked right-looking order of dpotf2; returns LAPACK info (ignored by the
 // reference, src/backward_pass.jl:69 — we only record it).
+// Unblocked dpotf2 order: row j is scaled by ONE / AJJ (DSCAL), as LAPACK and OpenBLAS's potf2 do. R[j] = 1 / U(j,j)
+// is handed out for solves that multiply by the inverted diagonal (what OpenBLAS's TRSM kernels do); after a
+// failed factorisation (info > 0, ignored by the reference) R holds the reciprocals of whatever is on the diagonal.
 template <int m>
-__device__ __forceinline__ int potrf_U(double (&A)[m * m]) {
+__device__ __forceinline__ int potrf_U(double (&A)[m * m], double (&R)[m]) {
+    int info = 0;
 #pragma unroll
     for (int j = 0; j < m; ++j) {
-        double ajj = A[j * m + j];
+        if (info == 0) {
+            double ajj = A[j * m + j];
 #pragma unroll
-        for (int l = 0; l < j; ++l) ajj -= A[j * m + l] * A[j * m + l];
-        if (!(ajj > 0.0)) { A[j * m + j] = ajj; return j + 1; }
-        ajj = sqrt(ajj);
-        A[j * m + j] = ajj;
+            for (int l = 0; l < j; ++l) ajj -= A[j * m + l] * A[j * m + l];
+            if (!(ajj > 0.0)) { A[j * m + j] = ajj; info = j + 1; }
+            else {
+                ajj = sqrt(ajj);
+                A[j * m + j] = ajj;
+                const double r = 1.0 / ajj;
+                R[j] = r;
 #pragma unroll
-        for (int c = j + 1; c < m; ++c) {
-            double v = A[c * m + j];
+                for (int c = j + 1; c < m; ++c) {
+                    double v = A[c * m + j];
 #pragma unroll
-            for (int l = 0; l < j; ++l) v -= A[j * m + l] * A[c * m + l];
-            A[c * m + j] = v / ajj;
+                    for (int l = 0; l < j; ++l) v -= A[j * m + l] * A[c * m + l];
+                    A[c * m + j] = v * r;
+                }
+            }
+        }
+        if (info != 0) R[j] = 1.0 / A[j * m + j];
+    }
+    return info;
+}
+template <int m>
+__device__ __forceinline__ int potrf_U(double (&A)[m * m]) {
+    double R[m];
+    return potrf_U<m>(A, R);
+}
+// potrs('U') with the inverted diagonal R
+template <int m, int nrhs>
+__device__ __forceinline__ void potrs_U_rdiag(const double (&U)[m * m], const double (&R)[m], double (&B)[m * nrhs]) {
+#pragma unroll
+    for (int c = 0; c < nrhs; ++c) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            double v = B[c * m + i];
+#pragma unroll
+            for (int l = 0; l < i; ++l) v -= U[i * m + l] * B[c * m + l];
+            B[c * m + i] = v * R[i];
+        }
+#pragma unroll
+        for (int i = m - 1; i >= 0; --i) {
+            double v = B[c * m + i];
+#pragma unroll
+            for (int l = i + 1; l < m; ++l) v -= U[l * m + i] * B[c * m + l];
+            B[c * m + i] = v * R[i];
         }
     }
-    return 0;
 }
 template <int m, int nrhs>
 __device__ __forceinline__ void potrs_U(const double (&U)[m * m], double (&B)[m * nrhs]) {
@@ -554,8 +601,9 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
 #pragma unroll
             for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
         int info = 0;
+        double Ur[m];                                                   // inverted diagonal of the factor
         if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
-        else info = potrf_U<m>(Uc);
+        else info = potrf_U<m>(Uc, Ur);
         if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
         // potrs('U') for K (block 0: m x n) and k (block 1, column 0) at once   (:70-75)
         const double Qu_b1 = row_from_prev_quad(Qu);                    // block 0 -> block 1
@@ -565,7 +613,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             // (~220 clk) on the serial chain. The literal path below still runs when potrf fails.
             Y = Y / Uc[0];
         } else {
-            if (m == 1) potrf_U<m>(Uc);
+            if (m == 1) potrf_U<m>(Uc, Ur);
 #pragma unroll
             for (int i = 0; i < m; ++i) {                               // U^T y = b
 #pragma unroll
@@ -574,7 +622,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
                     const double v = Y - Uc[i * m + l] * yl;
                     Y = (r == i) ? v : Y;
                 }
-                const double q = Y / Uc[i * m + i];
+                const double q = Y * Ur[i];
                 Y = (r == i) ? q : Y;
             }
 #pragma unroll
@@ -585,7 +633,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
                     const double v = Y - Uc[l * m + i] * xl;
                     Y = (r == i) ? v : Y;
                 }
-                const double q = Y / Uc[i * m + i];
+                const double q = Y * Ur[i];
                 Y = (r == i) ? q : Y;
             }
         }

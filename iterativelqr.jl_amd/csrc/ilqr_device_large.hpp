@@ -16,49 +16,81 @@
 
 namespace ilqr {
 
+constexpr int r16(int v) { return (v + 15) & ~15; }
+constexpr int r4(int v) { return (v + 3) & ~3; }
+
 template <class M>
 struct LargeDims {
     static constexpr int n = M::NX, m = M::NU;
-    static constexpr int ld = n | 1;      // odd leading dimensions: conflict-free LDS column walks
-    static constexpr int ldm = m | 1;
-    // LDS carve (doubles)
-    static constexpr int oP = 0, oFx = oP + n * ld, oT = oFx + n * ld, oQxx = oT + n * ld,
-                         oFu = oQxx + n * ld, oUh = oFu + m * ld, oQux = oUh + n * ldm, oK = oQux + n * ldm,
-                         oUxt = oK + n * ldm, oQuu = oUxt + n * ldm, oVec = oQuu + m * ldm,
-                         total = oVec + 4 * n + 4 * m + 8;
+    static constexpr int NP = r16(n), MP = r16(m);          // whole 16x16 tiles; the padding is kept at zero
+    static constexpr int ld = NP + 1, ldm = MP + 1;         // odd leading dimensions: conflict-free LDS column walks
+    // LDS carve (doubles); must match large_lds_doubles() of ilqr_layout.hpp
+    static constexpr int oP = 0, oFx = oP + NP * ld, oT = oFx + NP * ld, oFu = oT + NP * ld, oUh = oFu + MP * ld,
+                         oQux = oUh + NP * ldm, oK = oQux + NP * ldm, oUxt = oK + NP * ldm, oQuu = oUxt + NP * ldm,
+                         oVec = oQuu + MP * ldm, total = oVec + 4 * NP + 4 * MP + 8;
 };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// D (R x Cc, column-major, leading dimension ldd, in LDS) = [D +] op(A) * op(B), inner dimension Kd.
-// A(i,k) lives at A[a_i * i + a_k * k], B(k,j) at B[b_k * k + b_j * j] (any transposition for free).
-// Everything outside the real extents reads as zero, so dimensions need not be multiples of the tile.
-__device__ __forceinline__ void tile_gemm(double* D, int ldd, int R, int Cc, const double* A, int a_i, int a_k,
-                                          const double* B, int b_k, int b_j, int Kd, bool accumulate, int lane) {
-    const int li = lane & 15, lk = lane >> 4;
-    for (int I0 = 0; I0 < R; I0 += 16)
-        for (int J0 = 0; J0 < Cc; J0 += 16) {
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
-            const int col = J0 + li;
-            if (accumulate) {
+// One 16x16 output tile on v_mfma_f64_16x16x4_f64: acc += sum_{k<KD} A(I0+li, k) * B(k, J0+li), where
+// A(i,k) lives at A[AI*i + AK*k] and B(k,j) at B[BK*k + BJ*j] (any transposition is just a stride pattern).
+// Strides and KD are compile-time: every operand read is a ds_read_b64 with an immediate offset from one
+// per-lane base, the loop is fully unrolled, and the operands are zero-padded so there are no bounds checks.
+template <int KD, int AI, int AK, int BK, int BJ>
+__device__ __forceinline__ double4_t tile_mac(double4_t acc, const double* A, const double* B, int I0, int J0, int li,
+                                              int lk) {
+    const double* pa = A + AI * (I0 + li) + AK * lk;
+    const double* pb = B + BK * lk + BJ * (J0 + li);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = I0 + lk + 4 * r;
-                    acc[r] = (row < R && col < Cc) ? D[col * ldd + row] : 0.0;
-                }
-            }
-            for (int s = 0; s < Kd; s += 4) {
-                const int k = s + lk;
-                const double a = (I0 + li < R && k < Kd) ? A[a_i * (I0 + li) + a_k * k] : 0.0;
-                const double b = (col < Cc && k < Kd) ? B[b_k * k + b_j * col] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
+    for (int s = 0; s < KD; s += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[AK * s], pb[BK * s], acc, 0, 0, 0);
+    return acc;
+}
+// D-layout of the tile: element r of lane (li, lk) is (row I0 + lk + 4r, column J0 + li)
+template <int LDD>
+__device__ __forceinline__ void tile_store(double* D, double4_t acc, int I0, int J0, int li, int lk) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = I0 + lk + 4 * r;
-                if (row < R && col < Cc) D[col * ldd + row] = acc[r];
-            }
-        }
+    for (int r = 0; r < 4; ++r) D[(J0 + li) * LDD + I0 + lk + 4 * r] = acc[r];
+}
+// the same elements of a packed column-major global matrix (R x Cc), zero outside
+template <int R, int Cc, class Ptr>
+__device__ __forceinline__ double4_t tile_load_global(Ptr G, int I0, int J0, int li, int lk) {
+    double4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = I0 + lk + 4 * r, col = J0 + li;
+        if constexpr (R % 16 == 0 && Cc % 16 == 0) v[r] = G[col * R + row];
+        else v[r] = (row < R && col < Cc) ? G[col * R + row] : 0.0;
+    }
+    return v;
+}
+
+// Register-blocked product of TR x TC tiles: all operand fragments are read from LDS FIRST (TR*KD/4 + TC*KD/4
+// doubles per lane), then the MFMAs issue back to back, k-step outermost so that consecutive instructions hit
+// different accumulators. Row tile a takes its A operand from Aop[a] (so two matrices can share one B pass).
+template <int TR, int TC, int KD, int AI, int AK, int BK, int BJ>
+__device__ __forceinline__ void tiles_mac(double4_t (&acc)[TR * TC], const double* const (&Aop)[TR], const int (&Arow)[TR],
+                                          const double* B, int li, int lk) {
+    constexpr int KS = KD / 4;
+    double fa[TR][KS], fb[TC][KS];
+#pragma unroll
+    for (int a = 0; a < TR; ++a) {
+        const double* pa = Aop[a] + AI * (Arow[a] + li) + AK * lk;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) fa[a][s] = pa[AK * 4 * s];
+    }
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        const double* pb = B + BK * lk + BJ * (16 * c + li);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) fb[c][s] = pb[BK * 4 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int a = 0; a < TR; ++a)
+#pragma unroll
+            for (int c = 0; c < TC; ++c)
+                acc[a * TC + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][s], fb[c][s], acc[a * TC + c], 0, 0, 0);
 }
 
 // LDS matrix (R x Cc, ldd) += / = global matrix (packed column-major R x Cc)
@@ -131,63 +163,212 @@ __device__ void gradients_large(Inst<M>& I, bool constrained) {
 }
 
 // ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles)
+// One Riccati step (src/backward_pass.jl:42-90) for n = 32, m = 8 issues 132 tile MFMAs (64 cycles each on
+// gfx950: the matrix pipe is the floor, ~8.4 k cycles per step). Everything around them is arranged so that the
+// pipe does not wait: next step's fx, fu, gxx, guu, gux, gx, gu are fetched from HBM into registers a step
+// ahead (the cost Hessians directly in the D-layout of the tiles they are added to), Qxx never leaves the
+// accumulators, and the three products of the P update accumulate in one register tile.
+// The phase is a real (noinline) function: the fused solve kernel inlines every other phase (dense 32-state model
+// code included), and inside that one register allocation the Riccati loop ended up with hundreds of spills
+// whose scratch reloads wait on vmcnt(0), i.e. on the HBM prefetch. As a function it gets its own allocation.
+// Pointers cross the call with their address space attached (a plain double* would turn every access into a
+// flat_load), LDS is re-derived from the dynamic shared symbol.
+typedef __attribute__((address_space(1))) double gdbl;
+template <class T> __device__ __forceinline__ gdbl* as_global(T* p) { return (gdbl*)p; }
+__device__ __forceinline__ gdbl* uniform_ptr(gdbl* p) {
+    unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gdbl*)(((unsigned long long)hi << 32) | lo);
+}
+struct RiccatiArgs { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int N; };
+struct RiccatiOut { double gradient_norm; int potrf_info; double prof[6]; };
+
 template <class M, bool STORE_VALUE>
-__device__ void backward_pass_large(Inst<M>& I) {
+__attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiArgs A) {
     typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, ld = LD::ld, ldm = LD::ldm;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, ldm = LD::ldm;
+    constexpr int n4 = r4(n), m4 = r4(m), TN = NP / 16, TM = MP / 16;
+    constexpr int EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
     static_assert(n <= 32 && m <= 16, "large path: nx <= 32, nu <= 16");
-    const int lane = I.lane, N = I.N;
-    double* S = I.lds;
-    double *sP = S + LD::oP, *sFx = S + LD::oFx, *sT = S + LD::oT, *sQxx = S + LD::oQxx, *sFu = S + LD::oFu,
-           *sUh = S + LD::oUh, *sQux = S + LD::oQux, *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
-    double *sp = S + LD::oVec, *sQx = sp + n, *sQu = sQx + n, *sk = sQu + m;
-    lds_load_global(sP, ld, n, n, I.gxx + (size_t)N * n * n, lane);       // P[H] .= gxx[H]  (:39)
-    for (int i = lane; i < n; i += 64) sp[i] = I.gx[N * n + i];           // p[H] .= gx[H]   (:40)
-    if (STORE_VALUE) {
-        for (int e = lane; e < n * n; e += 64) I.P[(size_t)N * n * n + e] = I.gxx[(size_t)N * n * n + e];
-        for (int i = lane; i < n; i += 64) I.p[N * n + i] = I.gx[N * n + i];
+    static_assert(LD::total == large_lds_doubles(n, m), "LDS carve and host-side size disagree");
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    struct { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int potrf_info; double prof[6]; } I;
+    I.fx = uniform_ptr(A.fx); I.fu = uniform_ptr(A.fu); I.gx = uniform_ptr(A.gx); I.gu = uniform_ptr(A.gu);
+    I.gxx = uniform_ptr(A.gxx); I.guu = uniform_ptr(A.guu); I.gux = uniform_ptr(A.gux); I.K = uniform_ptr(A.K);
+    I.k = uniform_ptr(A.k); I.Lx = uniform_ptr(A.Lx); I.Lu = uniform_ptr(A.Lu); I.P = uniform_ptr(A.P); I.p = uniform_ptr(A.p);
+    I.potrf_info = 0;
+    for (int q = 0; q < 6; ++q) I.prof[q] = 0.0;
+    const int lane = threadIdx.x, N = __builtin_amdgcn_readfirstlane(A.N), li = lane & 15, lk = lane >> 4;
+    double* S = lds_dyn;
+    double *sP = S + LD::oP, *sFx = S + LD::oFx, *sT = S + LD::oT, *sFu = S + LD::oFu, *sUh = S + LD::oUh,
+           *sQux = S + LD::oQux, *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
+    double *sp = S + LD::oVec, *sQx = sp + NP, *sQu = sQx + NP, *sk = sQu + MP;
+    for (int e = lane; e < LD::total; e += 64) S[e] = 0.0;               // the tile padding must read as zero
+    __syncthreads();
+    for (int e = lane; e < n * n; e += 64) {                              // P[H] .= gxx[H]  (:39)
+        const double v = I.gxx[(size_t)N * n * n + e];
+        sP[(e / n) * ld + e % n] = v;
+        if (STORE_VALUE) I.P[(size_t)N * n * n + e] = v;
     }
+    for (int i = lane; i < n; i += 64) {                                  // p[H] .= gx[H]   (:40)
+        const double v = I.gx[N * n + i];
+        sp[i] = v;
+        if (STORE_VALUE) I.p[N * n + i] = v;
+    }
+    // register prefetch of step t's operands
+    double rfx[EFX], rfu[EFU], rgv = 0.0;
+    double4_t rgxx[TN * TN], rguu[TM * TM], rgux[TM * TN];
+    auto fetch_early = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < EFX; ++q) {
+            const int e = lane + 64 * q;
+            if constexpr ((n * n) % 64 == 0) rfx[q] = I.fx[(size_t)t * n * n + e];
+            else rfx[q] = e < n * n ? I.fx[(size_t)t * n * n + e] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < EFU; ++q) {
+            const int e = lane + 64 * q;
+            if constexpr ((n * m) % 64 == 0) rfu[q] = I.fu[(size_t)t * n * m + e];
+            else rfu[q] = e < n * m ? I.fu[(size_t)t * n * m + e] : 0.0;
+        }
+        rgv = lane < n ? I.gx[t * n + lane] : (lane < n + m ? I.gu[t * m + (lane - n)] : 0.0);
+    };
+    auto fetch_late = [&](int t) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int c = 0; c < TN; ++c) rgxx[a * TN + c] = tile_load_global<n, n>(I.gxx + (size_t)t * n * n, 16 * a, 16 * c, li, lk);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int c = 0; c < TM; ++c) rguu[a * TM + c] = tile_load_global<m, m>(I.guu + (size_t)t * m * m, 16 * a, 16 * c, li, lk);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int c = 0; c < TN; ++c) rgux[a * TN + c] = tile_load_global<m, n>(I.gux + (size_t)t * m * n, 16 * a, 16 * c, li, lk);
+    };
+    if (N > 0) { fetch_early(N - 1); fetch_late(N - 1); }
     double gmax = 0.0;
     __syncthreads();
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
-        lds_load_global(sFx, ld, n, n, I.fx + (size_t)t * n * n, lane);
-        lds_load_global(sFu, ld, n, m, I.fu + (size_t)t * n * m, lane);
-        __syncthreads();
-        // Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49): one output per lane
-        for (int i = lane; i < n + m; i += 64) {
-            const double* colp = i < n ? sFx + i * ld : sFu + (i - n) * ld;
-            double acc = 0.0;
-            for (int l = 0; l < n; ++l) acc += colp[l] * sp[l];
-            if (i < n) sQx[i] = acc + I.gx[t * n + i];
-            else sQu[i - n] = acc + I.gu[t * m + (i - n)];
+        ILQR_SUB_BEGIN();
+#pragma unroll
+        for (int q = 0; q < EFX; ++q) {
+            const int e = lane + 64 * q;
+            if ((n * n) % 64 == 0 || e < n * n) sFx[(e / n) * ld + e % n] = rfx[q];
         }
-        // Qxx = (fx^T P') fx + gxx   (:52-54)
-        tile_gemm(sT, ld, n, n, sFx, ld, 1, sP, 1, ld, n, false, lane);
-        // ux_hat = fu^T P'   (:57, :62)
-        tile_gemm(sUh, ldm, m, n, sFu, ld, 1, sP, 1, ld, n, false, lane);
+#pragma unroll
+        for (int q = 0; q < EFU; ++q) {
+            const int e = lane + 64 * q;
+            if ((n * m) % 64 == 0 || e < n * m) sFu[(e / n) * ld + e % n] = rfu[q];
+        }
+        const double gv = rgv;
         __syncthreads();
-        tile_gemm(sQxx, ld, n, n, sT, 1, ld, sFx, 1, ld, n, false, lane);
-        tile_gemm(sQuu, ldm, m, m, sUh, 1, ldm, sFu, 1, ld, n, false, lane);   // Quu = ux_hat fu + guu (:58-59)
-        tile_gemm(sQux, ldm, m, n, sUh, 1, ldm, sFx, 1, ld, n, false, lane);   // Qux = ux_hat fx + gux (:63-64)
+        if (t > 0) fetch_early(t - 1);
+        // Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49): one output per lane
+        if (lane < n + m) {
+            const double* colp = lane < n ? sFx + lane * ld : sFu + (lane - n) * ld;
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < n; ++l) acc += colp[l] * sp[l];
+            if (lane < n) sQx[lane] = acc + gv;
+            else sQu[lane - n] = acc + gv;
+        }
+        ILQR_SUB_MARK(I, 0);
+        // [T; ux_hat] = [fx fu]^T P'  (:52, :57, :62): one pass over the P' fragments
+        {
+            constexpr int TR = TN + TM;
+            double4_t acc[TR * TN];
+#pragma unroll
+            for (int q = 0; q < TR * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
+            const double* Aop[TR]; int Arow[TR];
+#pragma unroll
+            for (int a = 0; a < TR; ++a) { Aop[a] = a < TN ? sFx : sFu; Arow[a] = a < TN ? 16 * a : 16 * (a - TN); }
+            tiles_mac<TR, TN, n4, ld, 1, 1, ld>(acc, Aop, Arow, sP, li, lk);
+#pragma unroll
+            for (int a = 0; a < TR; ++a)
+#pragma unroll
+                for (int c = 0; c < TN; ++c) {
+                    if (a < TN) tile_store<ld>(sT, acc[a * TN + c], 16 * a, 16 * c, li, lk);
+                    else tile_store<ldm>(sUh, acc[a * TN + c], 16 * (a - TN), 16 * c, li, lk);
+                }
+        }
         __syncthreads();
-        lds_add_global(sQxx, ld, n, n, I.gxx + (size_t)t * n * n, lane);
-        lds_add_global(sQuu, ldm, m, m, I.guu + (size_t)t * m * m, lane);
-        lds_add_global(sQux, ldm, m, n, I.gux + (size_t)t * m * n, lane);
+        ILQR_SUB_MARK(I, 1);
+        // [Qxx; Qux] = [T; ux_hat] fx + [gxx; gux] (:53-54, :63-64): Qxx stays in the accumulators
+        double4_t qxx[TN * TN];
+        {
+            constexpr int TR = TN + TM;
+            double4_t acc[TR * TN];
+#pragma unroll
+            for (int q = 0; q < TR * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
+            const double* Aop[TR]; int Arow[TR];
+#pragma unroll
+            for (int a = 0; a < TR; ++a) { Aop[a] = a < TN ? sT : sUh; Arow[a] = a < TN ? 16 * a : 16 * (a - TN); }
+            // A(i,k) = T(i,k) at sT[k*ld + i] resp. ux_hat(i,k) at sUh[k*ldm + i]: different leading dimensions
+            {
+                constexpr int KS = n4 / 4;
+                double fa[TR][KS], fb[TN][KS];
+#pragma unroll
+                for (int a = 0; a < TR; ++a)
+#pragma unroll
+                    for (int sx = 0; sx < KS; ++sx)
+                        fa[a][sx] = a < TN ? sT[(4 * sx + lk) * ld + 16 * a + li] : sUh[(4 * sx + lk) * ldm + 16 * (a - TN) + li];
+#pragma unroll
+                for (int c = 0; c < TN; ++c)
+#pragma unroll
+                    for (int sx = 0; sx < KS; ++sx) fb[c][sx] = sFx[(16 * c + li) * ld + 4 * sx + lk];
+#pragma unroll
+                for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+                    for (int a = 0; a < TR; ++a)
+#pragma unroll
+                        for (int c = 0; c < TN; ++c)
+                            acc[a * TN + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][sx], fb[c][sx], acc[a * TN + c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int c = 0; c < TN; ++c) qxx[a * TN + c] = acc[a * TN + c] + rgxx[a * TN + c];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int c = 0; c < TN; ++c)
+                    tile_store<ldm>(sQux, acc[(TN + a) * TN + c] + rgux[a * TN + c], 16 * a, 16 * c, li, lk);
+        }
+        // Quu = ux_hat fu + guu (:58-59)
+        {
+            double4_t acc[TM * TM];
+#pragma unroll
+            for (int q = 0; q < TM * TM; ++q) acc[q] = double4_t{0, 0, 0, 0};
+            const double* Aop[TM]; int Arow[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) { Aop[a] = sUh; Arow[a] = 16 * a; }
+            tiles_mac<TM, TM, n4, 1, ldm, 1, ld>(acc, Aop, Arow, sFu, li, lk);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int c = 0; c < TM; ++c) tile_store<ldm>(sQuu, acc[a * TM + c] + rguu[a * TM + c], 16 * a, 16 * c, li, lk);
+        }
         __syncthreads();
+        ILQR_SUB_MARK(I, 2);
+        if (t > 0) fetch_late(t - 1);
         // potrf('U') on wave-uniform registers (info ignored, :68-69)
         double Uc[m * m];
 #pragma unroll
         for (int j = 0; j < m; ++j)
 #pragma unroll
             for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? sQuu[j * ldm + i] : 0.0;
-        const int info = potrf_U<m>(Uc);
+        double Ur[m];
+        const int info = potrf_U<m>(Uc, Ur);
         if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
+        ILQR_SUB_MARK(I, 3);
         // potrs('U'): column j of Qux per lane, Qu on lane n   (:70-75)
         for (int j = lane; j <= n; j += 64) {
             double b[m];
 #pragma unroll
             for (int i = 0; i < m; ++i) b[i] = j < n ? sQux[j * ldm + i] : sQu[i];
-            potrs_U<m, 1>(Uc, b);
+            potrs_U_rdiag<m, 1>(Uc, Ur, b);           // inverted diagonal from the factorisation: no divisions here
 #pragma unroll
             for (int i = 0; i < m; ++i) {
                 const double v = b[i] * -1.0;
@@ -196,48 +377,92 @@ __device__ void backward_pass_large(Inst<M>& I) {
             }
         }
         __syncthreads();
+        ILQR_SUB_MARK(I, 4);
         // ux_tmp = Quu K   (:79)
-        tile_gemm(sUxt, ldm, m, n, sQuu, 1, ldm, sK, 1, ldm, m, false, lane);
+        {
+            double4_t acc[TM * TN];
+#pragma unroll
+            for (int q = 0; q < TM * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
+            const double* Aop[TM]; int Arow[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) { Aop[a] = sQuu; Arow[a] = 16 * a; }
+            tiles_mac<TM, TN, m4, 1, ldm, 1, ldm>(acc, Aop, Arow, sK, li, lk);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int c = 0; c < TN; ++c) tile_store<ldm>(sUxt, acc[a * TN + c], 16 * a, 16 * c, li, lk);
+        }
         __syncthreads();
-        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order into sT
-        tile_gemm(sT, ld, n, n, sK, ldm, 1, sUxt, 1, ldm, m, false, lane);
-        __syncthreads();
-        tile_gemm(sT, ld, n, n, sK, ldm, 1, sQux, 1, ldm, m, true, lane);
-        __syncthreads();
-        tile_gemm(sT, ld, n, n, sQux, ldm, 1, sK, 1, ldm, m, true, lane);
-        __syncthreads();
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e % n, j = e / n;
-            const double v = sT[j * ld + i] + sQxx[j * ld + i];
-            sP[j * ld + i] = v;
-            if (STORE_VALUE) I.P[(size_t)t * n * n + e] = v;
+        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order
+        {
+            double4_t acc[TN * TN];
+#pragma unroll
+            for (int q = 0; q < TN * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
+            const double* Ak[TN]; const double* Aq[TN]; int Arow[TN];
+#pragma unroll
+            for (int a = 0; a < TN; ++a) { Ak[a] = sK; Aq[a] = sQux; Arow[a] = 16 * a; }
+            tiles_mac<TN, TN, m4, ldm, 1, 1, ldm>(acc, Ak, Arow, sUxt, li, lk);
+            tiles_mac<TN, TN, m4, ldm, 1, 1, ldm>(acc, Ak, Arow, sQux, li, lk);
+            tiles_mac<TN, TN, m4, ldm, 1, 1, ldm>(acc, Aq, Arow, sK, li, lk);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int c = 0; c < TN; ++c) {
+                    const double4_t v = acc[a * TN + c] + qxx[a * TN + c];
+                    tile_store<ld>(sP, v, 16 * a, 16 * c, li, lk);
+                    if (STORE_VALUE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
+                            if (row < n && col < n) I.P[(size_t)t * n * n + col * n + row] = v[r];
+                        }
+                    }
+                }
         }
         // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89); Lagrangian gradient (src/solve.jl:73-81)
-        for (int i = lane; i < n; i += 64) {
+        double pn = 0.0;
+        if (lane < n) {
             double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
             for (int l = 0; l < m; ++l) {
-                a1 += sUxt[i * ldm + l] * sk[l];
-                a2 += sK[i * ldm + l] * sQu[l];
-                a3 += sQux[i * ldm + l] * sk[l];
+                a1 += sUxt[lane * ldm + l] * sk[l];
+                a2 += sK[lane * ldm + l] * sQu[l];
+                a3 += sQux[lane * ldm + l] * sk[l];
             }
-            const double pn = ((a1 + a2) + a3) + sQx[i];
-            const double Lx = sQx[i] - pn;
+            pn = ((a1 + a2) + a3) + sQx[lane];
+            const double Lx = sQx[lane] - pn;
             gmax = nanmax(gmax, fabs(Lx));
-            I.Lx[t * n + i] = Lx;
-            if (STORE_VALUE) I.p[t * n + i] = pn;
-            sQx[i] = pn;                      // becomes p' of the next step (copied below)
+            I.Lx[t * n + lane] = Lx;
+            if (STORE_VALUE) I.p[t * n + lane] = pn;
         }
-        for (int i = lane; i < m; i += 64) {
-            gmax = nanmax(gmax, fabs(sQu[i]));
-            I.Lu[t * m + i] = sQu[i];
+        if (lane < m) {
+            gmax = nanmax(gmax, fabs(sQu[lane]));
+            I.Lu[t * m + lane] = sQu[lane];
         }
         __syncthreads();
-        for (int i = lane; i < n; i += 64) sp[i] = sQx[i];
+        if (lane < n) sp[lane] = pn;                                      // p' of the next step
         __syncthreads();
+        ILQR_SUB_MARK(I, 5);
     }
-    I.gradient_norm = wave_max(gmax);
+    RiccatiOut out;
+    out.gradient_norm = wave_max(gmax);
+    out.potrf_info = I.potrf_info;
+    for (int q = 0; q < 6; ++q) out.prof[q] = I.prof[q];
     __syncthreads();
+    return out;
+}
+
+template <class M, bool STORE_VALUE>
+__device__ __forceinline__ void backward_pass_large(Inst<M>& I) {
+    RiccatiArgs A{as_global(I.fx), as_global(I.fu), as_global(I.gx), as_global(I.gu), as_global(I.gxx), as_global(I.guu),
+                  as_global(I.gux), as_global(I.K), as_global(I.k), as_global(I.Lx), as_global(I.Lu), as_global(I.P),
+                  as_global(I.p), I.N};
+    const RiccatiOut o = backward_pass_large_fn<M, STORE_VALUE>(A);
+    I.gradient_norm = o.gradient_norm;
+    if (o.potrf_info != 0 && I.potrf_info == 0) I.potrf_info = o.potrf_info;
+#if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
+    for (int q = 0; q < 6; ++q) I.prof[q] += o.prof[q];
+#endif
 }
 
 // ---------------------------------------------------------------- rollout! (wave-uniform state, lane-parallel policy)

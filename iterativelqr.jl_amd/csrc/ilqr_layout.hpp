@@ -33,9 +33,9 @@ inline __host__ __device__ int pad2(int v) { return (v + 1) & ~1; }   // keep 16
 // models with nx > 4 or nu > 4 take the HBM-resident large path (ilqr_device_large.hpp)
 inline __host__ __device__ bool is_large_model(int nx, int nu) { return nx > 4 || nu > 4; }
 // LDS staging of the large path (must match LargeDims<M>::total)
-inline __host__ __device__ int large_lds_doubles(int n, int m) {
-    const int ld = n | 1, ldm = m | 1;
-    return 4 * n * ld + m * ld + 4 * n * ldm + m * ldm + 4 * n + 4 * m + 8;
+constexpr __host__ __device__ int large_lds_doubles(int n, int m) {
+    const int NP = (n + 15) & ~15, MP = (m + 15) & ~15, ld = NP + 1, ldm = MP + 1;
+    return 3 * NP * ld + MP * ld + 4 * NP * ldm + MP * ldm + 4 * NP + 4 * MP + 8;
 }
 
 inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, int nct, int T) {

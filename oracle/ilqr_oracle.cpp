@@ -413,10 +413,11 @@ static int potrf_U(double* A, int m) {
         if (!(ajj > 0.0)) { A[j * m + j] = ajj; return j + 1; }
         ajj = std::sqrt(ajj);
         A[j * m + j] = ajj;
+        const double r = 1.0 / ajj;             // dpotf2: CALL DSCAL(N-J, ONE / AJJ, A(J,J+1), LDA)
         for (int c = j + 1; c < m; ++c) {
             double v = A[c * m + j];
             for (int l = 0; l < j; ++l) v -= A[j * m + l] * A[c * m + l];
-            A[c * m + j] = v / ajj;
+            A[c * m + j] = v * r;
         }
     }
     return 0;
