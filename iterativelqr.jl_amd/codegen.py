@@ -286,6 +286,71 @@ def _prune_unpack(unpack, body):
     return keep
 
 
+def _table(name, rows):
+    """static constexpr double name[R][C] = {...};"""
+    body = ",\n".join("        {" + ", ".join(repr(float(v)) for v in r) + "}" for r in rows)
+    return ["    static constexpr double %s[%d][%d] = {" % (name, len(rows), len(rows[0])), body, "    };"]
+
+
+def _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu):
+    """Extra members for models on the HBM-resident large path (ilqr_device_large.hpp):
+
+    * JAC_CONST_FX / JAC_CONST_FU + dyn_jac_var_mem: the Jacobian entries that do not depend on (x, u, w) — for
+      mostly-linear models nearly all of them — are written by coalesced wave-wide stores from these tables and
+      only the JAC_NVAR state-dependent entries are evaluated and stored per timestep;
+    * DYN_AFF + dyn_rem_wave: y = DYN_AFF [x; u; 1] + r(x, u, w). The affine part of row i is evaluated by lane i
+      (one FMA chain per lane instead of the whole dense model on every lane); the remainder r keeps the
+      wave-cooperative trig form of dyn_wave.
+    """
+    xs, us = dynamics.x, dynamics.u
+    z = list(xs) + list(us)
+    # --- Jacobian split
+    cfx = [[0.0] * (n * n)]
+    cfu = [[0.0] * (n * m)]
+    var = []
+    for j in range(n):
+        for i in range(n):
+            e = sp.sympify(dynamics.jacobian_state[i][j])
+            if e.free_symbols:
+                var.append(("fx[%d]" % (j * n + i), e))
+            else:
+                cfx[0][j * n + i] = float(e)
+    for j in range(m):
+        for i in range(n):
+            e = sp.sympify(dynamics.jacobian_action[i][j])
+            if e.free_symbols:
+                var.append(("fu[%d]" % (j * n + i), e))
+            else:
+                cfu[0][j * n + i] = float(e)
+    L.append("    static constexpr int JAC_NVAR = %d;   // state-dependent Jacobian entries (of %d)" % (len(var), n * n + n * m))
+    L.extend(_table("JAC_CONST_FX", cfx))
+    L.extend(_table("JAC_CONST_FU", cfu))
+    add("void", "dyn_jac_var_mem", sig_xu + ["double* fx", "double* fu"], dynamics, var)
+    # --- affine split of the dynamics
+    aff = [[0.0] * (n + m + 1) for _ in range(n)]
+    rem = []
+    zi = {s_: k for k, s_ in enumerate(z)}
+    for i, y in enumerate(dynamics.evaluate):
+        r = 0
+        for term in sp.Add.make_args(sp.expand(sp.sympify(y))):
+            if not term.free_symbols:
+                aff[i][n + m] += float(term)
+                continue
+            c, rest = term.as_coeff_Mul()
+            if rest in zi and c.is_number:
+                aff[i][zi[rest]] += float(c)
+            else:
+                r = r + term
+        rem.append(r)
+    L.extend(_table("DYN_AFF", aff))
+    L.append("    static constexpr bool DYN_HAS_REM = %s;" % ("true" if any(sp.sympify(r) != 0 for r in rem) else "false"))
+    L.append("#if defined(__HIPCC__)")
+    add("void", "dyn_rem_wave", ["const int lane"] + sig_xu + [_arr("r", n, False)], dynamics,
+        [("r[%d]" % i, e) for i, e in enumerate(rem)], coop=True)
+    L.append("#endif")
+
+
+
 def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None, con_term=None):
     """Return (struct_name, C++ source) of the device model struct.
 
@@ -425,6 +490,9 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         body = _emit_block(outs_, "t")
         un = _prune_unpack(unpack_xu(obj, with_u) + unp, body)
         L.extend(_fn("void", fname, sig, un + body))
+
+    if n > 4 or m > 4:
+        _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu)
 
     add_al("al_s", sig_xu + [_arr("ct", ncs), _arr("ir", ncs), _arr("gx", n, False), _arr("gu", m, False),
                              "double* gxx", "double* guu", "double* gux"], con_stage if ncs else dynamics, con_stage, ncs, True, True)

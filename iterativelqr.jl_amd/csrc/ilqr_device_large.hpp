@@ -2,15 +2,23 @@
 //
 // Differences from the LDS-resident small-model path of ilqr_device.hpp:
 //   * the per-instance workspace (2.4 MB for nx=32, nu=8, T=101) stays in HBM; the wave streams the
-//     per-timestep matrices through LDS staging buffers;
-//   * linearisation writes Jacobians straight to memory (M::dyn_jac_mem), accumulates only the
-//     structurally non-zero Hessian entries (M::cost_*_hess_acc) and uses the symbolically derived
-//     Gauss-Newton AL terms (M::al_s / M::al_t);
-//   * the Riccati step's contractions fx^T P' fx, fu^T P' fx, ... are real matrix products here and
-//     run as 16x16x4 fp64 MFMA tiles (v_mfma_f64_16x16x4_f64) out of LDS operands
+//     per-timestep matrices through LDS staging buffers, fetching the next step's operands into registers
+//     while the current step computes;
+//   * every phase is a real (noinline) function with its own register allocation, taking typed global
+//     pointers; inside the fused solve kernel the dense model code otherwise pushes the Riccati loop into
+//     hundreds of spills whose scratch reloads wait for the HBM prefetch;
+//   * linearisation: the Jacobian entries that are constants (generated tables M::JAC_CONST_*) are written by
+//     coalesced wave-wide stores, only the state-dependent ones are evaluated per timestep
+//     (M::dyn_jac_var_mem); Hessians accumulate only their structurally non-zero entries
+//     (M::cost_*_hess_acc); the Gauss-Newton AL terms are derived symbolically (M::al_s / M::al_t);
+//   * the Riccati step's contractions fx^T P' fx, fu^T P' fx, ... are real matrix products here and run as
+//     register-blocked 16x16x4 fp64 MFMA tiles (v_mfma_f64_16x16x4_f64) out of zero-padded LDS operands
 //     (A[i][k]: i = lane&15, k = lane>>4; B[k][j]: k = lane>>4, j = lane&15;
 //      C/D[i][j]: j = lane&15, i = (lane>>4) + 4*reg  — cdna_hip_programming.md §3);
-//   * Cholesky of Quu runs on wave-uniform registers, the triangular solves one column per lane.
+//   * Cholesky of Quu runs on wave-uniform registers (dpotf2 order), the triangular solves one column per lane
+//     with the inverted diagonal;
+//   * rollout: one state component per lane — row i of the affine part of the dynamics (generated table
+//     M::DYN_AFF) on lane i, the nonlinear remainder in wave-cooperative form (M::dyn_rem_wave).
 // Same reference semantics and citations as ilqr_device.hpp.
 #pragma once
 
@@ -32,19 +40,6 @@ struct LargeDims {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// One 16x16 output tile on v_mfma_f64_16x16x4_f64: acc += sum_{k<KD} A(I0+li, k) * B(k, J0+li), where
-// A(i,k) lives at A[AI*i + AK*k] and B(k,j) at B[BK*k + BJ*j] (any transposition is just a stride pattern).
-// Strides and KD are compile-time: every operand read is a ds_read_b64 with an immediate offset from one
-// per-lane base, the loop is fully unrolled, and the operands are zero-padded so there are no bounds checks.
-template <int KD, int AI, int AK, int BK, int BJ>
-__device__ __forceinline__ double4_t tile_mac(double4_t acc, const double* A, const double* B, int I0, int J0, int li,
-                                              int lk) {
-    const double* pa = A + AI * (I0 + li) + AK * lk;
-    const double* pb = B + BK * lk + BJ * (J0 + li);
-#pragma unroll
-    for (int s = 0; s < KD; s += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[AK * s], pb[BK * s], acc, 0, 0, 0);
-    return acc;
-}
 // D-layout of the tile: element r of lane (li, lk) is (row I0 + lk + 4r, column J0 + li)
 template <int LDD>
 __device__ __forceinline__ void tile_store(double* D, double4_t acc, int I0, int J0, int li, int lk) {
@@ -64,7 +59,9 @@ __device__ __forceinline__ double4_t tile_load_global(Ptr G, int I0, int J0, int
     return v;
 }
 
-// Register-blocked product of TR x TC tiles: all operand fragments are read from LDS FIRST (TR*KD/4 + TC*KD/4
+// Register-blocked product of TR x TC output tiles on v_mfma_f64_16x16x4_f64: acc(a,c) += sum_{k<KD} A_a(i,k) B(k,j)
+// with A(i,k) at A[AI*i + AK*k] and B(k,j) at B[BK*k + BJ*j] (any transposition is just a stride pattern; strides
+// and KD are compile-time, operands zero-padded: no bounds checks). All operand fragments are read from LDS FIRST (TR*KD/4 + TC*KD/4
 // doubles per lane), then the MFMAs issue back to back, k-step outermost so that consecutive instructions hit
 // different accumulators. Row tile a takes its A operand from Aop[a] (so two matrices can share one B pass).
 template <int TR, int TC, int KD, int AI, int AK, int BK, int BJ>
@@ -93,81 +90,6 @@ __device__ __forceinline__ void tiles_mac(double4_t (&acc)[TR * TC], const doubl
                 acc[a * TC + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][s], fb[c][s], acc[a * TC + c], 0, 0, 0);
 }
 
-// LDS matrix (R x Cc, ldd) += / = global matrix (packed column-major R x Cc)
-__device__ __forceinline__ void lds_add_global(double* D, int ldd, int R, int Cc, const double* G, int lane) {
-    for (int e = lane; e < R * Cc; e += 64) { const int i = e % R, j = e / R; D[j * ldd + i] += G[e]; }
-}
-__device__ __forceinline__ void lds_load_global(double* D, int ldd, int R, int Cc, const double* G, int lane) {
-    for (int e = lane; e < R * Cc; e += 64) { const int i = e % R, j = e / R; D[j * ldd + i] = G[e]; }
-}
-
-// ---------------------------------------------------------------- gradients! (one timestep per lane)
-template <class M>
-__device__ void gradients_large(Inst<M>& I, bool constrained) {
-    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
-    ILQR_PROF_BEGIN();
-    for (int t = I.lane; t < I.T; t += 64) {
-        double w[cdim<M::NW>::v];
-        load_w<M::NW>(I.w, t, w);
-        double xt[n];
-#pragma unroll
-        for (int i = 0; i < n; ++i) xt[i] = I.xb[t * n + i];
-        if (t < I.N) {
-            double ut[m];
-#pragma unroll
-            for (int i = 0; i < m; ++i) ut[i] = I.ub[t * m + i];
-            M::dyn_jac_mem(xt, ut, w, I.fx + (size_t)t * n * n, I.fu + (size_t)t * n * m);     // `.=`  (src/dynamics.jl:45-46)
-            double gx[n], gu[m];
-            M::cost_s_grad(xt, ut, w, gx, gu);                                                // `.=`  (src/costs.jl:61,65)
-            M::cost_s_hess_acc(xt, ut, w, I.gxx + (size_t)t * n * n, I.guu + (size_t)t * m * m,
-                               I.gux + (size_t)t * m * n);                                    // `.+=` (src/costs.jl:74-80)
-            if constexpr (ncs > 0) {
-                if (constrained) {                                                            // src/gradients.jl:54-80
-                    double ct[ncs], ir[ncs];
-                    const int off = t * ncs;
-#pragma unroll
-                    for (int i = 0; i < ncs; ++i) {
-                        ir[i] = I.rho[off + i] * I.act[off + i];
-                        ct[i] = I.lam[off + i] + ir[i] * I.c[off + i];
-                    }
-                    M::al_s(xt, ut, w, ct, ir, gx, gu, I.gxx + (size_t)t * n * n, I.guu + (size_t)t * m * m,
-                            I.gux + (size_t)t * m * n);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < n; ++i) I.gx[t * n + i] = gx[i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) I.gu[t * m + i] = gu[i];
-        } else {
-            double gx[n];
-            M::cost_t_grad(xt, w, gx);
-            M::cost_t_hess_acc(xt, w, I.gxx + (size_t)t * n * n);
-            if constexpr (nct > 0) {
-                if (constrained) {
-                    double ct[nct], ir[nct];
-                    const int off = I.N * ncs;
-#pragma unroll
-                    for (int i = 0; i < nct; ++i) {
-                        ir[i] = I.rho[off + i] * I.act[off + i];
-                        ct[i] = I.lam[off + i] + ir[i] * I.c[off + i];
-                    }
-                    M::al_t(xt, w, ct, ir, gx, I.gxx + (size_t)t * n * n);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < n; ++i) I.gx[t * n + i] = gx[i];
-        }
-    }
-    __syncthreads();
-    ILQR_PROF_END(I, PROF_GRAD);
-}
-
-// ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles)
-// One Riccati step (src/backward_pass.jl:42-90) for n = 32, m = 8 issues 132 tile MFMAs (64 cycles each on
-// gfx950: the matrix pipe is the floor, ~8.4 k cycles per step). Everything around them is arranged so that the
-// pipe does not wait: next step's fx, fu, gxx, guu, gux, gx, gu are fetched from HBM into registers a step
-// ahead (the cost Hessians directly in the D-layout of the tiles they are added to), Qxx never leaves the
-// accumulators, and the three products of the P update accumulate in one register tile.
 // The phase is a real (noinline) function: the fused solve kernel inlines every other phase (dense 32-state model
 // code included), and inside that one register allocation the Riccati loop ended up with hundreds of spills
 // whose scratch reloads wait on vmcnt(0), i.e. on the HBM prefetch. As a function it gets its own allocation.
@@ -180,6 +102,123 @@ __device__ __forceinline__ gdbl* uniform_ptr(gdbl* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (gdbl*)(((unsigned long long)hi << 32) | lo);
 }
+// what the other large-path phase functions need of one instance
+struct LargeArgs {
+    gdbl *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act, *w, *gxx, *guu, *gux;
+    int T, N;
+};
+template <class M>
+__device__ __forceinline__ LargeArgs large_args(Inst<M>& I) {
+    return LargeArgs{as_global(I.xb), as_global(I.ub), as_global(I.x), as_global(I.u), as_global(I.fx), as_global(I.fu),
+                     as_global(I.gx), as_global(I.gu), as_global(I.K), as_global(I.k), as_global(I.Lx), as_global(I.Lu),
+                     as_global(I.c), as_global(I.lam), as_global(I.rho), as_global(I.act), as_global(I.w),
+                     as_global(I.gxx), as_global(I.guu), as_global(I.gux), I.T, I.N};
+}
+__device__ __forceinline__ void uniform_args(LargeArgs& A) {
+    A.xb = uniform_ptr(A.xb); A.ub = uniform_ptr(A.ub); A.x = uniform_ptr(A.x); A.u = uniform_ptr(A.u);
+    A.fx = uniform_ptr(A.fx); A.fu = uniform_ptr(A.fu); A.gx = uniform_ptr(A.gx); A.gu = uniform_ptr(A.gu);
+    A.K = uniform_ptr(A.K); A.k = uniform_ptr(A.k); A.Lx = uniform_ptr(A.Lx); A.Lu = uniform_ptr(A.Lu);
+    A.c = uniform_ptr(A.c); A.lam = uniform_ptr(A.lam); A.rho = uniform_ptr(A.rho); A.act = uniform_ptr(A.act);
+    A.w = uniform_ptr(A.w); A.gxx = uniform_ptr(A.gxx); A.guu = uniform_ptr(A.guu); A.gux = uniform_ptr(A.gux);
+    A.T = __builtin_amdgcn_readfirstlane(A.T); A.N = __builtin_amdgcn_readfirstlane(A.N);
+}
+
+// ---------------------------------------------------------------- gradients! (one timestep per lane)
+// Jacobian entries that do not depend on (x, u, θ) — 1248 of 1280 for synth32 — come from the generated tables
+// M::JAC_CONST_* and are written by coalesced wave-wide stores; only the M::JAC_NVAR state-dependent entries
+// are evaluated per timestep (M::dyn_jac_var_mem). Same `.=` semantics as src/dynamics.jl:45-46 every call.
+template <class M>
+__attribute__((noinline)) __device__ void gradients_large_fn(LargeArgs A, int constrained) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    uniform_args(A);
+    const int lane = threadIdx.x, T = A.T, N = A.N;
+    constexpr bool split = M::JAC_NVAR < n * n + n * m;
+    if constexpr (split) {
+        constexpr int EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
+        double cfx[EFX], cfu[EFU];
+#pragma unroll
+        for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; cfx[q] = e < n * n ? M::JAC_CONST_FX[0][e] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; cfu[q] = e < n * m ? M::JAC_CONST_FU[0][e] : 0.0; }
+        for (int t = 0; t < N; ++t) {
+#pragma unroll
+            for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) A.fx[(size_t)t * n * n + e] = cfx[q]; }
+#pragma unroll
+            for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) A.fu[(size_t)t * n * m + e] = cfu[q]; }
+        }
+        __threadfence_block();       // the state-dependent entries below overwrite some of these addresses
+    }
+    for (int t = lane; t < T; t += 64) {
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>((const double*)A.w, t, w);
+        double xt[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) xt[i] = A.xb[t * n + i];
+        double* gxx = (double*)(A.gxx + (size_t)t * n * n);
+        if (t < N) {
+            double ut[m];
+#pragma unroll
+            for (int i = 0; i < m; ++i) ut[i] = A.ub[t * m + i];
+            double* fx = (double*)(A.fx + (size_t)t * n * n);
+            double* fu = (double*)(A.fu + (size_t)t * n * m);
+            double* guu = (double*)(A.guu + (size_t)t * m * m);
+            double* gux = (double*)(A.gux + (size_t)t * m * n);
+            if constexpr (split) M::dyn_jac_var_mem(xt, ut, w, fx, fu);                       // `.=`  (src/dynamics.jl:45-46)
+            else M::dyn_jac_mem(xt, ut, w, fx, fu);
+            double gx[n], gu[m];
+            M::cost_s_grad(xt, ut, w, gx, gu);                                                // `.=`  (src/costs.jl:61,65)
+            M::cost_s_hess_acc(xt, ut, w, gxx, guu, gux);                                     // `.+=` (src/costs.jl:74-80)
+            if constexpr (ncs > 0) {
+                if (constrained) {                                                            // src/gradients.jl:54-80
+                    double ct[ncs], ir[ncs];
+                    const int off = t * ncs;
+#pragma unroll
+                    for (int i = 0; i < ncs; ++i) {
+                        ir[i] = A.rho[off + i] * A.act[off + i];
+                        ct[i] = A.lam[off + i] + ir[i] * A.c[off + i];
+                    }
+                    M::al_s(xt, ut, w, ct, ir, gx, gu, gxx, guu, gux);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < n; ++i) A.gx[t * n + i] = gx[i];
+#pragma unroll
+            for (int i = 0; i < m; ++i) A.gu[t * m + i] = gu[i];
+        } else {
+            double gx[n];
+            M::cost_t_grad(xt, w, gx);
+            M::cost_t_hess_acc(xt, w, gxx);
+            if constexpr (nct > 0) {
+                if (constrained) {
+                    double ct[nct], ir[nct];
+                    const int off = N * ncs;
+#pragma unroll
+                    for (int i = 0; i < nct; ++i) {
+                        ir[i] = A.rho[off + i] * A.act[off + i];
+                        ct[i] = A.lam[off + i] + ir[i] * A.c[off + i];
+                    }
+                    M::al_t(xt, w, ct, ir, gx, gxx);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < n; ++i) A.gx[t * n + i] = gx[i];
+        }
+    }
+    __syncthreads();
+}
+template <class M>
+__device__ __forceinline__ void gradients_large(Inst<M>& I, bool constrained) {
+    ILQR_PROF_BEGIN();
+    gradients_large_fn<M>(large_args(I), constrained ? 1 : 0);
+    ILQR_PROF_END(I, PROF_GRAD);
+}
+
+// ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles)
+// One Riccati step (src/backward_pass.jl:42-90) for n = 32, m = 8 issues 132 tile MFMAs (64 cycles each on
+// gfx950: the matrix pipe is the floor, ~8.4 k cycles per step). Everything around them is arranged so that the
+// pipe does not wait: next step's fx, fu, gxx, guu, gux, gx, gu are fetched from HBM into registers a step
+// ahead (the cost Hessians directly in the D-layout of the tiles they are added to), Qxx never leaves the
+// accumulators, and the three products of the P update accumulate in one register tile.
 struct RiccatiArgs { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int N; };
 struct RiccatiOut { double gradient_norm; int potrf_info; double prof[6]; };
 
@@ -465,85 +504,155 @@ __device__ __forceinline__ void backward_pass_large(Inst<M>& I) {
 #endif
 }
 
-// ---------------------------------------------------------------- rollout! (wave-uniform state, lane-parallel policy)
+// ---------------------------------------------------------------- rollout! (one state component per lane)
+// u = αk + ū + Kx − Kx̄ (src/rollout.jl:24-28): K x on lanes 0..m-1 and K x̄ on lanes 32..32+m-1 at the same time
+// (K_t staged in LDS, fetched from HBM a step ahead). Dynamics: lane i evaluates row i of the affine part
+// y = DYN_AFF [x; u; 1] with its coefficient row held in registers for the whole rollout, plus the generated
+// remainder (wave-cooperative trig). x and u travel between lanes through LDS.
 template <class M>
-__device__ void rollout_large(Inst<M>& I, double alpha) {
-    constexpr int n = M::NX, m = M::NU;
-    ILQR_PROF_BEGIN();
-    double xt[n];
+__attribute__((noinline)) __device__ void rollout_large_fn(LargeArgs A, double alpha) {
+    typedef LargeDims<M> LD;
+    constexpr int n = M::NX, m = M::NU, EK = (m * n + 63) / 64;
+    static_assert(n <= 32 && m <= 16, "large path: nx <= 32, nu <= 16");
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    uniform_args(A);
+    const int lane = threadIdx.x, N = A.N;
+    double* sK = lds_dyn + LD::oK;                     // packed m x n
+    double* sx = lds_dyn + LD::oVec;                   // x (n), then x̄ (n), then u (m)
+    double* sxb = sx + LD::NP;
+    double* su = sxb + LD::NP;
+    const int row = lane < n ? lane : n - 1;
+    double aff[n + m + 1];
 #pragma unroll
-    for (int i = 0; i < n; ++i) xt[i] = I.xb[i];                          // (:19)
-    if (I.lane == 0) {
+    for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
+    double xl = lane < n ? A.xb[lane] : 0.0;                              // x[1] = x̄[1]  (:19)
+    if (lane < n) A.x[lane] = xl;
+    double rK[EK];
+    auto fetchK = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < n; ++i) I.x[i] = xt[i];
-    }
-    const int li = I.lane < m ? I.lane : m - 1;                           // lane i evaluates control component i
-    for (int t = 0; t < I.N; ++t) {
-        double v = I.k[t * m + li] * alpha;                               // (:24-25)
-        v += I.ub[t * m + li];                                            // (:26)
-        double a1 = 0.0, a2 = 0.0;
+        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; rK[q] = ((m * n) % 64 == 0 || e < m * n) ? A.K[(size_t)t * m * n + e] : 0.0; }
+    };
+    if (N > 0) fetchK(0);
+    double xbl = lane < n ? A.xb[lane] : 0.0;                             // x̄_t component of this lane
+    const bool hi = lane >= 32;                                           // lanes 32.. work on K x̄
+    const int ui = (lane & 31) < m ? (lane & 31) : m - 1;
+    for (int t = 0; t < N; ++t) {
 #pragma unroll
-        for (int j = 0; j < n; ++j) {
-            const double Kij = I.K[(size_t)t * m * n + j * m + li];
-            a1 += Kij * xt[j];
-            a2 += Kij * I.xb[t * n + j];
-        }
-        v += a1;                                                          // (:27)
+        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; if ((m * n) % 64 == 0 || e < m * n) sK[e] = rK[q]; }
+        if (lane < n) { sx[lane] = xl; sxb[lane] = xbl; }
+        __syncthreads();
+        if (t + 1 < N) fetchK(t + 1);
+        const double xb_next = lane < n ? A.xb[(t + 1) * n + lane] : 0.0;
+        const double kv = A.k[t * m + ui], ubv = A.ub[t * m + ui];
+        double xa[n];
+#pragma unroll
+        for (int j = 0; j < n; ++j) xa[j] = sx[j];
+        const double* src = hi ? sxb : sx;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; ++j) acc += sK[j * m + ui] * src[j];       // K x (lanes < 32) | K x̄ (lanes >= 32)
+        const double a2 = __shfl(acc, lane + 32);
+        double v = kv * alpha;                                            // (:24-25)
+        v += ubv;                                                         // (:26)
+        v += acc;                                                         // (:27)
         v += -1.0 * a2;                                                   // (:28)
-        double ut[m];
-        bcast_array<m>(v, ut);
-        double w[cdim<M::NW>::v], y[n];
-        load_w<M::NW>(I.w, t, w);
-        M::dyn_wave(I.lane, xt, ut, w, y);                                // (:29)
-        if (I.lane == 0) {
+        if (lane < m) { su[lane] = v; A.u[t * m + lane] = v; }
+        __syncthreads();
+        double ua[m];
 #pragma unroll
-            for (int i = 0; i < m; ++i) I.u[t * m + i] = ut[i];
+        for (int j = 0; j < m; ++j) ua[j] = su[j];
+        double y = aff[n + m];                                            // (:29) row `lane` of the dynamics
 #pragma unroll
-            for (int i = 0; i < n; ++i) I.x[(t + 1) * n + i] = y[i];
+        for (int j = 0; j < n; ++j) y += aff[j] * xa[j];
+#pragma unroll
+        for (int j = 0; j < m; ++j) y += aff[n + j] * ua[j];
+        if constexpr (M::DYN_HAS_REM) {
+            double w[cdim<M::NW>::v], r[n];
+            load_w<M::NW>((const double*)A.w, t, w);
+            M::dyn_rem_wave(lane, xa, ua, w, r);
+            double rl = r[0];
+#pragma unroll
+            for (int i = 1; i < n; ++i) rl = (lane == i) ? r[i] : rl;
+            y += rl;
         }
-#pragma unroll
-        for (int i = 0; i < n; ++i) xt[i] = y[i];
+        xl = y;
+        xbl = xb_next;
+        if (lane < n) A.x[(t + 1) * n + lane] = y;
+        __syncthreads();
     }
+    __syncthreads();
+}
+template <class M>
+__device__ __forceinline__ void rollout_large(Inst<M>& I, double alpha) {
+    ILQR_PROF_BEGIN();
+    rollout_large_fn<M>(large_args(I), alpha);
     I.rollouts += 1;
     I.states_eq_nominal = 0;
-    __syncthreads();
     ILQR_PROF_END(I, PROF_ROLLOUT);
 }
 
 // ---------------------------------------------------------------- trajectory_sensitivities + gradient^T dz
+// src/data/methods.jl:42-54 and the dot product of src/forward_pass.jl:20. K_t, fx_t, fu_t are staged in LDS
+// (HBM fetch a step ahead); Δu on lanes 0..m-1, Δx⁺ one row per lane.
 template <class M>
-__device__ double delta_large(Inst<M>& I) {
+__attribute__((noinline)) __device__ double delta_large_fn(LargeArgs A) {
     typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU;
-    ILQR_PROF_BEGIN();
-    double* zx = I.lds + LD::oVec;          // n
-    double* zu = zx + n;                    // m
-    const int lane = I.lane;
-    for (int i = lane; i < n; i += 64) zx[i] = 0.0;
-    __syncthreads();
+    constexpr int n = M::NX, m = M::NU, ld = LD::ld;
+    constexpr int EK = (m * n + 63) / 64, EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    uniform_args(A);
+    const int lane = threadIdx.x, N = A.N;
+    double *sK = lds_dyn + LD::oK, *sFx = lds_dyn + LD::oFx, *sFu = lds_dyn + LD::oFu;
+    double* zx = lds_dyn + LD::oVec;        // n
+    double* zu = zx + LD::NP;               // m
+    double rK[EK], rfx[EFX], rfu[EFU];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; rK[q] = ((m * n) % 64 == 0 || e < m * n) ? A.K[(size_t)t * m * n + e] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; rfx[q] = ((n * n) % 64 == 0 || e < n * n) ? A.fx[(size_t)t * n * n + e] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; rfu[q] = ((n * m) % 64 == 0 || e < n * m) ? A.fu[(size_t)t * n * m + e] : 0.0; }
+    };
+    if (N > 0) fetch(0);
+    if (lane < n) zx[lane] = 0.0;
     double dpart = 0.0;
-    for (int t = 0; t < I.N; ++t) {
-        for (int i = lane; i < m; i += 64) {                              // Δu = k + K Δx
-            double acc = 0.0;
-            for (int j = 0; j < n; ++j) acc += I.K[(size_t)t * m * n + j * m + i] * zx[j];
-            const double v = I.k[t * m + i] + acc;
-            zu[i] = v;
-            dpart += I.Lu[t * m + i] * v;
-        }
-        for (int i = lane; i < n; i += 64) dpart += I.Lx[t * n + i] * zx[i];
+    const int ui = lane < m ? lane : m - 1, xi = lane < n ? lane : n - 1;
+    for (int t = 0; t < N; ++t) {
+#pragma unroll
+        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; if ((m * n) % 64 == 0 || e < m * n) sK[e] = rK[q]; }
+#pragma unroll
+        for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) sFx[(e / n) * ld + e % n] = rfx[q]; }
+#pragma unroll
+        for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) sFu[(e / n) * ld + e % n] = rfu[q]; }
         __syncthreads();
-        double zy = 0.0;
-        if (lane < n) {                                                   // Δx⁺ = fu Δu + fx Δx
-            double a1 = 0.0, a2 = 0.0;
-            for (int j = 0; j < m; ++j) a1 += I.fu[(size_t)t * n * m + j * n + lane] * zu[j];
-            for (int j = 0; j < n; ++j) a2 += I.fx[(size_t)t * n * n + j * n + lane] * zx[j];
-            zy = a1 + a2;
-        }
+        if (t + 1 < N) fetch(t + 1);
+        const double kv = A.k[t * m + ui], Luv = A.Lu[t * m + ui], Lxv = A.Lx[t * n + xi];
+        double za[n];
+#pragma unroll
+        for (int j = 0; j < n; ++j) za[j] = zx[j];
+        double acc = 0.0;                                                 // Δu = k + K Δx
+#pragma unroll
+        for (int j = 0; j < n; ++j) acc += sK[j * m + ui] * za[j];
+        const double du = kv + acc;
+        if (lane < m) { zu[lane] = du; dpart += Luv * du; }
+        if (lane < n) dpart += Lxv * zx[xi];
         __syncthreads();
-        if (lane < n) zx[lane] = zy;
+        double a1 = 0.0, a2 = 0.0;                                        // Δx⁺ = fu Δu + fx Δx
+#pragma unroll
+        for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * zu[j];
+#pragma unroll
+        for (int j = 0; j < n; ++j) a2 += sFx[j * ld + xi] * za[j];
+        __syncthreads();
+        if (lane < n) zx[lane] = a1 + a2;
         __syncthreads();
     }
-    const double d = wave_sum(dpart);
+    return wave_sum(dpart);
+}
+template <class M>
+__device__ __forceinline__ double delta_large(Inst<M>& I) {
+    ILQR_PROF_BEGIN();
+    const double d = delta_large_fn<M>(large_args(I));
     ILQR_PROF_END(I, PROF_DELTA);
     return d;
 }
