@@ -399,29 +399,27 @@ __device__ void gradients_small(Inst<M>& I, bool constrained) {
 // failed factorisation (info > 0, ignored by the reference) R holds the reciprocals of whatever is on the diagonal.
 template <int m>
 __device__ __forceinline__ int potrf_U(double (&A)[m * m], double (&R)[m]) {
+    // branch-free (selects only), so that the scheduler can interleave it with independent MFMA work
     int info = 0;
 #pragma unroll
     for (int j = 0; j < m; ++j) {
-        if (info == 0) {
-            double ajj = A[j * m + j];
+        double ajj = A[j * m + j];
 #pragma unroll
-            for (int l = 0; l < j; ++l) ajj -= A[j * m + l] * A[j * m + l];
-            if (!(ajj > 0.0)) { A[j * m + j] = ajj; info = j + 1; }
-            else {
-                ajj = sqrt(ajj);
-                A[j * m + j] = ajj;
-                const double r = 1.0 / ajj;
-                R[j] = r;
+        for (int l = 0; l < j; ++l) ajj -= A[j * m + l] * A[j * m + l];
+        const bool ok = (info == 0) && (ajj > 0.0);
+        const bool fail_now = (info == 0) && !(ajj > 0.0);
+        info = fail_now ? j + 1 : info;
+        const double d = ok ? sqrt(ajj) : (fail_now ? ajj : A[j * m + j]);
+        A[j * m + j] = d;
+        const double r = 1.0 / d;
+        R[j] = r;
 #pragma unroll
-                for (int c = j + 1; c < m; ++c) {
-                    double v = A[c * m + j];
+        for (int c = j + 1; c < m; ++c) {
+            double v = A[c * m + j];
 #pragma unroll
-                    for (int l = 0; l < j; ++l) v -= A[j * m + l] * A[c * m + l];
-                    A[c * m + j] = v * r;
-                }
-            }
+            for (int l = 0; l < j; ++l) v -= A[j * m + l] * A[c * m + l];
+            A[c * m + j] = ok ? v * r : A[c * m + j];
         }
-        if (info != 0) R[j] = 1.0 / A[j * m + j];
     }
     return info;
 }
@@ -600,14 +598,13 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         for (int j = 0; j < m; ++j)
 #pragma unroll
             for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
+        // potrs('U') for K (block 0: m x n) and k (block 1, column 0) at once   (:70-75)
+        const double Qu_b1 = row_from_prev_quad(Qu);                    // block 0 -> block 1
+        double Y = (blk == 1) ? Qu_b1 : Qux;
         int info = 0;
         double Ur[m];                                                   // inverted diagonal of the factor
         if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
         else info = potrf_U<m>(Uc, Ur);
-        if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
-        // potrs('U') for K (block 0: m x n) and k (block 1, column 0) at once   (:70-75)
-        const double Qu_b1 = row_from_prev_quad(Qu);                    // block 0 -> block 1
-        double Y = (blk == 1) ? Qu_b1 : Qux;
         if (m == 1 && info == 0) {
             // 1x1: (b / sqrt(q)) / sqrt(q) == b / q up to one rounding; saves a sqrt and a division
             // (~220 clk) on the serial chain. The literal path below still runs when potrf fails.
@@ -637,6 +634,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
                 Y = (r == i) ? q : Y;
             }
         }
+        if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
         Y *= -1.0;                                                      // K .*= -1, k .*= -1
         const double K = Y;                                             // valid in block 0
         const double k = row_from_next_quad(Y);                         // block 1 -> block 0, column 0

@@ -54,7 +54,11 @@ __device__ __forceinline__ double4_t tile_load_global(Ptr G, int I0, int J0, int
     for (int r = 0; r < 4; ++r) {
         const int row = I0 + lk + 4 * r, col = J0 + li;
         if constexpr (R % 16 == 0 && Cc % 16 == 0) v[r] = G[col * R + row];
-        else v[r] = (row < R && col < Cc) ? G[col * R + row] : 0.0;
+        else {                                      // clamped address + select: no exec-mask branch
+            const bool in = row < R && col < Cc;
+            const double x = G[in ? col * R + row : 0];
+            v[r] = in ? x : 0.0;
+        }
     }
     return v;
 }
@@ -303,7 +307,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
         }
         const double gv = rgv;
         __syncthreads();
-        if (t > 0) fetch_early(t - 1);
+        fetch_early(t > 0 ? t - 1 : 0);
         // Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49): one output per lane
         if (lane < n + m) {
             const double* colp = lane < n ? sFx + lane * ld : sFu + (lane - n) * ld;
@@ -334,73 +338,64 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
         }
         __syncthreads();
         ILQR_SUB_MARK(I, 1);
-        // [Qxx; Qux] = [T; ux_hat] fx + [gxx; gux] (:53-54, :63-64): Qxx stays in the accumulators
-        double4_t qxx[TN * TN];
+        // Qux = ux_hat fx + gux (:63-64), Quu = ux_hat fu + guu (:58-59): one pass over the ux_hat fragments
         {
-            constexpr int TR = TN + TM;
-            double4_t acc[TR * TN];
+            constexpr int KS = n4 / 4, TC = TN + TM;
+            double4_t acc[TM * TC];
 #pragma unroll
-            for (int q = 0; q < TR * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
-            const double* Aop[TR]; int Arow[TR];
+            for (int q = 0; q < TM * TC; ++q) acc[q] = double4_t{0, 0, 0, 0};
+            double fa[TM][KS], fb[TC][KS];
 #pragma unroll
-            for (int a = 0; a < TR; ++a) { Aop[a] = a < TN ? sT : sUh; Arow[a] = a < TN ? 16 * a : 16 * (a - TN); }
-            // A(i,k) = T(i,k) at sT[k*ld + i] resp. ux_hat(i,k) at sUh[k*ldm + i]: different leading dimensions
-            {
-                constexpr int KS = n4 / 4;
-                double fa[TR][KS], fb[TN][KS];
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int a = 0; a < TR; ++a)
+                for (int sx = 0; sx < KS; ++sx) fa[a][sx] = sUh[(4 * sx + lk) * ldm + 16 * a + li];
 #pragma unroll
-                    for (int sx = 0; sx < KS; ++sx)
-                        fa[a][sx] = a < TN ? sT[(4 * sx + lk) * ld + 16 * a + li] : sUh[(4 * sx + lk) * ldm + 16 * (a - TN) + li];
-#pragma unroll
-                for (int c = 0; c < TN; ++c)
-#pragma unroll
-                    for (int sx = 0; sx < KS; ++sx) fb[c][sx] = sFx[(16 * c + li) * ld + 4 * sx + lk];
+            for (int c = 0; c < TC; ++c)
 #pragma unroll
                 for (int sx = 0; sx < KS; ++sx)
+                    fb[c][sx] = c < TN ? sFx[(16 * c + li) * ld + 4 * sx + lk] : sFu[(16 * (c - TN) + li) * ld + 4 * sx + lk];
 #pragma unroll
-                    for (int a = 0; a < TR; ++a)
+            for (int sx = 0; sx < KS; ++sx)
 #pragma unroll
-                        for (int c = 0; c < TN; ++c)
-                            acc[a * TN + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][sx], fb[c][sx], acc[a * TN + c], 0, 0, 0);
-            }
+                for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int c = 0; c < TN; ++c) qxx[a * TN + c] = acc[a * TN + c] + rgxx[a * TN + c];
+                    for (int c = 0; c < TC; ++c)
+                        acc[a * TC + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][sx], fb[c][sx], acc[a * TC + c], 0, 0, 0);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int c = 0; c < TN; ++c)
-                    tile_store<ldm>(sQux, acc[(TN + a) * TN + c] + rgux[a * TN + c], 16 * a, 16 * c, li, lk);
-        }
-        // Quu = ux_hat fu + guu (:58-59)
-        {
-            double4_t acc[TM * TM];
-#pragma unroll
-            for (int q = 0; q < TM * TM; ++q) acc[q] = double4_t{0, 0, 0, 0};
-            const double* Aop[TM]; int Arow[TM];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) { Aop[a] = sUh; Arow[a] = 16 * a; }
-            tiles_mac<TM, TM, n4, 1, ldm, 1, ld>(acc, Aop, Arow, sFu, li, lk);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int c = 0; c < TM; ++c) tile_store<ldm>(sQuu, acc[a * TM + c] + rguu[a * TM + c], 16 * a, 16 * c, li, lk);
+                for (int c = 0; c < TC; ++c) {
+                    if (c < TN) tile_store<ldm>(sQux, acc[a * TC + c] + rgux[a * TN + c], 16 * a, 16 * c, li, lk);
+                    else tile_store<ldm>(sQuu, acc[a * TC + c] + rguu[a * TM + (c - TN)], 16 * a, 16 * (c - TN), li, lk);
+                }
         }
         __syncthreads();
         ILQR_SUB_MARK(I, 2);
-        if (t > 0) fetch_late(t - 1);
-        // potrf('U') on wave-uniform registers (info ignored, :68-69)
-        double Uc[m * m];
+        // Qxx = T fx + gxx (:53-54) stays in the accumulators. Its 32 MFMAs are independent of the Cholesky below
+        // (VALU only, branch-free) and share its basic block. (Measured: the scheduler still issues them in clumps,
+        // so the two pipes overlap little; sched_group_barrier patterns did not change that.)
+        double4_t qxx[TN * TN];
+        double Uc[m * m], Ur[m];
+        int info;
+        {
+            double4_t acc[TN * TN];
 #pragma unroll
-        for (int j = 0; j < m; ++j)
+            for (int q = 0; q < TN * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
+            const double* Aop[TN]; int Arow[TN];
 #pragma unroll
-            for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? sQuu[j * ldm + i] : 0.0;
-        double Ur[m];
-        const int info = potrf_U<m>(Uc, Ur);
+            for (int a = 0; a < TN; ++a) { Aop[a] = sT; Arow[a] = 16 * a; }
+            // potrf('U') operands on wave-uniform registers (info ignored, :68-69)
+#pragma unroll
+            for (int j = 0; j < m; ++j)
+#pragma unroll
+                for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? sQuu[j * ldm + i] : 0.0;
+            tiles_mac<TN, TN, n4, 1, ld, 1, ld>(acc, Aop, Arow, sFx, li, lk);
+            info = potrf_U<m>(Uc, Ur);
+#pragma unroll
+            for (int q = 0; q < TN * TN; ++q) qxx[q] = acc[q] + rgxx[q];
+        }
         if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
+        fetch_late(t > 0 ? t - 1 : 0);                 // (t = 0: a harmless re-read instead of a branch)
         ILQR_SUB_MARK(I, 3);
         // potrs('U'): column j of Qux per lane, Qu on lane n   (:70-75)
         for (int j = lane; j <= n; j += 64) {
