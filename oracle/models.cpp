@@ -194,6 +194,32 @@ struct Synth32F {
     }
 };
 
+// ----------------------------------------------------------------- synth12
+// A second large-path model with dimensions that are NOT multiples of the MFMA tile (nx = 12, nu = 5), a bilinear
+// term (state-dependent fu entries) and a terminal equality: x⁺ = x + h(Ax + Bu + 0.1 sin x + 0.02 x∘u_{i mod 5}),
+// h = 0.05, A_ij = −δ_ij + 0.3 cos(i + 2j)/12, B_ij = sin(3i + j)/√12 (1-based).
+struct Synth12F {
+    template <class S> void operator()(const S* x, const S* u, S* y) const {
+        const double h = 0.05;
+        for (int i = 0; i < 12; ++i) {
+            S acc = S(0.0);
+            for (int j = 0; j < 12; ++j)
+                acc = acc + ((i == j ? -1.0 : 0.0) + 0.3 * std::cos((double)((i + 1) + 2 * (j + 1))) / 12.0) * x[j];
+            for (int j = 0; j < 5; ++j) acc = acc + (std::sin((double)(3 * (i + 1) + (j + 1))) / std::sqrt(12.0)) * u[j];
+            acc = acc + 0.1 * sin(x[i]);
+            acc = acc + 0.02 * (x[i] * u[i % 5]);
+            y[i] = x[i] + h * acc;
+        }
+    }
+};
+// terminal equality on the first three states: c = x[1:3] − 0.1
+void synth12_term_eval(double* out, const double* x, const double*, const double*, const void*) {
+    for (int i = 0; i < 3; ++i) out[i] = x[i] - 0.1;
+}
+void synth12_term_jx(double* out, const double*, const double*, const double*, const void*) {
+    for (int i = 0; i < 3; ++i) out[i * 3 + i] = 1.0;
+}
+
 // generic wrappers: orc_fn adaptors for a dynamics functor
 template <int NX, int NU, class F> void dyn_eval(double* out, const double* x, const double* u, const double*, const void*) {
     F f; f(x, u, out);
@@ -453,6 +479,17 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
         z->ks.evaluate = ubox_eval; z->ks.jacobian_state = con_nothing; z->ks.jacobian_action = ubox_ju;
         z->ks.num_constraint = 16; z->ks.num_state = 32; z->ks.num_action = 8; z->ks.ctx = &z->box;
         z->ks.num_inequality = 16; for (int i = 0; i < 16; ++i) z->ks.indices_inequality[i] = i;
+    } else if (!std::strcmp(name, "synth12")) {
+        z->dyn = make_dynamics<12, 5, Synth12F>();
+        quad_init(&z->qs, 12, 5); quad_init(&z->qt, 12, 0);
+        for (int i = 0; i < 12; ++i) { z->qs.q[i] = 0.1; z->qt.q[i] = 10.0; z->qs.xg[i] = 0.5; z->qt.xg[i] = 0.5; }
+        for (int j = 0; j < 5; ++j) z->qs.r[j] = 0.01;
+        z->box.n = 5;
+        z->ks.evaluate = ubox_eval; z->ks.jacobian_state = con_nothing; z->ks.jacobian_action = ubox_ju;
+        z->ks.num_constraint = 10; z->ks.num_state = 12; z->ks.num_action = 5; z->ks.ctx = &z->box;
+        z->ks.num_inequality = 10; for (int i = 0; i < 10; ++i) z->ks.indices_inequality[i] = i;
+        z->kt.evaluate = synth12_term_eval; z->kt.jacobian_state = synth12_term_jx;
+        z->kt.num_constraint = 3; z->kt.num_state = 12;
     } else if (!std::strcmp(name, "kat_objective")) {
         // test/objective.jl:6-10 (dynamics are a placeholder: particle)
         z->dyn = make_dynamics<2, 1, ParticleF>();

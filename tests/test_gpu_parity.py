@@ -576,3 +576,42 @@ def test_time_varying_stage_objects(pkg, oracle):
         off = [i for i in range(6) if i not in sol.constraint_rows[t]]
         assert (c[:, t, off] == 0).all() and (lam[:, t, off] == 0).all()
     sol.close()
+
+
+def test_large_path_odd_dimensions_and_terminal_constraint(pkg, oracle):
+    """synth12: nx = 12, nu = 5 (not multiples of the 16x16 MFMA tile or of the k-step: the zero-padded
+    tile paths), state-dependent fu entries (bilinear term), a terminal equality (al_t on the large path) and
+    a binding action box. User-defined model through the plugin path; oracle twin in oracle/models.cpp."""
+    T, B = 41, 64
+    mdl = pkg.models.synth12()
+    rng = np.random.default_rng(12)
+    x1 = 0.5 * rng.standard_normal((B, 12)); ub = 0.1 * rng.standard_normal((B, T - 1, 5))
+    kw = dict(max_iterations=15, max_dual_updates=3)      # the problem is hard for the reference's AL loop; parity, not convergence
+    sol = pkg.Solver([mdl["dynamics"]] * (T - 1), [mdl["cost_stage"]] * (T - 1) + [mdl["cost_term"]],
+                     [mdl["con_stage"]] * (T - 1) + [mdl["con_term"]], batch=B, options=pkg.Options(verbose=0, **kw),
+                     name="synth12")
+    assert (sol.nx, sol.nu, sol.nc_stage, sol.nc_term) == (12, 5, 10, 3)
+    sol.initialize_rollout_(x1, ub)
+    xb0 = np.stack([oracle.Problem("synth12", T).rollout(x1[b], ub[b]) for b in range(4)])
+    assert np.abs(sol.buffer("nominal_states").reshape(B, T, 12)[:4] - xb0).max() < 1e-12
+    # one linearisation + Riccati pass from identical inputs, stage level
+    refs = []
+    for b in range(4):
+        pr, s, _ = _oracle_solver(oracle, "synth12", T, x1[b], ub[b])
+        s.call("cost_bang", 0); s.call("gradients"); s.call("backward_pass")
+        refs.append((pr, s))
+    sol.run_stage_("cost_nominal"); sol.run_stage_("gradients"); sol.run_stage_("backward_pass")
+    for name in ("jacobian_state", "jacobian_action", "hessian_state_state", "hessian_action_action", "K", "k", "P", "p"):
+        got = sol.buffer(name)[:4]
+        want = np.stack([r[1].buffer(name) for r in refs])
+        assert _rel(got, want) < 1e-9, name
+    # whole solve
+    sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    ref = oracle.solve_batch("synth12", T, x1, ub, options=oracle.default_options(**kw), nthreads=4)
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.9, same.mean()
+    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    assert np.abs(K - ref["K"])[same].max() <= 1e-5 * np.abs(ref["K"]).max()
+    assert np.allclose(st["max_violation"][same], ref["stats"]["max_violation"][same], atol=1e-7)
+    sol.close()
