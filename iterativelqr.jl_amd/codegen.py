@@ -325,7 +325,7 @@ def _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu):
     L.append("    static constexpr int JAC_NVAR = %d;   // state-dependent Jacobian entries (of %d)" % (len(var), n * n + n * m))
     L.extend(_table("JAC_CONST_FX", cfx))
     L.extend(_table("JAC_CONST_FU", cfu))
-    add("void", "dyn_jac_var_mem", sig_xu + ["double* fx", "double* fu"], dynamics, var)
+    add("void", "dyn_jac_var_mem", sig_xu + ["double* __restrict__ fx", "double* __restrict__ fu"], dynamics, var)
     # --- affine split of the dynamics
     aff = [[0.0] * (n + m + 1) for _ in range(n)]
     rem = []
@@ -452,13 +452,13 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
 
     outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
     outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
-    add("void", "dyn_jac_mem", sig_xu + ["double* fx", "double* fu"], dynamics, outs)
+    add("void", "dyn_jac_mem", sig_xu + ["double* __restrict__ fx", "double* __restrict__ fu"], dynamics, outs)
     outs = nz([("gxx[%d]" % (j * n + i), cost_stage.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
     outs += nz([("guu[%d]" % (j * m + i), cost_stage.hessian_action_action[i][j]) for j in range(m) for i in range(m)])
     outs += nz([("gux[%d]" % (j * m + i), cost_stage.hessian_action_state[i][j]) for j in range(n) for i in range(m)])
-    add("void", "cost_s_hess_acc", sig_xu + ["double* gxx", "double* guu", "double* gux"], cost_stage, outs)
+    add("void", "cost_s_hess_acc", sig_xu + ["double* __restrict__ gxx", "double* __restrict__ guu", "double* __restrict__ gux"], cost_stage, outs)
     outs = nz([("gxx[%d]" % (j * n + i), cost_term.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
-    add("void", "cost_t_hess_acc", sig_x + ["double* gxx"], cost_term, outs, with_u=False)
+    add("void", "cost_t_hess_acc", sig_x + ["double* __restrict__ gxx"], cost_term, outs, with_u=False)
 
     def al_terms(con, nc, stage):
         ct = [sp.Symbol("ct%d" % i, real=True) for i in range(nc)]     # λ + Iρ c
@@ -495,8 +495,8 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu)
 
     add_al("al_s", sig_xu + [_arr("ct", ncs), _arr("ir", ncs), _arr("gx", n, False), _arr("gu", m, False),
-                             "double* gxx", "double* guu", "double* gux"], con_stage if ncs else dynamics, con_stage, ncs, True, True)
-    add_al("al_t", sig_x + [_arr("ct", nct), _arr("ir", nct), _arr("gx", n, False), "double* gxx"],
+                             "double* __restrict__ gxx", "double* __restrict__ guu", "double* __restrict__ gux"], con_stage if ncs else dynamics, con_stage, ncs, True, True)
+    add_al("al_t", sig_x + [_arr("ct", nct), _arr("ir", nct), _arr("gx", n, False), "double* __restrict__ gxx"],
            con_term if nct else dynamics, con_term, nct, False, False)
     L.append("};")
     src = "\n".join(L) + "\n"

@@ -398,6 +398,10 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
     if (!h || !name || !in) return fail(ILQR_ERR_INVALID, "null argument");
     const BufferDesc* bd = find_buffer(h, name);
     if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
+    if (!std::strncmp(name, "jacobian_", 9)) {     // host-written Jacobians: their constant entries are no longer known to be in place
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemset2DAsync(h->ws + h->L.scal + ilqr::S_JAC_CONST, (size_t)h->L.stride * 8, 0, 8, (size_t)h->B, h->stream));
+    }
     return copy_in(h, bd, in);
 }
 

@@ -874,10 +874,16 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
 
 // reset!(problem.model); reset!(problem.objective) — src/solve.jl:9-10
 template <class M>
-__device__ void reset_model_objective(Inst<M>& I) {
+__device__ void reset_model_objective(Inst<M>& I, bool literal = true) {
     constexpr int n = M::NX, m = M::NU;
-    for (int i = I.lane; i < I.N * n * n; i += 64) I.fx[i] = 0.0;
-    for (int i = I.lane; i < I.N * n * m; i += 64) I.fu[i] = 0.0;
+    // Inside the fused solve the Jacobians are overwritten (`.=`) by the gradients! call that follows at once
+    // (src/solve.jl:9-16), so zeroing them is unobservable; on the HBM-resident large path it would cost a
+    // megabyte of writes per instance and throw away the constant entries already in place (S_JAC_CONST).
+    if (literal || !is_large<M>::value) {
+        for (int i = I.lane; i < I.N * n * n; i += 64) I.fx[i] = 0.0;
+        for (int i = I.lane; i < I.N * n * m; i += 64) I.fu[i] = 0.0;
+        if (is_large<M>::value && I.lane == 0) I.scal[S_JAC_CONST] = 0.0;
+    }
     for (int i = I.lane; i < I.T * n; i += 64) I.gx[i] = 0.0;
     for (int i = I.lane; i < I.N * m; i += 64) I.gu[i] = 0.0;
     for (int i = I.lane; i < I.T * n * n; i += 64) I.gxx[i] = 0.0;
@@ -927,7 +933,7 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
     for (int o = 1; o <= outer_max; ++o) {                            // src/solve.jl:105
         if (al_outer) I.outer_iterations = o;
         // ---------------- ilqr_solve! (src/solve.jl:1-54)
-        reset_model_objective<M>(I);                                  // (:9-10)
+        reset_model_objective<M>(I, false);                           // (:9-10)
         if (opt.reset_cache) {                                        // (:12) reset!(data)
             I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0;
         }

@@ -108,7 +108,7 @@ __device__ __forceinline__ gdbl* uniform_ptr(gdbl* p) {
 }
 // what the other large-path phase functions need of one instance
 struct LargeArgs {
-    gdbl *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act, *w, *gxx, *guu, *gux;
+    gdbl *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act, *w, *gxx, *guu, *gux, *scal;
     int T, N;
 };
 template <class M>
@@ -116,7 +116,7 @@ __device__ __forceinline__ LargeArgs large_args(Inst<M>& I) {
     return LargeArgs{as_global(I.xb), as_global(I.ub), as_global(I.x), as_global(I.u), as_global(I.fx), as_global(I.fu),
                      as_global(I.gx), as_global(I.gu), as_global(I.K), as_global(I.k), as_global(I.Lx), as_global(I.Lu),
                      as_global(I.c), as_global(I.lam), as_global(I.rho), as_global(I.act), as_global(I.w),
-                     as_global(I.gxx), as_global(I.guu), as_global(I.gux), I.T, I.N};
+                     as_global(I.gxx), as_global(I.guu), as_global(I.gux), as_global(I.scal), I.T, I.N};
 }
 __device__ __forceinline__ void uniform_args(LargeArgs& A) {
     A.xb = uniform_ptr(A.xb); A.ub = uniform_ptr(A.ub); A.x = uniform_ptr(A.x); A.u = uniform_ptr(A.u);
@@ -124,6 +124,7 @@ __device__ __forceinline__ void uniform_args(LargeArgs& A) {
     A.K = uniform_ptr(A.K); A.k = uniform_ptr(A.k); A.Lx = uniform_ptr(A.Lx); A.Lu = uniform_ptr(A.Lu);
     A.c = uniform_ptr(A.c); A.lam = uniform_ptr(A.lam); A.rho = uniform_ptr(A.rho); A.act = uniform_ptr(A.act);
     A.w = uniform_ptr(A.w); A.gxx = uniform_ptr(A.gxx); A.guu = uniform_ptr(A.guu); A.gux = uniform_ptr(A.gux);
+    A.scal = uniform_ptr(A.scal);
     A.T = __builtin_amdgcn_readfirstlane(A.T); A.N = __builtin_amdgcn_readfirstlane(A.N);
 }
 
@@ -138,19 +139,25 @@ __attribute__((noinline)) __device__ void gradients_large_fn(LargeArgs A, int co
     const int lane = threadIdx.x, T = A.T, N = A.N;
     constexpr bool split = M::JAC_NVAR < n * n + n * m;
     if constexpr (split) {
-        constexpr int EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
-        double cfx[EFX], cfu[EFU];
+        // The constant entries are written once per buffer lifetime: 10 KB per timestep and instance that would
+        // otherwise be re-sent to HBM every iteration (530 MB per call for 512 synth32 instances — that alone
+        // was half of this phase). ilqr_reset and ilqr_set_buffer on the Jacobians clear the flag.
+        if (A.scal[S_JAC_CONST] == 0.0) {
+            constexpr int EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
+            double cfx[EFX], cfu[EFU];
 #pragma unroll
-        for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; cfx[q] = e < n * n ? M::JAC_CONST_FX[0][e] : 0.0; }
+            for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; cfx[q] = e < n * n ? M::JAC_CONST_FX[0][e] : 0.0; }
 #pragma unroll
-        for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; cfu[q] = e < n * m ? M::JAC_CONST_FU[0][e] : 0.0; }
-        for (int t = 0; t < N; ++t) {
+            for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; cfu[q] = e < n * m ? M::JAC_CONST_FU[0][e] : 0.0; }
+            for (int t = 0; t < N; ++t) {
 #pragma unroll
-            for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) A.fx[(size_t)t * n * n + e] = cfx[q]; }
+                for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) A.fx[(size_t)t * n * n + e] = cfx[q]; }
 #pragma unroll
-            for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) A.fu[(size_t)t * n * m + e] = cfu[q]; }
+                for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) A.fu[(size_t)t * n * m + e] = cfu[q]; }
+            }
+            __threadfence_block();       // the state-dependent entries below overwrite some of these addresses
+            if (lane == 0) A.scal[S_JAC_CONST] = 1.0;
         }
-        __threadfence_block();       // the state-dependent entries below overwrite some of these addresses
     }
     for (int t = lane; t < T; t += 64) {
         double w[cdim<M::NW>::v];

@@ -12,8 +12,10 @@ namespace ilqr {
 // scalar slots (stored as doubles) at Layout::scal
 enum {
     S_OBJECTIVE = 0, S_MAX_VIOLATION, S_STEP_SIZE, S_STATUS, S_ITERATIONS, S_GRADIENT_NORM,
-    S_OUTER_ITERATIONS, S_POTRF_INFO, S_ROLLOUTS, S_STATES_EQ_NOMINAL, S_PROF = 10, S_COUNT = 16,
-    S_DONE = 15   // host-stepped AL loop only: instance finished (shares the last profiling slot)
+    S_OUTER_ITERATIONS, S_POTRF_INFO, S_ROLLOUTS, S_STATES_EQ_NOMINAL, S_PROF = 10,
+    S_DONE = 15,  // host-stepped AL loop only: instance finished (shares the last profiling slot)
+    S_JAC_CONST = 16,   // large path: the constant entries of this instance's fx/fu buffers are in place
+    S_COUNT = 24
 };
 
 struct Layout {
