@@ -69,6 +69,7 @@ class Solver:
             self._selectors = low["selectors"]
             self.num_user_parameter = low["num_user_parameter"]
             self.constraint_rows = low["constraint_rows"]
+            self.state_dims, self.action_dims = low["state_dims"], low["action_dims"]
             model_library = compile_model(name, low["dynamics"], low["cost_stage"], low["cost_term"],
                                           low["con_stage"], low["con_term"])
             model, horizon = name, T

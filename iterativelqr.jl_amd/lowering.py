@@ -16,8 +16,10 @@ distinct objects are LOWERED here, exactly, onto that template:
     to the AL cost, its gradient and Gauss-Newton Hessian (src/augmented_lagrangian.jl:39-66,
     src/gradients.jl:23-81) and nothing to max_violation (src/data/constraints.jl:23-46).
 
-The selectors ride in the parameter trajectory θ_t behind the user's own parameters. All objects must share
-(num_state, num_action): time-varying DIMENSIONS are not lowered.
+The selectors ride in the parameter trajectory θ_t behind the user's own parameters. Time-varying DIMENSIONS
+(num_next_state ≠ num_state, src/dynamics.jl:5-7) are lowered by zero-padding every kind to the largest
+(num_state, num_action) of the horizon — see the comment at the padding site for why that is exact; the host
+arrays (x1, ū, trajectories, gains) are then the padded ones, with `state_dims[t]` / `action_dims[t]` real entries.
 """
 import numpy as np
 
@@ -48,19 +50,24 @@ def lower(dynamics, costs, constraints=None):
     kk, ki = _kinds(constraints[:-1]) if constraints is not None else ([], [])
     cost_term = costs[-1]
     con_term = constraints[-1] if constraints is not None else None
-    n, m = dk[0].num_state, dk[0].num_action
-    for d in dk:
-        assert (d.num_state, d.num_action, d.num_next_state) == (n, m, n), "time-varying dimensions are not supported"
-    for c in ck:
-        assert (c.num_state, c.num_action) == (n, m)
-    for c in kk:
-        assert c.num_constraint == 0 or (c.num_state, c.num_action) == (n, m)
+    # dimensions along the horizon (src/dynamics.jl:5-7: num_next_state may differ from num_state)
+    n_t = [d.num_state for d in dynamics] + [dynamics[-1].num_next_state]
+    m_t = [d.num_action for d in dynamics]
+    for t in range(T - 1):
+        assert dynamics[t].num_next_state == n_t[t + 1], "dynamics[%d] does not produce the state of step %d" % (t, t + 1)
+        assert (costs[t].num_state, costs[t].num_action) == (n_t[t], m_t[t]), "cost[%d] dimensions" % t
+        if constraints is not None and constraints[t].num_constraint:
+            assert (constraints[t].num_state, constraints[t].num_action) == (n_t[t], m_t[t]), "constraint[%d] dimensions" % t
+    assert cost_term.num_state == n_t[-1]
+    assert con_term is None or con_term.num_constraint == 0 or con_term.num_state == n_t[-1]
+    n, m = max(n_t), max(m_t)
     everything = dk + ck + kk + [cost_term] + ([con_term] if con_term is not None else [])
     nwu = max(o.num_parameter for o in everything)
     if len(dk) == 1 and len(ck) == 1 and len(kk) <= 1:
         return dict(dynamics=dk[0], cost_stage=ck[0], cost_term=cost_term, con_stage=kk[0] if kk else None,
                     con_term=con_term, num_user_parameter=nwu, selectors=np.zeros((T, 0)),
-                    constraint_rows=[list(range(kk[0].num_constraint if kk else 0))] * (T - 1))
+                    constraint_rows=[list(range(kk[0].num_constraint if kk else 0))] * (T - 1),
+                    state_dims=n_t, action_dims=m_t)
     # selector columns: one block per category that really varies
     off, blocks = nwu, {}
     for name, kinds in (("dynamics", dk), ("cost", ck), ("constraint", kk)):
@@ -79,9 +86,14 @@ def lower(dynamics, costs, constraints=None):
 
     # the traced objects all use the same symbols x0.., u0.., w0.. (codegen._variables), so their expressions can be
     # combined directly; the lambdas only pick up the selector symbols
-    dyn = Dynamics(lambda x, u, w: [sum(gate("dynamics", k, w) * d.evaluate[i] for k, d in enumerate(dk)) for i in range(n)],
-                   n, m, nw)
-    cost_stage = Cost(lambda x, u, w: sum(gate("cost", k, w) * c.evaluate for k, c in enumerate(ck)), n, m, nw)
+    # time-varying DIMENSIONS: every kind is zero-padded to (n, m) = (max n_t, max m_t). Padded next-state rows are 0;
+    # padded actions get the cost u²/2 so that Quu stays positive definite — block-diagonal with the real block, so
+    # its Cholesky and solves leave the real block untouched and return K = 0, k = 0 for the padding (u stays 0);
+    # padded states never enter any function, so their rows/columns of fx, Qxx, Qux, P are exactly zero.
+    dyn = Dynamics(lambda x, u, w: [sum(gate("dynamics", k, w) * (d.evaluate[i] if i < d.num_next_state else 0)
+                                        for k, d in enumerate(dk)) for i in range(n)], n, m, nw)
+    cost_stage = Cost(lambda x, u, w: sum(gate("cost", k, w) * (c.evaluate + sum(u[j] * u[j] for j in range(c.num_action, m)) / 2)
+                                          for k, c in enumerate(ck)), n, m, nw)
     cost_term_l = Cost(lambda x, u, w: cost_term.evaluate, n, 0, nw)
     con_stage = con_term_l = None
     rows = [[] for _ in range(T - 1)]
@@ -105,4 +117,4 @@ def lower(dynamics, costs, constraints=None):
         else:
             con_term_l = Constraint()
     return dict(dynamics=dyn, cost_stage=cost_stage, cost_term=cost_term_l, con_stage=con_stage, con_term=con_term_l,
-                num_user_parameter=nwu, selectors=sel, constraint_rows=rows)
+                num_user_parameter=nwu, selectors=sel, constraint_rows=rows, state_dims=n_t, action_dims=m_t)

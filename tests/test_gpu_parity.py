@@ -615,3 +615,65 @@ def test_large_path_odd_dimensions_and_terminal_constraint(pkg, oracle):
     assert np.abs(K - ref["K"])[same].max() <= 1e-5 * np.abs(ref["K"]).max()
     assert np.allclose(st["max_violation"][same], ref["stats"]["max_violation"][same], atol=1e-7)
     sol.close()
+
+
+def test_time_varying_dimensions(pkg):
+    """num_next_state != num_state along the horizon (src/dynamics.jl:5-7), lowered by zero padding (lowering.py).
+    The oracle keeps uniform dimensions, so the check is direct: the Riccati recursion of src/backward_pass.jl:42-90
+    evaluated with numpy on the RAGGED blocks of the device's own linearisation must reproduce the device's gains and
+    value function, and everything in the padding must be exactly zero."""
+    from test_codegen import _ragged_problem
+    T, B = 9, 8
+    dynamics, costs, constraints, n_t, m_t = _ragged_problem(pkg, T)
+    sol = pkg.Solver(dynamics, costs, constraints, batch=B, options=pkg.Options(verbose=0), name="ragged")
+    n, m = sol.nx, sol.nu
+    assert (n, m, sol.state_dims, sol.action_dims) == (4, 2, n_t, m_t)
+    rng = np.random.default_rng(5)
+    x1 = np.zeros((B, n)); x1[:, :n_t[0]] = 0.5 * rng.standard_normal((B, n_t[0]))
+    ub = np.zeros((B, T - 1, m))
+    for t in range(T - 1):
+        ub[:, t, :m_t[t]] = 0.2 * rng.standard_normal((B, m_t[t]))
+    sol.initialize_rollout_(x1, ub)
+    xb = sol.buffer("nominal_states").reshape(B, T, n)
+    for t in range(T):
+        assert (xb[:, t, n_t[t]:] == 0).all()
+    sol.run_stage_("cost_nominal"); sol.run_stage_("gradients"); sol.run_stage_("backward_pass")
+    g = {k: sol.buffer(k) for k in ("jacobian_state", "jacobian_action", "gradient_state", "gradient_action",
+                                    "hessian_state_state", "hessian_action_action", "hessian_action_state", "K", "k", "P", "p")}
+    fx = g["jacobian_state"].reshape(B, T - 1, n, n).transpose(0, 1, 3, 2)          # [b][t][row][col]
+    fu = g["jacobian_action"].reshape(B, T - 1, m, n).transpose(0, 1, 3, 2)
+    gxx = g["hessian_state_state"].reshape(B, T, n, n).transpose(0, 1, 3, 2)
+    guu = g["hessian_action_action"].reshape(B, T - 1, m, m).transpose(0, 1, 3, 2)
+    gux = g["hessian_action_state"].reshape(B, T - 1, n, m).transpose(0, 1, 3, 2)   # [b][t][m][n]
+    gx = g["gradient_state"].reshape(B, T, n); gu = g["gradient_action"].reshape(B, T - 1, m)
+    K = g["K"].reshape(B, T - 1, n, m).transpose(0, 1, 3, 2); k = g["k"].reshape(B, T - 1, m)
+    P = g["P"].reshape(B, T, n, n).transpose(0, 1, 3, 2); p = g["p"].reshape(B, T, n)
+    for b in range(B):
+        nT = n_t[-1]
+        Pn, pn = gxx[b, T - 1, :nT, :nT], gx[b, T - 1, :nT]
+        for t in range(T - 2, -1, -1):
+            n0, m0, n1 = n_t[t], m_t[t], n_t[t + 1]
+            A, Bm = fx[b, t, :n1, :n0], fu[b, t, :n1, :m0]
+            Qx = A.T @ pn + gx[b, t, :n0]; Qu = Bm.T @ pn + gu[b, t, :m0]
+            Qxx = A.T @ Pn @ A + gxx[b, t, :n0, :n0]
+            Quu = Bm.T @ Pn @ Bm + guu[b, t, :m0, :m0]
+            Qux = Bm.T @ Pn @ A + gux[b, t, :m0, :n0]
+            Kt = -np.linalg.solve(Quu, Qux); kt = -np.linalg.solve(Quu, Qu)
+            assert np.allclose(K[b, t, :m0, :n0], Kt, rtol=1e-9, atol=1e-11), (b, t)
+            assert np.allclose(k[b, t, :m0], kt, rtol=1e-9, atol=1e-11)
+            assert (K[b, t, m0:, :] == 0).all() and (K[b, t, :, n0:] == 0).all() and (k[b, t, m0:] == 0).all()
+            Pn = Kt.T @ Quu @ Kt + Kt.T @ Qux + Qux.T @ Kt + Qxx
+            pn = (Quu @ Kt).T @ kt + Kt.T @ Qu + Qux.T @ kt + Qx
+            assert np.allclose(P[b, t, :n0, :n0], Pn, rtol=1e-9, atol=1e-11)
+            assert np.allclose(p[b, t, :n0], pn, rtol=1e-9, atol=1e-11)
+            assert (P[b, t, n0:, :] == 0).all() and (P[b, t, :, n0:] == 0).all() and (p[b, t, n0:] == 0).all()
+    # whole solve: converges on the real problem, the padding stays exactly zero
+    sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    for t in range(T):
+        assert (x[:, t, n_t[t]:] == 0).all()
+    for t in range(T - 1):
+        assert (u[:, t, m_t[t]:] == 0).all()
+    assert np.isfinite(x).all() and (st["max_violation"] <= 5e-3).all(), st["max_violation"]
+    assert np.abs(x[:, -1, 0] - 0.2).max() <= 5e-3 and np.abs(x[:, -1, 1] + 0.1).max() <= 5e-3
+    sol.close()
