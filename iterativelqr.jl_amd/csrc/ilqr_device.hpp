@@ -74,6 +74,10 @@ __device__ __forceinline__ void bcast_array(double v, double (&out)[N]) {
 template <int N_> struct cdim { static constexpr int v = N_ > 0 ? N_ : 1; };
 
 template <class M> struct is_large { static constexpr bool value = (M::NX > 4 || M::NU > 4); };
+// Waves per instance (= per workgroup). The large path runs TWO: both execute the whole solve with identical,
+// wave-uniform control flow (so every barrier is reached by both); phases with idempotent global effects simply run
+// twice, the linearisation and the dual update split their index range, the Riccati step splits its MFMA tiles.
+template <class M> struct waves_of { static constexpr int value = is_large<M>::value ? 2 : 1; };
 
 // Throughput ("slim") variant of a small model: the Jacobians fx, fu stay in HBM/L2 instead of LDS, so the
 // LDS set shrinks (acrobot T=101: 36 KB -> 20 KB, 8 instances per CU) and the kernel is compiled for two
@@ -126,7 +130,7 @@ struct Inst {
     double *trace;         // per-iteration trace rows of this instance (what `verbose` prints, src/solve.jl:40-45)
     int trace_cap, trace_len;
     const double* gzero;   // HBM: a 0.0
-    int T, N, C, lane;
+    int T, N, C, lane, wave;
     double objective, max_violation, step_size, gradient_norm;
     int status, iterations, outer_iterations, potrf_info, rollouts, states_eq_nominal;
 #ifdef ILQR_PROFILE
@@ -137,8 +141,7 @@ struct Inst {
 // large-model path (ilqr_device_large.hpp)
 template <class M> __device__ void gradients_large(Inst<M>& I, bool constrained);
 template <class M, bool STORE_VALUE> __device__ void backward_pass_large(Inst<M>& I);
-template <class M> __device__ void rollout_large(Inst<M>& I, double alpha);
-template <class M> __device__ double delta_large(Inst<M>& I);
+template <class M> __device__ void rollout_large(Inst<M>& I, double alpha, bool want_delta, double& delta_out);
 
 // ------------------------------------------------------------------ cost!
 // One timestep per lane. upd_J: evaluate J and the active set at (X,U)
@@ -827,7 +830,7 @@ __device__ __forceinline__ void gradients(Inst<M>& I, bool constrained) {
 }
 template <class M>
 __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
-    if constexpr (is_large<M>::value) rollout_large<M>(I, alpha);
+    if constexpr (is_large<M>::value) rollout_large<M>(I, alpha, with_delta, delta_out);
     else rollout_small<M>(I, alpha, with_delta, delta_out);
 }
 
@@ -835,7 +838,7 @@ __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with
 template <class M>
 __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrained) {
     constexpr int n = M::NX, m = M::NU;
-    constexpr bool MF = (n <= 4 && m <= 4);
+    constexpr bool MF = true;       // Δ rides along the first rollout on both paths (small: MFMAs beside the VALU chain; large: wave 1)
     const double c1 = 1.0e-4;
     const int max_iterations = 25;
     I.status = 0;                                                     // (:10)
@@ -844,9 +847,6 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     // trajectory_sensitivities (src/data/methods.jl:42-54) fused with the product
     // gradientᵀ·Δz (:20): on the MFMA path it rides along the first rollout below.
     double delta = 0.0;
-    if constexpr (is_large<M>::value) {
-        if (opt.line_search == 1) delta = delta_large<M>(I);
-    }
     I.step_size = 1.0;                                                // (:26)
     int iteration = 1;
     while (I.step_size >= opt.min_step_size) {                        // (:28)
@@ -895,8 +895,8 @@ __device__ void reset_model_objective(Inst<M>& I, bool literal = true) {
 // augmented_lagrangian_update! — src/augmented_lagrangian.jl:87-110
 template <class M>
 __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
-    constexpr int ncs = M::NCS;
-    for (int i = I.lane; i < I.C; i += 64) {
+    constexpr int ncs = M::NCS, W = waves_of<M>::value;
+    for (int i = I.lane + 64 * I.wave; i < I.C; i += 64 * W) {            // read-modify-write: each index exactly once
         const int ns = I.N * ncs;
         bool ineq;
         if (i < ns) ineq = ncs > 0 ? ((M::INEQ_S >> (i % (ncs > 0 ? ncs : 1))) & 1ull) : false;
@@ -976,7 +976,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.c = smem + L.c; I.lam = smem + L.lam; I.rho = smem + L.rho; I.act = smem + L.act;
     I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
-    I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x;
+    I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x & 63; I.wave = threadIdx.x >> 6;
     I.lds = smem;
     I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
 
 // solve!(solver) for every instance — src/solve.jl:137-143
 template <class M>
-__global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * waves_of<M>::value) void solve_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_slim(KArgs a) {
 
 // single stages for parity tests (STORE_VALUE: P, p are written to HBM)
 template <class M>
-__global__ __launch_bounds__(64) void stage_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * waves_of<M>::value) void stage_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -1155,14 +1155,14 @@ struct ModelModule {
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<M>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-        hipLaunchKernelGGL(solve_kernel<M>, dim3(a->B), dim3(64), lds, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(solve_kernel<M>, dim3(a->B), dim3(64 * waves_of<M>::value), lds, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     static int launch_stage(const KArgs* a, size_t lds, void* stream) {
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<M>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-        hipLaunchKernelGGL(stage_kernel<M>, dim3(a->B), dim3(64), lds, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(stage_kernel<M>, dim3(a->B), dim3(64 * waves_of<M>::value), lds, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     static int launch_solve_slim(const KArgs* a, size_t lds, void* stream) {

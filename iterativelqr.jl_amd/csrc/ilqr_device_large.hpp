@@ -70,7 +70,7 @@ __device__ __forceinline__ double4_t tile_load_global(Ptr G, int I0, int J0, int
 // different accumulators. Row tile a takes its A operand from Aop[a] (so two matrices can share one B pass).
 template <int TR, int TC, int KD, int AI, int AK, int BK, int BJ>
 __device__ __forceinline__ void tiles_mac(double4_t (&acc)[TR * TC], const double* const (&Aop)[TR], const int (&Arow)[TR],
-                                          const double* B, int li, int lk) {
+                                          const double* B, int li, int lk, int c0 = 0) {
     constexpr int KS = KD / 4;
     double fa[TR][KS], fb[TC][KS];
 #pragma unroll
@@ -81,7 +81,7 @@ __device__ __forceinline__ void tiles_mac(double4_t (&acc)[TR * TC], const doubl
     }
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-        const double* pb = B + BK * lk + BJ * (16 * c + li);
+        const double* pb = B + BK * lk + BJ * (16 * (c0 + c) + li);
 #pragma unroll
         for (int s = 0; s < KS; ++s) fb[c][s] = pb[BK * 4 * s];
     }
@@ -101,6 +101,8 @@ __device__ __forceinline__ void tiles_mac(double4_t (&acc)[TR * TC], const doubl
 // flat_load), LDS is re-derived from the dynamic shared symbol.
 typedef __attribute__((address_space(1))) double gdbl;
 template <class T> __device__ __forceinline__ gdbl* as_global(T* p) { return (gdbl*)p; }
+// LDS traffic of ONE wave is in order: a wave-local exchange between lanes needs no workgroup barrier
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ gdbl* uniform_ptr(gdbl* p) {
     unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -134,32 +136,34 @@ __device__ __forceinline__ void uniform_args(LargeArgs& A) {
 // are evaluated per timestep (M::dyn_jac_var_mem). Same `.=` semantics as src/dynamics.jl:45-46 every call.
 template <class M>
 __attribute__((noinline)) __device__ void gradients_large_fn(LargeArgs A, int constrained) {
-    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, W = waves_of<M>::value;
     uniform_args(A);
-    const int lane = threadIdx.x, T = A.T, N = A.N;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = A.T, N = A.N;
     constexpr bool split = M::JAC_NVAR < n * n + n * m;
     if constexpr (split) {
         // The constant entries are written once per buffer lifetime: 10 KB per timestep and instance that would
         // otherwise be re-sent to HBM every iteration (530 MB per call for 512 synth32 instances — that alone
         // was half of this phase). ilqr_reset and ilqr_set_buffer on the Jacobians clear the flag.
-        if (A.scal[S_JAC_CONST] == 0.0) {
+        const bool fresh = A.scal[S_JAC_CONST] == 0.0;   // read by both waves BEFORE anyone may set it ...
+        __syncthreads();                                  // ... so that both take the same branch (barriers inside)
+        if (fresh) {
             constexpr int EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
             double cfx[EFX], cfu[EFU];
 #pragma unroll
             for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; cfx[q] = e < n * n ? M::JAC_CONST_FX[0][e] : 0.0; }
 #pragma unroll
             for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; cfu[q] = e < n * m ? M::JAC_CONST_FU[0][e] : 0.0; }
-            for (int t = 0; t < N; ++t) {
+            for (int t = wave; t < N; t += W) {
 #pragma unroll
                 for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) A.fx[(size_t)t * n * n + e] = cfx[q]; }
 #pragma unroll
                 for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) A.fu[(size_t)t * n * m + e] = cfu[q]; }
             }
-            __threadfence_block();       // the state-dependent entries below overwrite some of these addresses
-            if (lane == 0) A.scal[S_JAC_CONST] = 1.0;
+            __syncthreads();             // the state-dependent entries below overwrite some of these addresses
+            if (lane == 0 && wave == 0) A.scal[S_JAC_CONST] = 1.0;
         }
     }
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane + 64 * wave; t < T; t += 64 * W) {                 // Hessians accumulate: each timestep exactly once
         double w[cdim<M::NW>::v];
         load_w<M::NW>((const double*)A.w, t, w);
         double xt[n];
@@ -226,10 +230,15 @@ __device__ __forceinline__ void gradients_large(Inst<M>& I, bool constrained) {
 
 // ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles)
 // One Riccati step (src/backward_pass.jl:42-90) for n = 32, m = 8 issues 132 tile MFMAs (64 cycles each on
-// gfx950: the matrix pipe is the floor, ~8.4 k cycles per step). Everything around them is arranged so that the
-// pipe does not wait: next step's fx, fu, gxx, guu, gux, gx, gu are fetched from HBM into registers a step
-// ahead (the cost Hessians directly in the D-layout of the tiles they are added to), Qxx never leaves the
-// accumulators, and the three products of the P update accumulate in one register tile.
+// gfx950 ⇒ 8.4 k cycles of one matrix pipe) around a serial Cholesky/solve chain of ~4 k cycles. The instance's
+// TWO waves (two SIMDs) split it:
+//     both    stage fx, fu (HBM → registers a step ahead → LDS);   [T; ûx] = [fx fu]ᵀ P′, one column tile each
+//     wave 0  Qx, Qux, Quu → potrf → potrs (K, k) → ûxt = Quu K → p, ∇L        (the serial chain)
+//     wave 1  Qu, Qxx = T fx + gxx (overlaps wave 0's chain) → ûxt → P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx
+// Three workgroup barriers per timestep. Operand fragments of a product are read from zero-padded LDS matrices first
+// (odd leading dimensions, transposition = stride pattern, no bounds checks), then the MFMAs issue back to back;
+// Qxx never leaves wave 1's accumulators; the cost Hessians are prefetched in the D-layout of the tiles they are
+// added to, by the wave that owns those tiles.
 struct RiccatiArgs { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int N; };
 struct RiccatiOut { double gradient_norm; int potrf_info; double prof[6]; };
 
@@ -237,10 +246,11 @@ template <class M, bool STORE_VALUE>
 __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiArgs A) {
     typedef LargeDims<M> LD;
     constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, ldm = LD::ldm;
-    constexpr int n4 = r4(n), m4 = r4(m), TN = NP / 16, TM = MP / 16;
-    constexpr int EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
+    constexpr int n4 = r4(n), m4 = r4(m), TN = NP / 16, TM = MP / 16, NT = 128;
+    constexpr int EFX = (n * n + NT - 1) / NT, EFU = (n * m + NT - 1) / NT;
     static_assert(n <= 32 && m <= 16, "large path: nx <= 32, nu <= 16");
     static_assert(LD::total == large_lds_doubles(n, m), "LDS carve and host-side size disagree");
+    static_assert(waves_of<M>::value == 2, "the Riccati step is written for two waves per instance");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     struct { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int potrf_info; double prof[6]; } I;
     I.fx = uniform_ptr(A.fx); I.fu = uniform_ptr(A.fu); I.gx = uniform_ptr(A.gx); I.gu = uniform_ptr(A.gu);
@@ -248,55 +258,67 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
     I.k = uniform_ptr(A.k); I.Lx = uniform_ptr(A.Lx); I.Lu = uniform_ptr(A.Lu); I.P = uniform_ptr(A.P); I.p = uniform_ptr(A.p);
     I.potrf_info = 0;
     for (int q = 0; q < 6; ++q) I.prof[q] = 0.0;
-    const int lane = threadIdx.x, N = __builtin_amdgcn_readfirstlane(A.N), li = lane & 15, lk = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = __builtin_amdgcn_readfirstlane(A.N), li = lane & 15, lk = lane >> 4;
+    const bool w0 = wave == 0;
     double* S = lds_dyn;
     double *sP = S + LD::oP, *sFx = S + LD::oFx, *sT = S + LD::oT, *sFu = S + LD::oFu, *sUh = S + LD::oUh,
            *sQux = S + LD::oQux, *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
-    double *sp = S + LD::oVec, *sQx = sp + NP, *sQu = sQx + NP, *sk = sQu + MP;
-    for (int e = lane; e < LD::total; e += 64) S[e] = 0.0;               // the tile padding must read as zero
+    double* sUxt0 = sT;                                                   // wave 0's copy of ûxt (T is dead by then)
+    double *sp = S + LD::oVec, *sQx = sp + NP, *sQu = sQx + NP, *sk = sQu + MP, *sOut = sk + MP;
+    for (int e = tid; e < LD::total; e += NT) S[e] = 0.0;                 // the tile padding must read as zero
     __syncthreads();
-    for (int e = lane; e < n * n; e += 64) {                              // P[H] .= gxx[H]  (:39)
+    for (int e = tid; e < n * n; e += NT) {                               // P[H] .= gxx[H]  (:39)
         const double v = I.gxx[(size_t)N * n * n + e];
         sP[(e / n) * ld + e % n] = v;
         if (STORE_VALUE) I.P[(size_t)N * n * n + e] = v;
     }
-    for (int i = lane; i < n; i += 64) {                                  // p[H] .= gx[H]   (:40)
+    for (int i = tid; i < n; i += NT) {                                   // p[H] .= gx[H]   (:40)
         const double v = I.gx[N * n + i];
         sp[i] = v;
         if (STORE_VALUE) I.p[N * n + i] = v;
     }
-    // register prefetch of step t's operands
+    // register prefetch of step t's operands (each wave fetches what it will consume)
     double rfx[EFX], rfu[EFU], rgv = 0.0;
     double4_t rgxx[TN * TN], rguu[TM * TM], rgux[TM * TN];
     auto fetch_early = [&](int t) {
 #pragma unroll
         for (int q = 0; q < EFX; ++q) {
-            const int e = lane + 64 * q;
-            if constexpr ((n * n) % 64 == 0) rfx[q] = I.fx[(size_t)t * n * n + e];
+            const int e = tid + NT * q;
+            if constexpr ((n * n) % NT == 0) rfx[q] = I.fx[(size_t)t * n * n + e];
             else rfx[q] = e < n * n ? I.fx[(size_t)t * n * n + e] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < EFU; ++q) {
-            const int e = lane + 64 * q;
-            if constexpr ((n * m) % 64 == 0) rfu[q] = I.fu[(size_t)t * n * m + e];
+            const int e = tid + NT * q;
+            if constexpr ((n * m) % NT == 0) rfu[q] = I.fu[(size_t)t * n * m + e];
             else rfu[q] = e < n * m ? I.fu[(size_t)t * n * m + e] : 0.0;
         }
-        rgv = lane < n ? I.gx[t * n + lane] : (lane < n + m ? I.gu[t * m + (lane - n)] : 0.0);
+        rgv = w0 ? I.gx[t * n + (lane < n ? lane : 0)] : I.gu[t * m + (lane < m ? lane : 0)];
     };
     auto fetch_late = [&](int t) {
+        if (w0) {
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int c = 0; c < TN; ++c) rgxx[a * TN + c] = tile_load_global<n, n>(I.gxx + (size_t)t * n * n, 16 * a, 16 * c, li, lk);
+                for (int c = 0; c < TM; ++c) rguu[a * TM + c] = tile_load_global<m, m>(I.guu + (size_t)t * m * m, 16 * a, 16 * c, li, lk);
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int c = 0; c < TM; ++c) rguu[a * TM + c] = tile_load_global<m, m>(I.guu + (size_t)t * m * m, 16 * a, 16 * c, li, lk);
+                for (int c = 0; c < TN; ++c) rgux[a * TN + c] = tile_load_global<m, n>(I.gux + (size_t)t * m * n, 16 * a, 16 * c, li, lk);
+        } else {
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int c = 0; c < TN; ++c) rgux[a * TN + c] = tile_load_global<m, n>(I.gux + (size_t)t * m * n, 16 * a, 16 * c, li, lk);
+                for (int c = 0; c < TN; ++c) rgxx[a * TN + c] = tile_load_global<n, n>(I.gxx + (size_t)t * n * n, 16 * a, 16 * c, li, lk);
+        }
     };
+#pragma unroll
+    for (int q = 0; q < TN * TN; ++q) rgxx[q] = double4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < TM * TM; ++q) rguu[q] = double4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < TM * TN; ++q) rgux[q] = double4_t{0, 0, 0, 0};
     if (N > 0) { fetch_early(N - 1); fetch_late(N - 1); }
     double gmax = 0.0;
     __syncthreads();
@@ -304,122 +326,125 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
         ILQR_SUB_BEGIN();
 #pragma unroll
         for (int q = 0; q < EFX; ++q) {
-            const int e = lane + 64 * q;
-            if ((n * n) % 64 == 0 || e < n * n) sFx[(e / n) * ld + e % n] = rfx[q];
+            const int e = tid + NT * q;
+            if ((n * n) % NT == 0 || e < n * n) sFx[(e / n) * ld + e % n] = rfx[q];
         }
 #pragma unroll
         for (int q = 0; q < EFU; ++q) {
-            const int e = lane + 64 * q;
-            if ((n * m) % 64 == 0 || e < n * m) sFu[(e / n) * ld + e % n] = rfu[q];
+            const int e = tid + NT * q;
+            if ((n * m) % NT == 0 || e < n * m) sFu[(e / n) * ld + e % n] = rfu[q];
         }
         const double gv = rgv;
-        __syncthreads();
-        fetch_early(t > 0 ? t - 1 : 0);
-        // Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49): one output per lane
-        if (lane < n + m) {
-            const double* colp = lane < n ? sFx + lane * ld : sFu + (lane - n) * ld;
+        __syncthreads();                                                  // (1) fx, fu staged; P′, p′ of the previous step visible
+        fetch_early(t > 0 ? t - 1 : 0);                                   // (t = 0: a harmless re-read instead of a branch)
+        // Qx = fx^T p' + gx (wave 0), Qu = fu^T p' + gu (wave 1)   (:44-49): one output per lane
+        {
+            const int col = w0 ? (lane < n ? lane : 0) : (lane < m ? lane : 0);
+            const double* colp = w0 ? sFx + col * ld : sFu + col * ld;
             double acc = 0.0;
 #pragma unroll
             for (int l = 0; l < n; ++l) acc += colp[l] * sp[l];
-            if (lane < n) sQx[lane] = acc + gv;
-            else sQu[lane - n] = acc + gv;
+            if (w0 && lane < n) sQx[lane] = acc + gv;
+            if (!w0 && lane < m) sQu[lane] = acc + gv;
         }
         ILQR_SUB_MARK(I, 0);
-        // [T; ux_hat] = [fx fu]^T P'  (:52, :57, :62): one pass over the P' fragments
+        // [T; ux_hat] = [fx fu]^T P'  (:52, :57, :62): each wave one column tile (wave 0 all of them when there is one)
         {
-            constexpr int TR = TN + TM;
-            double4_t acc[TR * TN];
+            constexpr int TR = TN + TM, TC = TN == 2 ? 1 : TN;
+            if (TN == 2 || w0) {
+                const int c0 = TN == 2 ? wave : 0;
+                double4_t acc[TR * TC];
 #pragma unroll
-            for (int q = 0; q < TR * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
-            const double* Aop[TR]; int Arow[TR];
+                for (int q = 0; q < TR * TC; ++q) acc[q] = double4_t{0, 0, 0, 0};
+                const double* Aop[TR]; int Arow[TR];
 #pragma unroll
-            for (int a = 0; a < TR; ++a) { Aop[a] = a < TN ? sFx : sFu; Arow[a] = a < TN ? 16 * a : 16 * (a - TN); }
-            tiles_mac<TR, TN, n4, ld, 1, 1, ld>(acc, Aop, Arow, sP, li, lk);
+                for (int a = 0; a < TR; ++a) { Aop[a] = a < TN ? sFx : sFu; Arow[a] = a < TN ? 16 * a : 16 * (a - TN); }
+                tiles_mac<TR, TC, n4, ld, 1, 1, ld>(acc, Aop, Arow, sP, li, lk, c0);
 #pragma unroll
-            for (int a = 0; a < TR; ++a)
+                for (int a = 0; a < TR; ++a)
 #pragma unroll
-                for (int c = 0; c < TN; ++c) {
-                    if (a < TN) tile_store<ld>(sT, acc[a * TN + c], 16 * a, 16 * c, li, lk);
-                    else tile_store<ldm>(sUh, acc[a * TN + c], 16 * (a - TN), 16 * c, li, lk);
-                }
+                    for (int c = 0; c < TC; ++c) {
+                        if (a < TN) tile_store<ld>(sT, acc[a * TC + c], 16 * a, 16 * (c0 + c), li, lk);
+                        else tile_store<ldm>(sUh, acc[a * TC + c], 16 * (a - TN), 16 * (c0 + c), li, lk);
+                    }
+            }
         }
-        __syncthreads();
+        __syncthreads();                                                  // (2) T, ux_hat, Qx, Qu complete
         ILQR_SUB_MARK(I, 1);
-        // Qux = ux_hat fx + gux (:63-64), Quu = ux_hat fu + guu (:58-59): one pass over the ux_hat fragments
-        {
-            constexpr int KS = n4 / 4, TC = TN + TM;
-            double4_t acc[TM * TC];
+        double4_t qxx[TN * TN];
 #pragma unroll
-            for (int q = 0; q < TM * TC; ++q) acc[q] = double4_t{0, 0, 0, 0};
-            double fa[TM][KS], fb[TC][KS];
+        for (int q = 0; q < TN * TN; ++q) qxx[q] = double4_t{0, 0, 0, 0};
+        if (w0) {
+            // Qux = ux_hat fx + gux (:63-64), Quu = ux_hat fu + guu (:58-59): one pass over the ux_hat fragments
+            {
+                constexpr int KS = n4 / 4, TC = TN + TM;
+                double4_t acc[TM * TC];
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int sx = 0; sx < KS; ++sx) fa[a][sx] = sUh[(4 * sx + lk) * ldm + 16 * a + li];
-#pragma unroll
-            for (int c = 0; c < TC; ++c)
-#pragma unroll
-                for (int sx = 0; sx < KS; ++sx)
-                    fb[c][sx] = c < TN ? sFx[(16 * c + li) * ld + 4 * sx + lk] : sFu[(16 * (c - TN) + li) * ld + 4 * sx + lk];
-#pragma unroll
-            for (int sx = 0; sx < KS; ++sx)
+                for (int q = 0; q < TM * TC; ++q) acc[q] = double4_t{0, 0, 0, 0};
+                double fa[TM][KS], fb[TC][KS];
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int c = 0; c < TC; ++c)
-                        acc[a * TC + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][sx], fb[c][sx], acc[a * TC + c], 0, 0, 0);
+                    for (int sx = 0; sx < KS; ++sx) fa[a][sx] = sUh[(4 * sx + lk) * ldm + 16 * a + li];
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+                for (int c = 0; c < TC; ++c)
 #pragma unroll
-                for (int c = 0; c < TC; ++c) {
-                    if (c < TN) tile_store<ldm>(sQux, acc[a * TC + c] + rgux[a * TN + c], 16 * a, 16 * c, li, lk);
-                    else tile_store<ldm>(sQuu, acc[a * TC + c] + rguu[a * TM + (c - TN)], 16 * a, 16 * (c - TN), li, lk);
-                }
-        }
-        __syncthreads();
-        ILQR_SUB_MARK(I, 2);
-        // Qxx = T fx + gxx (:53-54) stays in the accumulators. Its 32 MFMAs are independent of the Cholesky below
-        // (VALU only, branch-free) and share its basic block. (Measured: the scheduler still issues them in clumps,
-        // so the two pipes overlap little; sched_group_barrier patterns did not change that.)
-        double4_t qxx[TN * TN];
-        double Uc[m * m], Ur[m];
-        int info;
-        {
-            double4_t acc[TN * TN];
+                    for (int sx = 0; sx < KS; ++sx)
+                        fb[c][sx] = c < TN ? sFx[(16 * c + li) * ld + 4 * sx + lk] : sFu[(16 * (c - TN) + li) * ld + 4 * sx + lk];
 #pragma unroll
-            for (int q = 0; q < TN * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
-            const double* Aop[TN]; int Arow[TN];
+                for (int sx = 0; sx < KS; ++sx)
 #pragma unroll
-            for (int a = 0; a < TN; ++a) { Aop[a] = sT; Arow[a] = 16 * a; }
-            // potrf('U') operands on wave-uniform registers (info ignored, :68-69)
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int c = 0; c < TC; ++c)
+                            acc[a * TC + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][sx], fb[c][sx], acc[a * TC + c], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) {
+                        if (c < TN) tile_store<ldm>(sQux, acc[a * TC + c] + rgux[a * TN + c], 16 * a, 16 * c, li, lk);
+                        else tile_store<ldm>(sQuu, acc[a * TC + c] + rguu[a * TM + (c - TN)], 16 * a, 16 * (c - TN), li, lk);
+                    }
+            }
+            wave_lds_fence();                                             // this wave's own Quu, Qux writes
+            ILQR_SUB_MARK(I, 2);
+            // potrf('U') on wave-uniform registers (info ignored, :68-69)
+            double Uc[m * m], Ur[m];
 #pragma unroll
             for (int j = 0; j < m; ++j)
 #pragma unroll
                 for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? sQuu[j * ldm + i] : 0.0;
-            tiles_mac<TN, TN, n4, 1, ld, 1, ld>(acc, Aop, Arow, sFx, li, lk);
-            info = potrf_U<m>(Uc, Ur);
+            const int info = potrf_U<m>(Uc, Ur);
+            if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
+            fetch_late(t > 0 ? t - 1 : 0);
+            ILQR_SUB_MARK(I, 3);
+            // potrs('U'): column j of Qux per lane, Qu on lane n   (:70-75)
+            if (lane <= n) {
+                const int j = lane;
+                double b[m];
 #pragma unroll
-            for (int q = 0; q < TN * TN; ++q) qxx[q] = acc[q] + rgxx[q];
-        }
-        if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
-        fetch_late(t > 0 ? t - 1 : 0);                 // (t = 0: a harmless re-read instead of a branch)
-        ILQR_SUB_MARK(I, 3);
-        // potrs('U'): column j of Qux per lane, Qu on lane n   (:70-75)
-        for (int j = lane; j <= n; j += 64) {
-            double b[m];
+                for (int i = 0; i < m; ++i) b[i] = j < n ? sQux[j * ldm + i] : sQu[i];
+                potrs_U_rdiag<m, 1>(Uc, Ur, b);       // inverted diagonal from the factorisation: no divisions here
 #pragma unroll
-            for (int i = 0; i < m; ++i) b[i] = j < n ? sQux[j * ldm + i] : sQu[i];
-            potrs_U_rdiag<m, 1>(Uc, Ur, b);           // inverted diagonal from the factorisation: no divisions here
-#pragma unroll
-            for (int i = 0; i < m; ++i) {
-                const double v = b[i] * -1.0;
-                if (j < n) { sK[j * ldm + i] = v; I.K[(size_t)t * m * n + j * m + i] = v; }
-                else { sk[i] = v; I.k[t * m + i] = v; }
+                for (int i = 0; i < m; ++i) {
+                    const double v = b[i] * -1.0;
+                    if (j < n) { sK[j * ldm + i] = v; I.K[(size_t)t * m * n + j * m + i] = v; }
+                    else { sk[i] = v; I.k[t * m + i] = v; }
+                }
             }
+        } else {
+            // Qxx = T fx + gxx (:53-54): stays in this wave's accumulators, overlaps wave 0's Cholesky chain
+            const double* Aop[TN]; int Arow[TN];
+#pragma unroll
+            for (int a = 0; a < TN; ++a) { Aop[a] = sT; Arow[a] = 16 * a; }
+            tiles_mac<TN, TN, n4, 1, ld, 1, ld>(qxx, Aop, Arow, sFx, li, lk);
+#pragma unroll
+            for (int q = 0; q < TN * TN; ++q) qxx[q] = qxx[q] + rgxx[q];
+            fetch_late(t > 0 ? t - 1 : 0);
         }
-        __syncthreads();
+        __syncthreads();                                                  // (3) K, k in LDS; T no longer needed
         ILQR_SUB_MARK(I, 4);
-        // ux_tmp = Quu K   (:79)
+        // ux_tmp = Quu K   (:79): both waves, each into its own buffer (saves a barrier)
         {
             double4_t acc[TM * TN];
 #pragma unroll
@@ -428,14 +453,15 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
 #pragma unroll
             for (int a = 0; a < TM; ++a) { Aop[a] = sQuu; Arow[a] = 16 * a; }
             tiles_mac<TM, TN, m4, 1, ldm, 1, ldm>(acc, Aop, Arow, sK, li, lk);
+            double* dst = w0 ? sUxt0 : sUxt;
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int c = 0; c < TN; ++c) tile_store<ldm>(sUxt, acc[a * TN + c], 16 * a, 16 * c, li, lk);
+                for (int c = 0; c < TN; ++c) tile_store<ldm>(dst, acc[a * TN + c], 16 * a, 16 * c, li, lk);
+            wave_lds_fence();
         }
-        __syncthreads();
-        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order
-        {
+        if (!w0) {
+            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order
             double4_t acc[TN * TN];
 #pragma unroll
             for (int q = 0; q < TN * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
@@ -459,35 +485,38 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
                         }
                     }
                 }
-        }
-        // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89); Lagrangian gradient (src/solve.jl:73-81)
-        double pn = 0.0;
-        if (lane < n) {
-            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        } else {
+            // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89); Lagrangian gradient (src/solve.jl:73-81)
+            if (lane < n) {
+                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-            for (int l = 0; l < m; ++l) {
-                a1 += sUxt[lane * ldm + l] * sk[l];
-                a2 += sK[lane * ldm + l] * sQu[l];
-                a3 += sQux[lane * ldm + l] * sk[l];
+                for (int l = 0; l < m; ++l) {
+                    a1 += sUxt0[lane * ldm + l] * sk[l];
+                    a2 += sK[lane * ldm + l] * sQu[l];
+                    a3 += sQux[lane * ldm + l] * sk[l];
+                }
+                const double pn = ((a1 + a2) + a3) + sQx[lane];
+                const double Lx = sQx[lane] - pn;
+                gmax = nanmax(gmax, fabs(Lx));
+                I.Lx[t * n + lane] = Lx;
+                if (STORE_VALUE) I.p[t * n + lane] = pn;
+                sp[lane] = pn;                                            // p' of the next step (read after barrier (1))
             }
-            pn = ((a1 + a2) + a3) + sQx[lane];
-            const double Lx = sQx[lane] - pn;
-            gmax = nanmax(gmax, fabs(Lx));
-            I.Lx[t * n + lane] = Lx;
-            if (STORE_VALUE) I.p[t * n + lane] = pn;
+            if (lane < m) {
+                gmax = nanmax(gmax, fabs(sQu[lane]));
+                I.Lu[t * m + lane] = sQu[lane];
+            }
         }
-        if (lane < m) {
-            gmax = nanmax(gmax, fabs(sQu[lane]));
-            I.Lu[t * m + lane] = sQu[lane];
-        }
-        __syncthreads();
-        if (lane < n) sp[lane] = pn;                                      // p' of the next step
-        __syncthreads();
         ILQR_SUB_MARK(I, 5);
     }
+    __syncthreads();
+    // the serial chain lived on wave 0: hand its scalars to both waves (identical control flow afterwards)
+    const double gn = wave_max(gmax);
+    if (tid == 0) { sOut[0] = gn; sOut[1] = (double)I.potrf_info; }
+    __syncthreads();
     RiccatiOut out;
-    out.gradient_norm = wave_max(gmax);
-    out.potrf_info = I.potrf_info;
+    out.gradient_norm = sOut[0];
+    out.potrf_info = (int)sOut[1];
     for (int q = 0; q < 6; ++q) out.prof[q] = I.prof[q];
     __syncthreads();
     return out;
@@ -506,19 +535,23 @@ __device__ __forceinline__ void backward_pass_large(Inst<M>& I) {
 #endif
 }
 
-// ---------------------------------------------------------------- rollout! (one state component per lane)
-// u = αk + ū + Kx − Kx̄ (src/rollout.jl:24-28): K x on lanes 0..m-1 and K x̄ on lanes 32..32+m-1 at the same time
-// (K_t staged in LDS, fetched from HBM a step ahead). Dynamics: lane i evaluates row i of the affine part
+// ---------------------------------------------------------------- forward sweep: rollout! ∥ trajectory_sensitivities
+// The closed-loop rollout (src/rollout.jl:1-31) and, on the first line-search trial, the sensitivity recursion with its
+// dot product (src/data/methods.jl:42-54, src/forward_pass.jl:20) are independent forward sweeps over t: wave 0 runs
+// the rollout while wave 1 runs the sensitivities. Each works in its own LDS staging (wave-local fences, no workgroup
+// barrier inside the sweep); one barrier at the end.
+//
+// rollout: u = αk + ū + Kx − Kx̄ (:24-28) with K x on lanes 0..m-1 and K x̄ on lanes 32..32+m-1 at the same time (K_t
+// staged in LDS, fetched from HBM a step ahead); dynamics: lane i evaluates row i of the affine part
 // y = DYN_AFF [x; u; 1] with its coefficient row held in registers for the whole rollout, plus the generated
 // remainder (wave-cooperative trig). x and u travel between lanes through LDS.
 template <class M>
-__attribute__((noinline)) __device__ void rollout_large_fn(LargeArgs A, double alpha) {
+__device__ __forceinline__ void rollout_large_body(const LargeArgs& A, double alpha, int lane) {
     typedef LargeDims<M> LD;
     constexpr int n = M::NX, m = M::NU, EK = (m * n + 63) / 64;
     static_assert(n <= 32 && m <= 16, "large path: nx <= 32, nu <= 16");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    uniform_args(A);
-    const int lane = threadIdx.x, N = A.N;
+    const int N = A.N;
     double* sK = lds_dyn + LD::oK;                     // packed m x n
     double* sx = lds_dyn + LD::oVec;                   // x (n), then x̄ (n), then u (m)
     double* sxb = sx + LD::NP;
@@ -542,7 +575,7 @@ __attribute__((noinline)) __device__ void rollout_large_fn(LargeArgs A, double a
 #pragma unroll
         for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; if ((m * n) % 64 == 0 || e < m * n) sK[e] = rK[q]; }
         if (lane < n) { sx[lane] = xl; sxb[lane] = xbl; }
-        __syncthreads();
+        wave_lds_fence();
         if (t + 1 < N) fetchK(t + 1);
         const double xb_next = lane < n ? A.xb[(t + 1) * n + lane] : 0.0;
         const double kv = A.k[t * m + ui], ubv = A.ub[t * m + ui];
@@ -559,7 +592,7 @@ __attribute__((noinline)) __device__ void rollout_large_fn(LargeArgs A, double a
         v += acc;                                                         // (:27)
         v += -1.0 * a2;                                                   // (:28)
         if (lane < m) { su[lane] = v; A.u[t * m + lane] = v; }
-        __syncthreads();
+        wave_lds_fence();
         double ua[m];
 #pragma unroll
         for (int j = 0; j < m; ++j) ua[j] = su[j];
@@ -580,33 +613,22 @@ __attribute__((noinline)) __device__ void rollout_large_fn(LargeArgs A, double a
         xl = y;
         xbl = xb_next;
         if (lane < n) A.x[(t + 1) * n + lane] = y;
-        __syncthreads();
+        wave_lds_fence();
     }
-    __syncthreads();
-}
-template <class M>
-__device__ __forceinline__ void rollout_large(Inst<M>& I, double alpha) {
-    ILQR_PROF_BEGIN();
-    rollout_large_fn<M>(large_args(I), alpha);
-    I.rollouts += 1;
-    I.states_eq_nominal = 0;
-    ILQR_PROF_END(I, PROF_ROLLOUT);
 }
 
-// ---------------------------------------------------------------- trajectory_sensitivities + gradient^T dz
-// src/data/methods.jl:42-54 and the dot product of src/forward_pass.jl:20. K_t, fx_t, fu_t are staged in LDS
-// (HBM fetch a step ahead); Δu on lanes 0..m-1, Δx⁺ one row per lane.
+// Δu = k + KΔx on lanes 0..m-1, Δx⁺ = fuΔu + fxΔx one row per lane; K, fx, fu staged in LDS (HBM fetch a step ahead).
+// Staging buffers disjoint from the rollout's.
 template <class M>
-__attribute__((noinline)) __device__ double delta_large_fn(LargeArgs A) {
+__device__ __forceinline__ double delta_large_body(const LargeArgs& A, int lane) {
     typedef LargeDims<M> LD;
     constexpr int n = M::NX, m = M::NU, ld = LD::ld;
     constexpr int EK = (m * n + 63) / 64, EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    uniform_args(A);
-    const int lane = threadIdx.x, N = A.N;
-    double *sK = lds_dyn + LD::oK, *sFx = lds_dyn + LD::oFx, *sFu = lds_dyn + LD::oFu;
-    double* zx = lds_dyn + LD::oVec;        // n
-    double* zu = zx + LD::NP;               // m
+    const int N = A.N;
+    double *sK = lds_dyn + LD::oQux, *sFx = lds_dyn + LD::oFx, *sFu = lds_dyn + LD::oFu;
+    double* zx = lds_dyn + LD::oVec + 2 * LD::NP + LD::MP;        // n   (behind the rollout's x, x̄, u)
+    double* zu = zx + LD::NP;                                     // m
     double rK[EK], rfx[EFX], rfu[EFU];
     auto fetch = [&](int t) {
 #pragma unroll
@@ -627,7 +649,7 @@ __attribute__((noinline)) __device__ double delta_large_fn(LargeArgs A) {
         for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) sFx[(e / n) * ld + e % n] = rfx[q]; }
 #pragma unroll
         for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) sFu[(e / n) * ld + e % n] = rfu[q]; }
-        __syncthreads();
+        wave_lds_fence();
         if (t + 1 < N) fetch(t + 1);
         const double kv = A.k[t * m + ui], Luv = A.Lu[t * m + ui], Lxv = A.Lx[t * n + xi];
         double za[n];
@@ -639,24 +661,47 @@ __attribute__((noinline)) __device__ double delta_large_fn(LargeArgs A) {
         const double du = kv + acc;
         if (lane < m) { zu[lane] = du; dpart += Luv * du; }
         if (lane < n) dpart += Lxv * zx[xi];
-        __syncthreads();
+        wave_lds_fence();
         double a1 = 0.0, a2 = 0.0;                                        // Δx⁺ = fu Δu + fx Δx
 #pragma unroll
         for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * zu[j];
 #pragma unroll
         for (int j = 0; j < n; ++j) a2 += sFx[j * ld + xi] * za[j];
-        __syncthreads();
+        wave_lds_fence();
         if (lane < n) zx[lane] = a1 + a2;
-        __syncthreads();
+        wave_lds_fence();
     }
     return wave_sum(dpart);
 }
+
 template <class M>
-__device__ __forceinline__ double delta_large(Inst<M>& I) {
-    ILQR_PROF_BEGIN();
-    const double d = delta_large_fn<M>(large_args(I));
-    ILQR_PROF_END(I, PROF_DELTA);
+__attribute__((noinline)) __device__ double forward_sweep_large_fn(LargeArgs A, double alpha, int want_delta) {
+    typedef LargeDims<M> LD;
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    uniform_args(A);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    want_delta = __builtin_amdgcn_readfirstlane(want_delta);
+    double* sOut = lds_dyn + LD::oVec + 4 * LD::NP + 4 * LD::MP;
+    double d = 0.0;
+    if (wave == 0) rollout_large_body<M>(A, alpha, lane);
+    else if (want_delta) d = delta_large_body<M>(A, lane);
+    __syncthreads();
+    if (want_delta) {                     // hand wave 1's scalar to both waves (identical control flow afterwards)
+        if (tid == 64) sOut[2] = d;
+        __syncthreads();
+        d = sOut[2];
+        __syncthreads();
+    }
     return d;
+}
+template <class M>
+__device__ __forceinline__ void rollout_large(Inst<M>& I, double alpha, bool want_delta, double& delta_out) {
+    ILQR_PROF_BEGIN();
+    const double d = forward_sweep_large_fn<M>(large_args(I), alpha, want_delta ? 1 : 0);
+    if (want_delta) delta_out = d;
+    I.rollouts += 1;
+    I.states_eq_nominal = 0;
+    ILQR_PROF_END(I, PROF_ROLLOUT);
 }
 
 }  // namespace ilqr
