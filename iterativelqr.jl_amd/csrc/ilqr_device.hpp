@@ -74,10 +74,7 @@ __device__ __forceinline__ void bcast_array(double v, double (&out)[N]) {
 template <int N_> struct cdim { static constexpr int v = N_ > 0 ? N_ : 1; };
 
 template <class M> struct is_large { static constexpr bool value = (M::NX > 4 || M::NU > 4); };
-// Waves per instance (= per workgroup). The large path runs TWO: both execute the whole solve with identical,
-// wave-uniform control flow (so every barrier is reached by both); phases with idempotent global effects simply run
-// twice, the linearisation and the dual update split their index range, the Riccati step splits its MFMA tiles.
-template <class M> struct waves_of { static constexpr int value = is_large<M>::value ? 2 : 1; };
+
 
 // Throughput ("slim") variant of a small model: the Jacobians fx, fu stay in HBM/L2 instead of LDS, so the
 // LDS set shrinks (acrobot T=101: 36 KB -> 20 KB, 8 instances per CU) and the kernel is compiled for two
@@ -86,6 +83,14 @@ template <class M> struct waves_of { static constexpr int value = is_large<M>::v
 template <class M> struct Slim : M { static constexpr bool SLIM = true; };
 template <class M, class = void> struct slim_of { static constexpr bool value = false; };
 template <class M> struct slim_of<M, decltype((void)M::SLIM)> { static constexpr bool value = M::SLIM; };
+// Waves per instance (= per workgroup): TWO, except in the throughput variant (there the second wave of a SIMD
+// belongs to another instance). Both waves execute the whole solve with identical, wave-uniform control flow, so
+// every workgroup barrier is reached by both by construction. Cheap phases with idempotent effects simply run on
+// both; the linearisation and the dual update (read-modify-write) split their index range; wave 1 runs the
+// sensitivity sweep while wave 0 runs the first rollout; the small-model Riccati recursion stays on wave 0 (a
+// 1 k-cycle step cannot pay for a barrier), the large-model one splits its MFMA tiles. Scalars produced by one
+// wave are handed to the other through LDS.
+template <class M> struct waves_of { static constexpr int value = slim_of<M>::value ? 1 : 2; };
 
 // parameters of timestep t (empty when NW == 0)
 template <int NW>
@@ -257,9 +262,9 @@ __device__ void cost_bang(Inst<M>& I, bool mode_current, bool constrained) {
 // terms of src/gradients.jl:54-80 using the violations BUFFER (Q2).
 template <class M>
 __device__ void gradients_small(Inst<M>& I, bool constrained) {
-    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, W = waves_of<M>::value;
     ILQR_PROF_BEGIN();
-    for (int t = I.lane; t < I.T; t += 64) {
+    for (int t = I.lane + 64 * I.wave; t < I.T; t += 64 * W) {          // Hessians accumulate: each timestep exactly once
         double w[cdim<M::NW>::v];
         load_w<M::NW>(I.w, t, w);
         double xt[n];
@@ -686,14 +691,21 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
     }
     if (t == 0) riccati_step(A, 0);
     I.gradient_norm = wave_max((b0 && c == 0) ? gmax : 0.0);
-    __syncthreads();
 }
 
 template <class M, bool STORE_VALUE>
 __device__ __forceinline__ void backward_pass(Inst<M>& I) {
     ILQR_PROF_BEGIN();
     if constexpr (is_large<M>::value) backward_pass_large<M, STORE_VALUE>(I);
-    else backward_pass_mfma<M, STORE_VALUE>(I);
+    else {
+        // the serial recursion runs on wave 0; its scalars go to the other wave through LDS
+        if (I.wave == 0) {
+            backward_pass_mfma<M, STORE_VALUE>(I);
+            if (waves_of<M>::value > 1 && I.lane == 0) { I.zs[2] = I.gradient_norm; I.zs[3] = (double)I.potrf_info; }
+        }
+        __syncthreads();
+        if constexpr (waves_of<M>::value > 1) { I.gradient_norm = I.zs[2]; I.potrf_info = (int)I.zs[3]; }
+    }
     ILQR_PROF_END(I, PROF_BACKWARD);
 }
 
@@ -708,8 +720,7 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
 template <class M>
 __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
     constexpr int n = M::NX, m = M::NU;
-    constexpr bool MF = (n <= 4 && m <= 4);
-    ILQR_PROF_BEGIN();
+    constexpr bool MF = (n <= 4 && m <= 4) && waves_of<M>::value == 1;   // with two waves Δ is wave 1's job (delta_small)
     double xt[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) xt[i] = I.xb[i];                      // (:19)
@@ -812,10 +823,44 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     if constexpr (MF) {
         if (with_delta) delta_out = lane_bcast(dacc, 0);               // element (0,0) of block 0
     }
-    I.rollouts += 1;
-    I.states_eq_nominal = 0;
-    __syncthreads();
-    ILQR_PROF_END(I, PROF_ROLLOUT);
+}
+
+// trajectory_sensitivities (src/data/methods.jl:42-54) and the product gradient^T dz (src/forward_pass.jl:20) as a
+// sweep of its own: wave 1 runs it while wave 0 runs the first rollout (all operands are read-only LDS data by then).
+// Wave-uniform arithmetic (every lane the same values), broadcast LDS reads.
+template <class M>
+__device__ double delta_small(Inst<M>& I) {
+    constexpr int n = M::NX, m = M::NU;
+    double zx[n], d = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) zx[i] = 0.0;
+    for (int t = 0; t < I.N; ++t) {
+        double du[m];
+#pragma unroll
+        for (int i = 0; i < m; ++i) {                                   // Δu = k + K Δx
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) acc += I.K[t * m * n + j * m + i] * zx[j];
+            du[i] = I.k[t * m + i] + acc;
+        }
+#pragma unroll
+        for (int j = 0; j < n; ++j) d += I.Lx[t * n + j] * zx[j];
+#pragma unroll
+        for (int i = 0; i < m; ++i) d += I.Lu[t * m + i] * du[i];
+        double zn[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {                                   // Δx⁺ = fu Δu + fx Δx
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < m; ++j) a1 += I.fu[t * n * m + j * n + i] * du[j];
+#pragma unroll
+            for (int j = 0; j < n; ++j) a2 += I.fx[t * n * n + j * n + i] * zx[j];
+            zn[i] = a1 + a2;
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) zx[i] = zn[i];
+    }
+    return d;
 }
 
 }  // namespace ilqr
@@ -831,7 +876,26 @@ __device__ __forceinline__ void gradients(Inst<M>& I, bool constrained) {
 template <class M>
 __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
     if constexpr (is_large<M>::value) rollout_large<M>(I, alpha, with_delta, delta_out);
-    else rollout_small<M>(I, alpha, with_delta, delta_out);
+    else {
+        ILQR_PROF_BEGIN();
+        if constexpr (waves_of<M>::value == 1) {
+            rollout_small<M>(I, alpha, with_delta, delta_out);
+            __syncthreads();
+        } else {
+            if (I.wave == 0) {
+                double unused = 0.0;
+                rollout_small<M>(I, alpha, false, unused);
+            } else if (with_delta) {
+                const double d = delta_small<M>(I);
+                if (I.lane == 0) I.zs[4] = d;
+            }
+            __syncthreads();
+            if (with_delta) delta_out = I.zs[4];
+        }
+        I.rollouts += 1;
+        I.states_eq_nominal = 0;
+        ILQR_PROF_END(I, PROF_ROLLOUT);
+    }
 }
 
 // --------------------------------------------------------- forward_pass!
@@ -992,8 +1056,9 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
         const double2* src = reinterpret_cast<const double2*>(g);
         double2* dst = reinterpret_cast<double2*>(smem);
         const int nd = slim_of<M>::value ? L.lds_doubles_slim : L.lds_doubles;
-        for (int i = I.lane; i < nd / 2; i += 64) dst[i] = src[i];
-        if (I.lane == 0) { I.zs[0] = 0.0; I.zs[1] = 0.0; }
+        for (int i = I.lane + 64 * I.wave; i < nd / 2; i += 64 * waves_of<M>::value) dst[i] = src[i];
+        __syncthreads();
+        if (I.lane == 0 && I.wave == 0) { I.zs[0] = 0.0; I.zs[1] = 0.0; }
         if constexpr (slim_of<M>::value) { I.fx = g + L.fx; I.fu = g + L.fu; }
     }
     I.objective = I.scal[S_OBJECTIVE]; I.max_violation = I.scal[S_MAX_VIOLATION];
@@ -1016,9 +1081,9 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
         double2* dst = reinterpret_cast<double2*>(g);
         const double2* src = reinterpret_cast<const double2*>(smem);
         const int nd = slim_of<M>::value ? L.lds_doubles_slim : L.lds_doubles;
-        for (int i = I.lane; i < nd / 2; i += 64) dst[i] = src[i];
+        for (int i = I.lane + 64 * I.wave; i < nd / 2; i += 64 * waves_of<M>::value) dst[i] = src[i];
     }
-    if (I.lane == 0) {
+    if (I.lane == 0 && I.wave == 0) {
         I.scal[S_OBJECTIVE] = I.objective; I.scal[S_MAX_VIOLATION] = I.max_violation;
         I.scal[S_STEP_SIZE] = I.step_size; I.scal[S_GRADIENT_NORM] = I.gradient_norm;
         I.scal[S_STATUS] = (double)I.status; I.scal[S_ITERATIONS] = (double)I.iterations;
@@ -1032,7 +1097,7 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
 
 // solve!(solver) for every instance — src/solve.jl:137-143
 template <class M>
-__global__ __launch_bounds__(64 * waves_of<M>::value) void solve_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2) void solve_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -1063,7 +1128,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_slim(KArgs a) {
 
 // single stages for parity tests (STORE_VALUE: P, p are written to HBM)
 template <class M>
-__global__ __launch_bounds__(64 * waves_of<M>::value) void stage_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2) void stage_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;

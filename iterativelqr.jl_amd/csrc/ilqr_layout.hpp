@@ -23,7 +23,7 @@ struct Layout {
     int C;   // total number of constraints over the horizon
     // offsets (in doubles) inside one instance block
     int xb, ub, x, u, fx, fu, gx, gu, K, k, Lx, Lu, c, lam, rho, act, w;   // LDS-resident set (w: parameters θ_t)
-    int zslot;                                                          // [0] always 0.0, [1] write-only trash
+    int zslot;                                                          // [0] always 0.0, [1] write-only trash, [2..7] wave-to-wave scalars
     int lds_doubles;                                                    // size of that set
     int lds_doubles_slim;                                               // ... without fx, fu (throughput variant)
     int gxx, guu, gux, P, p, scal, gzero;                               // HBM-only set (gzero: a 0.0)
@@ -61,7 +61,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.rho = o; o += pad2(L.C);
     L.act = o; o += pad2(L.C);
     L.w = o; o += pad2(T * nw);
-    L.zslot = o; o += 2;
+    L.zslot = o; o += 8;               // [2..7]: scalars handed from one wave of the instance to the other
     L.lds_doubles_slim = o;            // the throughput variant keeps the Jacobians in HBM/L2
     L.fx = o; o += pad2(N * nx * nx);
     L.fu = o; o += pad2(N * nx * nu);
