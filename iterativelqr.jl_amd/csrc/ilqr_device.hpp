@@ -131,6 +131,7 @@ struct Inst {
     const double* w;       // parameters θ_t (problem.parameters, src/data/problem.jl:25-30), T x NW
     double *gxx, *guu, *gux, *P, *p, *scal;
     double *zs;            // LDS: zs[0] == 0.0 always, zs[1] is a write-only trash slot
+    double *ring;          // LDS: Riccati hand-over ring between the two waves (small path)
     double *lds;           // large path: LDS staging area (the workspace itself stays in HBM)
     double *trace;         // per-iteration trace rows of this instance (what `verbose` prints, src/solve.jl:40-45)
     int trace_cap, trace_len;
@@ -528,9 +529,18 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
 #ifndef ILQR_BW_PTR_STORES
 #define ILQR_BW_PTR_STORES 1
 #endif
-template <class M, bool STORE_VALUE>
+// ROLE 0: the whole recursion on one wave (throughput variant). With two waves per instance the recursion is
+// split along its data flow — the value-function MATRIX chain (W, Wu, Qxx, Qux, Quu, potrf, K, ux_tmp, P) never
+// reads the VECTOR chain (Qx, Qu, k, p, ∇L), which only consumes Quu, Qux, ux_tmp and K of the same timestep:
+//   ROLE 1 (wave 0) runs the matrix chain and hands {Quu, Qux, ux_tmp} over through a small LDS ring (K goes to
+//          its LDS array anyway), RING_STEPS timesteps per chunk, one workgroup barrier per chunk;
+//   ROLE 2 (wave 1) runs the vector chain one chunk behind (double-buffered ring), redoing the tiny Cholesky of
+//          Quu so that k comes out of bit-identical arithmetic.
+// Wave 0's step loses 5 of 14 MFMAs, the k/∇L stores and both DPP row moves with their hazard nops.
+template <class M, bool STORE_VALUE, int ROLE>
 __device__ void backward_pass_mfma(Inst<M>& I) {
     constexpr int n = M::NX, m = M::NU;
+    constexpr bool MAT = ROLE != 2, VEC = ROLE != 1;     // which chain(s) this wave runs
     static_assert(n <= 4 && m <= 4, "MFMA Riccati step handles nx, nu <= 4");
     const int lane = I.lane, r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
     const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n, vmm = r < m && c < m;
@@ -558,22 +568,28 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
     double* qLu = (b0 && vm1) ? I.Lu + (N - 1) * m + r : I.zs + 1;
     double* qLx = (b0 && vn1) ? I.Lx + (N - 1) * n + r : I.zs + 1;             const int sLx = (b0 && vn1) ? n : 0;
 #endif
+    // two-wave hand-over: element (r, c) of {Quu, Qux, ux_tmp} of ring slot s at ring[s*48 + q*16 + r*4 + c]
+    double* wring = (ROLE == 1 && b0) ? I.ring + r * 4 + c : I.zs + 1;   const int swr = (ROLE == 1 && b0) ? 1 : 0;   // writer (block 0)
+    const double* rring = I.ring + r * 4 + c;                                                                      // reader (every block)
+    const double* pKr = vmn ? I.K + (N - 1) * m * n + c * m + r : I.zs;   const int sKr = vmn ? m * n : 0;      // ROLE 2 reads K back
 
-    double P = vnn ? I.gxx[N * n * n + c * n + r] : 0.0;               // P[H] .= gxx[H]  (:39)
-    double p = vn1 ? I.gx[N * n + r] : 0.0;                            // p[H] .= gx[H]   (:40)
+    double P = (MAT && vnn) ? I.gxx[N * n * n + c * n + r] : 0.0;      // P[H] .= gxx[H]  (:39)
+    double p = (VEC && vn1) ? I.gx[N * n + r] : 0.0;                   // p[H] .= gx[H]   (:40)
     if (STORE_VALUE && b0) {
-        if (vnn) I.P[N * n * n + c * n + r] = P;
-        if (vn1) I.p[N * n + r] = p;
+        if (MAT && vnn) I.P[N * n * n + c * n + r] = P;
+        if (VEC && vn1) I.p[N * n + r] = p;
     }
     double gmax = 0.0;
     // operands of step t are fetched one step ahead (accumulated Hessians from HBM/L2, the rest from
     // LDS); the time loop is unrolled by two with ping-pong operand sets so no register copies are needed
     struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
     auto fetch_first = [&](Opnd& o, int tp) {
-        o.gxx = bxx[tp * sxx]; o.guu = buu[tp * suu]; o.gux = bux[tp * sux];
+        if constexpr (MAT) { o.gxx = bxx[tp * sxx]; o.guu = buu[tp * suu]; o.gux = bux[tp * sux]; }
+        else { o.gxx = 0.0; o.guu = 0.0; o.gux = 0.0; }
         if constexpr (SL) { o.fx = pfx[tp * sfx]; o.fu = pfu[tp * sfu]; }
         else { o.fx = *pfx; o.fu = *pfu; }
-        o.gx = *pgx; o.gu = *pgu;
+        if constexpr (VEC) { o.gx = *pgx; o.gu = *pgu; }
+        else { o.gx = 0.0; o.gu = 0.0; }
     };
     auto fetch_prev = [&](Opnd& o, int tp) {     // operands of step tp = (previously fetched step) - 1
 #if ILQR_BW_PTR_LOADS
@@ -589,36 +605,13 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         o.fx = vnn ? o.fx : 0.0; o.fu = vnm ? o.fu : 0.0; o.gx = vn1 ? o.gx : 0.0; o.gu = vm1 ? o.gu : 0.0;
 #endif
     };
-    auto riccati_step = [&](const Opnd& o, int t) {
-        const double gxx = o.gxx, guu = o.guu, gux = o.gux, fx = o.fx, fu = o.fu, gx = o.gx, gu = o.gu;
-        // level 1: W = P'^T fx (= (fx^T P')^T), Wu = P'^T fu, Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49)
-        const double W = mfma444(P, fx, 0.0);
-        const double Wu = mfma444(P, fu, 0.0);
-        const double Qx = mfma444(fx, p, gx);
-        const double Qu = mfma444(fu, p, gu);
-        // level 2: Qxx = (fx^T P') fx + gxx, Qux = (fu^T P') fx + gux, Quu = (fu^T P') fu + guu   (:52-64)
-        const double Qxx = mfma444(W, fx, gxx);
-        const double Qux = mfma444(Wu, fx, gux);
-        const double Quu = mfma444(Wu, fu, guu);
-        // potrf('U') of Quu on wave-uniform scalars (upper triangle only, info ignored)   (:68-69)
-        double Uc[m * m];
-#pragma unroll
-        for (int j = 0; j < m; ++j)
-#pragma unroll
-            for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
-        // potrs('U') for K (block 0: m x n) and k (block 1, column 0) at once   (:70-75)
-        const double Qu_b1 = row_from_prev_quad(Qu);                    // block 0 -> block 1
-        double Y = (blk == 1) ? Qu_b1 : Qux;
-        int info = 0;
-        double Ur[m];                                                   // inverted diagonal of the factor
-        if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
-        else info = potrf_U<m>(Uc, Ur);
+    // potrs('U') of one right-hand-side set held as Y(r, c) (rows on lanes 16 apart), given the factor   (:70-75)
+    auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
         if (m == 1 && info == 0) {
             // 1x1: (b / sqrt(q)) / sqrt(q) == b / q up to one rounding; saves a sqrt and a division
             // (~220 clk) on the serial chain. The literal path below still runs when potrf fails.
             Y = Y / Uc[0];
         } else {
-            if (m == 1) potrf_U<m>(Uc, Ur);
 #pragma unroll
             for (int i = 0; i < m; ++i) {                               // U^T y = b
 #pragma unroll
@@ -642,55 +635,122 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
                 Y = (r == i) ? q : Y;
             }
         }
-        if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
-        Y *= -1.0;                                                      // K .*= -1, k .*= -1
-        const double K = Y;                                             // valid in block 0
-        const double k = row_from_next_quad(Y);                         // block 1 -> block 0, column 0
-        // ux_tmp = Quu K   (:79)   (Quu^T K; Quu is symmetric up to rounding)
-        const double uxt = mfma444(Quu, K, 0.0);
-        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84)
-        double Pn = mfma444(K, uxt, 0.0);
-        Pn = mfma444(K, Qux, Pn);
-        Pn = mfma444(Qux, K, Pn);
-        Pn += Qxx;
-        // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89)
-        double pn = mfma444(uxt, k, 0.0);
-        pn = mfma444(K, Qu, pn);
-        pn = mfma444(Qux, k, pn);
-        pn += Qx;
-        // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81). The padding of Lx and
-        // Qu is exactly zero, so the running ∞-norm needs no lane predicate (block 0 is picked at the end).
-        const double Lx = Qx - pn;
-        gmax = nanmax(gmax, fabs(Lx));
-        gmax = nanmax(gmax, fabs(Qu));
-        if (b0) {
-#if ILQR_BW_PTR_STORES
-            *qK = K; *qk = k; *qLu = Qu; *qLx = Lx;
-            qK -= sK; qk -= sk; qLu -= sk; qLx -= sLx;
-#else
-            if (vn1) I.Lx[t * n + r] = Lx;
-            if (vm1) { I.Lu[t * m + r] = Qu; I.k[t * m + r] = k; }
-            if (vmn) I.K[t * m * n + c * m + r] = K;
-#endif
-            if (STORE_VALUE) {
-                if (vnn) I.P[t * n * n + c * n + r] = Pn;
-                if (vn1) I.p[t * n + r] = pn;
-            }
+        return Y * -1.0;                                                // K .*= -1, k .*= -1
+    };
+    auto riccati_step = [&](const Opnd& o, int t, int slot) {
+        const double gxx = o.gxx, guu = o.guu, gux = o.gux, fx = o.fx, fu = o.fu, gx = o.gx, gu = o.gu;
+        double Qxx = 0.0, Qux, Quu, Qx = 0.0, Qu = 0.0, K, k = 0.0, uxt;
+        if constexpr (MAT) {
+            // W = P'^T fx (= (fx^T P')^T), Wu = P'^T fu; Qxx = (fx^T P') fx + gxx, Qux = (fu^T P') fx + gux,
+            // Quu = (fu^T P') fu + guu   (:52-64)
+            const double W = mfma444(P, fx, 0.0);
+            const double Wu = mfma444(P, fu, 0.0);
+            Qxx = mfma444(W, fx, gxx);
+            Qux = mfma444(Wu, fx, gux);
+            Quu = mfma444(Wu, fu, guu);
+        } else {
+            Quu = rring[slot * 48]; Qux = rring[slot * 48 + 16]; uxt = rring[slot * 48 + 32];
         }
-        P = Pn;
-        p = pn;
+        if constexpr (VEC) {
+            Qx = mfma444(fx, p, gx);                                    // Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49)
+            Qu = mfma444(fu, p, gu);
+        }
+        // potrf('U') of Quu on wave-uniform scalars (upper triangle only, info ignored)   (:68-69)
+        double Uc[m * m];
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
+        int info = 0;
+        double Ur[m];                                                   // inverted diagonal of the factor
+        if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
+        else info = potrf_U<m>(Uc, Ur);
+        if (m == 1 && info != 0) potrf_U<m>(Uc, Ur);
+        if (MAT && info != 0 && I.potrf_info == 0) I.potrf_info = info;
+        if constexpr (ROLE == 0) {
+            // K (block 0: m x n) and k (block 1, column 0) through the same solve
+            const double Qu_b1 = row_from_prev_quad(Qu);                // block 0 -> block 1
+            const double Y = solve((blk == 1) ? Qu_b1 : Qux, Uc, Ur, info);
+            K = Y;                                                      // valid in block 0
+            k = row_from_next_quad(Y);                                  // block 1 -> block 0, column 0
+        } else if constexpr (ROLE == 1) {
+            K = solve(Qux, Uc, Ur, info);
+        } else {
+            k = solve(Qu, Uc, Ur, info);
+            K = *pKr; pKr -= sKr;
+        }
+        if constexpr (MAT) {
+            uxt = mfma444(Quu, K, 0.0);                                 // ux_tmp = Quu K   (:79)   (Quu^T K; Quu is symmetric up to rounding)
+            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84)
+            double Pn = mfma444(K, uxt, 0.0);
+            Pn = mfma444(K, Qux, Pn);
+            Pn = mfma444(Qux, K, Pn);
+            Pn += Qxx;
+            if (b0) {
+#if ILQR_BW_PTR_STORES
+                *qK = K; qK -= sK;
+#else
+                if (vmn) I.K[t * m * n + c * m + r] = K;
+#endif
+                if (STORE_VALUE && vnn) I.P[t * n * n + c * n + r] = Pn;
+            }
+            if constexpr (ROLE == 1) {                                  // hand Quu, Qux, ux_tmp to the vector chain
+                wring[slot * 48 * swr] = Quu; wring[(slot * 48 + 16) * swr] = Qux; wring[(slot * 48 + 32) * swr] = uxt;
+            }
+            P = Pn;
+        }
+        if constexpr (VEC) {
+            // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89)
+            double pn = mfma444(uxt, k, 0.0);
+            pn = mfma444(K, Qu, pn);
+            pn = mfma444(Qux, k, pn);
+            pn += Qx;
+            // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81). The padding of Lx and
+            // Qu is exactly zero, so the running ∞-norm needs no lane predicate (block 0 is picked at the end).
+            const double Lx = Qx - pn;
+            gmax = nanmax(gmax, fabs(Lx));
+            gmax = nanmax(gmax, fabs(Qu));
+            if (b0) {
+#if ILQR_BW_PTR_STORES
+                *qk = k; *qLu = Qu; *qLx = Lx;
+                qk -= sk; qLu -= sk; qLx -= sLx;
+#else
+                if (vn1) I.Lx[t * n + r] = Lx;
+                if (vm1) { I.Lu[t * m + r] = Qu; I.k[t * m + r] = k; }
+#endif
+                if (STORE_VALUE && vn1) I.p[t * n + r] = pn;
+            }
+            p = pn;
+        }
     };
     Opnd A, B;
     if (N > 0) fetch_first(A, N - 1);
     int t = N - 1;
-    for (; t >= 1; t -= 2) {                                            // (:42)
-        fetch_prev(B, t - 1);
-        riccati_step(A, t);
-        if (t >= 2) fetch_prev(A, t - 2);
-        riccati_step(B, t - 1);
+    if constexpr (ROLE == 0) {
+        for (; t >= 1; t -= 2) {                                        // (:42)
+            fetch_prev(B, t - 1);
+            riccati_step(A, t, 0);
+            if (t >= 2) fetch_prev(A, t - 2);
+            riccati_step(B, t - 1, 0);
+        }
+        if (t == 0) riccati_step(A, 0, 0);
+    } else {
+        // chunks of RING_STEPS timesteps; the vector chain works one chunk behind the matrix chain
+        for (int chunk = 0; t >= 0; ++chunk) {                          // (:42)
+            if constexpr (ROLE == 2) __syncthreads();                   // chunk `chunk` of the ring is complete
+            const int base = (chunk & 1) * RING_STEPS, cnt = t + 1 < RING_STEPS ? t + 1 : RING_STEPS;
+            int i = 0;
+            for (; i + 1 < cnt; i += 2, t -= 2) {
+                fetch_prev(B, t - 1);
+                riccati_step(A, t, base + i);
+                if (t >= 2) fetch_prev(A, t - 2);
+                riccati_step(B, t - 1, base + i + 1);
+            }
+            if (i < cnt) { riccati_step(A, t, base + i); t -= 1; }      // odd tail: only ever the very last step
+            if constexpr (ROLE == 1) __syncthreads();                   // hand the chunk over (the other half-ring is free again)
+        }
     }
-    if (t == 0) riccati_step(A, 0);
-    I.gradient_norm = wave_max((b0 && c == 0) ? gmax : 0.0);
+    if constexpr (VEC) I.gradient_norm = wave_max((b0 && c == 0) ? gmax : 0.0);
 }
 
 template <class M, bool STORE_VALUE>
@@ -698,13 +758,21 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
     ILQR_PROF_BEGIN();
     if constexpr (is_large<M>::value) backward_pass_large<M, STORE_VALUE>(I);
     else {
-        // the serial recursion runs on wave 0; its scalars go to the other wave through LDS
-        if (I.wave == 0) {
-            backward_pass_mfma<M, STORE_VALUE>(I);
-            if (waves_of<M>::value > 1 && I.lane == 0) { I.zs[2] = I.gradient_norm; I.zs[3] = (double)I.potrf_info; }
+        if constexpr (waves_of<M>::value == 1) {
+            backward_pass_mfma<M, STORE_VALUE, 0>(I);
+            __syncthreads();
+        } else {
+            // matrix chain on wave 0, vector chain on wave 1 (one ring chunk behind); scalars through LDS
+            if (I.wave == 0) {
+                backward_pass_mfma<M, STORE_VALUE, 1>(I);
+                if (I.lane == 0) I.zs[3] = (double)I.potrf_info;
+            } else {
+                backward_pass_mfma<M, STORE_VALUE, 2>(I);
+                if (I.lane == 0) I.zs[2] = I.gradient_norm;
+            }
+            __syncthreads();
+            I.gradient_norm = I.zs[2]; I.potrf_info = (int)I.zs[3];
         }
-        __syncthreads();
-        if constexpr (waves_of<M>::value > 1) { I.gradient_norm = I.zs[2]; I.potrf_info = (int)I.zs[3]; }
     }
     ILQR_PROF_END(I, PROF_BACKWARD);
 }
@@ -1038,7 +1106,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.fx = smem + L.fx; I.fu = smem + L.fu; I.gx = smem + L.gx; I.gu = smem + L.gu;
     I.K = smem + L.K; I.k = smem + L.k; I.Lx = smem + L.Lx; I.Lu = smem + L.Lu;
     I.c = smem + L.c; I.lam = smem + L.lam; I.rho = smem + L.rho; I.act = smem + L.act;
-    I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w;
+    I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w; I.ring = smem + L.ring;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x & 63; I.wave = threadIdx.x >> 6;
     I.lds = smem;

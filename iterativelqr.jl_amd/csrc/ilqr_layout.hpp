@@ -18,6 +18,9 @@ enum {
     S_COUNT = 24
 };
 
+// Riccati hand-over between the two waves of a small-model instance: chunks of RING_STEPS timesteps, double-buffered
+enum { RING_STEPS = 4, RING_DOUBLES = 2 * RING_STEPS * 3 * 16 };
+
 struct Layout {
     int T, nx, nu, nw, ncs, nct;
     int C;   // total number of constraints over the horizon
@@ -26,6 +29,7 @@ struct Layout {
     int zslot;                                                          // [0] always 0.0, [1] write-only trash, [2..7] wave-to-wave scalars
     int lds_doubles;                                                    // size of that set
     int lds_doubles_slim;                                               // ... without fx, fu (throughput variant)
+    int ring;                                                           // LDS: two half-rings of RING_STEPS x {Quu, Qux, ux_tmp} (4x4 each)
     int gxx, guu, gux, P, p, scal, gzero;                               // HBM-only set (gzero: a 0.0)
     int stride;
 };
@@ -65,6 +69,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.lds_doubles_slim = o;            // the throughput variant keeps the Jacobians in HBM/L2
     L.fx = o; o += pad2(N * nx * nx);
     L.fu = o; o += pad2(N * nx * nu);
+    L.ring = o; o += RING_DOUBLES;      // Riccati hand-over ring between the two waves of an instance (small path)
     L.lds_doubles = o;
     L.gxx = o; o += pad2(T * nx * nx);
     L.guu = o; o += pad2(N * nu * nu);
