@@ -153,6 +153,36 @@ def _extract_trig(exprs):
     return exprs, defs
 
 
+def _group_reciprocals(repl):
+    """CSE nodes of the form sym = 1/base that do not depend on each other, in groups of 2..64 (coop blocks only)."""
+    defs = dict(repl)
+    memo = {}
+
+    def deps(sym):
+        if sym not in memo:
+            memo[sym] = set()
+            for f in defs[sym].free_symbols:
+                if f in defs:
+                    memo[sym] |= {f} | deps(f)
+        return memo[sym]
+
+    recs = [(s_, e.base) for s_, e in repl if isinstance(e, sp.Pow) and e.exp == -1]
+    groups, used = [], set()
+    for i, (si, bi) in enumerate(recs):
+        if si in used:
+            continue
+        g = [(si, bi)]
+        for sj, bj in recs[i + 1:]:
+            if sj in used or len(g) >= 64:
+                continue
+            if all(sj not in deps(sk) and sk not in deps(sj) for sk, _ in g):
+                g.append((sj, bj))
+        if len(g) >= 2:
+            groups.append(g)
+            used |= {sk for sk, _ in g}
+    return groups
+
+
 def _emit_block(outputs, prefix, coop=False):
     """outputs: list of (lhs_string, expr). Returns C statements: CSE temporaries, one
     fused ilqr::sincos_fast per distinct trig argument, then the outputs, in dependency order.
@@ -181,8 +211,22 @@ def _emit_block(outputs, prefix, coop=False):
     del syms
     # nodes: (defined symbols, expression, text emitter)
     nodes = []
+    recip_groups = _group_reciprocals(repl) if coop else []
+    grouped = {s for g in recip_groups for s, _ in g}
     for s, e in repl:
+        if s in grouped:
+            continue
         nodes.append(({s}, e, "const double %s = %s;" % (s, _P.doprint(e))))
+    # wave-cooperative reciprocals: mutually independent 1/x nodes are divided on different lanes by ONE division
+    # sequence (11 fp64 instructions) and handed back with v_readlane — same IEEE quotient, fewer issue slots
+    for gi, g in enumerate(recip_groups):
+        txt = ["double rb%d = %s;" % (gi, _P.doprint(g[0][1]))]
+        for qi, (_, base) in enumerate(g[1:], start=1):
+            txt.append("rb%d = (lane == %d) ? (%s) : rb%d;" % (gi, qi, _P.doprint(base), gi))
+        txt.append("const double rr%d = 1.0 / rb%d;" % (gi, gi))
+        for qi, (sym, _) in enumerate(g):
+            txt.append("const double %s = ilqr::wave_bcast<%d>(rr%d);" % (sym, qi, gi))
+        nodes.append(({sym for sym, _ in g}, sp.Tuple(*[b for _, b in g]), "\n".join(txt)))
     trig_red = list(zip(trig, red[nout:]))
     if coop:
         rounds = {}
