@@ -157,10 +157,10 @@ int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len);
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out);
 int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in);
 
-/* Kernel variant of ilqr_solve: 0 = auto (default: the latency kernel while the batch fits one wave per
- * SIMD, the throughput kernel — two waves per SIMD, Jacobians in HBM/L2 — for larger batches),
- * 1 = latency kernel, 2 = throughput kernel. Results are identical up to rounding-free reordering: both
- * run the same arithmetic. */
+/* Kernel variant of ilqr_solve: 0 = auto (default: the latency kernel — two waves per instance, all iteration
+ * state in LDS — while the batch fits the chip (one instance per SIMD), the throughput kernel — one wave per
+ * instance, two instances per SIMD, Jacobians in HBM/L2 — for larger batches), 1 = latency kernel,
+ * 2 = throughput kernel. Both run the same arithmetic up to the association of a few sums. */
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);
 
 /* Per-iteration record of what the reference prints when `verbose` (src/solve.jl:40-45): for every
