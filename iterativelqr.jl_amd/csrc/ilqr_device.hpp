@@ -1,6 +1,8 @@
 // Batched iLQR / augmented-Lagrangian solve for gfx950 (MI355X), hand-written HIP.
 //
-// Mapping: ONE WAVEFRONT (64 lanes, one workgroup) PER PROBLEM INSTANCE.
+// Mapping: ONE WORKGROUP PER PROBLEM INSTANCE — two wavefronts in the latency kernel (see waves_of<M>: the
+// second wave takes the vector chain of the Riccati recursion, the sensitivity sweep and half of the
+// linearisation), one wavefront in the throughput kernel.
 //   * the per-instance working set (trajectories, Jacobians, gradients, gains)
 //     lives in LDS for the whole solve; HBM sees one load and one store of it;
 //   * time-parallel stages (cost, linearisation) put one timestep on each lane;
