@@ -100,9 +100,9 @@ def main():
     sols = [pkg.Solver(model=model, horizon=T, batch=B, device=local_rank, options=pkg.Options(verbose=0))
             for _ in range(max(1, args.inflight))]
     sol = sols[0]
-    if len(sols) > 1:      # several batches resident at once: the two-waves-per-SIMD kernel
+    if len(sols) > 1:      # several batches in flight: which kernel fills the SIMDs freed by early finishers best
         for s_ in sols:
-            s_.set_kernel_variant_("throughput")
+            s_.set_kernel_variant_(os.environ.get("ILQR_INFLIGHT_VARIANT", "throughput"))
     torch.cuda.synchronize()
     counter = [0]
 
