@@ -521,6 +521,21 @@ __device__ __forceinline__ double row_from_prev_quad(double v) {   // lane l <- 
                  : "=&v"(olo), "=&v"(ohi) : "v"(lo), "v"(hi));
     return __hiloint2double(ohi, olo);
 }
+// gfx950 v_permlane16_swap: rows of 16 lanes exchanged pairwise in one VALU instruction (no LDS crossbar trip like
+// ds_bpermute). swap(v, v) = {[r0 r0 r2 r2], [r1 r1 r3 r3]}: the first result hands an odd row its lower neighbour
+// (lane l <- l - 16), the second hands an even row its upper neighbour (lane l <- l + 16).
+__device__ __forceinline__ double from_lane_minus16_odd_rows(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+__device__ __forceinline__ double from_lane_plus16_even_rows(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
 __device__ __forceinline__ double mfma444(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
@@ -618,7 +633,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             for (int i = 0; i < m; ++i) {                               // U^T y = b
 #pragma unroll
                 for (int l = 0; l < i; ++l) {
-                    const double yl = __shfl(Y, lane - 16 * (i - l));
+                    const double yl = (m == 2) ? from_lane_minus16_odd_rows(Y) : __shfl(Y, lane - 16 * (i - l));
                     const double v = Y - Uc[i * m + l] * yl;
                     Y = (r == i) ? v : Y;
                 }
@@ -629,7 +644,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             for (int i = m - 1; i >= 0; --i) {                          // U x = y
 #pragma unroll
                 for (int l = i + 1; l < m; ++l) {
-                    const double xl = __shfl(Y, lane + 16 * (l - i));
+                    const double xl = (m == 2) ? from_lane_plus16_even_rows(Y) : __shfl(Y, lane + 16 * (l - i));
                     const double v = Y - Uc[l * m + i] * xl;
                     Y = (r == i) ? v : Y;
                 }
