@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
     ap.add_argument("--config", default="acrobot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct-shards", action="store_true",
+                    help="rank r solves instances [r*B, (r+1)*B) of one big synthetic batch instead of the same B instances "
+                         "on every rank (weak scaling then also measures how unlucky the worst shard's slowest instance is)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
@@ -94,7 +97,10 @@ def main():
     local_rank = gpu
 
     B = args.batch
-    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=rank * B)
+    # weak scaling with IDENTICAL per-GPU work by default: a step lasts as long as the slowest instance of the batch
+    # (iteration counts are data dependent: 500 for the slowest of these 1024 instances, 381..649 for the slowest of
+    # other shards), so distinct shards would fold that data lottery into the scaling figure
+    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(rank * B if args.distinct_shards else 0))
     d_x1 = torch.from_numpy(x1).to(dev)
     d_u = torch.from_numpy(ub).to(dev)
     sols = [pkg.Solver(model=model, horizon=T, batch=B, device=local_rank, options=pkg.Options(verbose=0))
@@ -174,7 +180,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s (nx=%d, nu=%d, T=%d) AL-iLQR solve!, batch=%d per GPU, fp64, faithful reference semantics"
                                % (args.config, sol.nx, sol.nu, T, B),
-                   "global_batch": world * B, "horizon": T, "parallelism": "batch-shard x%d (no collective)" % world,
+                   "global_batch": world * B, "horizon": T, "parallelism": "batch-shard x%d (no collective), %s" % (world, "distinct shards" if args.distinct_shards else "same 1024 instances per GPU"),
                    "batches_in_flight": len(sols)},
         "solve_stats": {"inner_iterations_mean": float(st["iterations"].mean()),
                         "rollouts_mean": float(st["rollouts"].mean()),
