@@ -36,7 +36,8 @@ typedef struct ilqr_handle ilqr_handle;
 
 /* Options{T} — src/options.jl:1-15, field for field (constraint_norm is
  * carried but, as in the reference, never read). line_search: 1 = :armijo,
- * 0 = :none. verbose is accepted and ignored on the device path. */
+ * 0 = :none. verbose is ignored by the device; the host mirror prints the reference's per-iteration report from the
+ * trace (ilqr_enable_trace) when it is set. */
 typedef struct {
     int32_t line_search;
     int32_t max_iterations;

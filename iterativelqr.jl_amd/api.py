@@ -130,10 +130,15 @@ class Solver:
         each dual update exactly where the reference calls it (src/solve.jl:125), e.g. for continuation
         on the parameters."""
         _ffi.check(_ffi.lib().ilqr_set_options(self._h, C.byref(self.options)))
+        verbose = bool(self.options.verbose) and augmented_lagrangian_callback_ is None
+        if verbose and not getattr(self, "_trace_cap", 0):     # options.verbose: the per-iteration report of src/solve.jl:39-44
+            self.enable_trace_(int(self.options.max_iterations) * max(1, int(self.options.max_dual_updates)))
         if augmented_lagrangian_callback_ is None:
             _ffi.check(_ffi.lib().ilqr_solve(self._h))
-            if sync:
+            if sync or verbose:
                 self.synchronize()
+            if verbose:
+                self.print_trace()
             return
         self.run_stage_("al_begin")
         for _ in range(int(self.options.max_dual_updates)):
@@ -196,6 +201,18 @@ class Solver:
         out = np.zeros((self.B, self._trace_cap, 8))
         _ffi.check(_ffi.lib().ilqr_get_trace(self._h, _p(out)))
         return out
+
+    def print_trace(self, instance=0):
+        """What the reference prints per inner iteration when options.verbose (src/solve.jl:39-44), for one instance."""
+        rows = self.trace()[instance]
+        for outer, inner, J, g, v, a, status, _ in rows:
+            if inner == 0:
+                break
+            print("iter:                  %d\n"
+                  "             cost:                  %r\n"
+                  "\t\t\t gradient_norm:         %r\n"
+                  "\t\t\t max_violation:         %r\n"
+                  "\t\t\t step_size:             %r" % (int(inner), float(J), float(g), float(v), float(a)))
 
     def timing(self):
         ms = C.c_double(0); nl = C.c_int32(0)

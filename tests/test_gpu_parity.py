@@ -677,3 +677,19 @@ def test_time_varying_dimensions(pkg):
     assert np.isfinite(x).all() and (st["max_violation"] <= 5e-3).all(), st["max_violation"]
     assert np.abs(x[:, -1, 0] - 0.2).max() <= 5e-3 and np.abs(x[:, -1, 1] + 0.1).max() <= 5e-3
     sol.close()
+
+
+def test_verbose_prints_the_reference_report(pkg, oracle, capsys):
+    """options.verbose: the per-iteration report of src/solve.jl:39-44 (for instance 0), fed by the device trace."""
+    model, T, x1, ub = pkg.workloads.make_inputs("particle", 4)
+    sol = pkg.Solver(model=model, horizon=T, batch=4, options=pkg.Options(verbose=1))
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    out = capsys.readouterr().out
+    pr, s, _ = _oracle_solver(oracle, model, T, x1[0], ub[0]); s.solve()
+    assert out.count("iter:") == s.stats().iterations
+    assert "gradient_norm:" in out and "max_violation:" in out and "step_size:" in out
+    first_cost = float(out.split("cost:")[1].split()[0])
+    s2 = oracle.Solver(pr, oracle.default_options()); s2.enable_trace(); s2.initialize_controls(ub[0])
+    s2.initialize_states(pr.rollout(x1[0], ub[0])); s2.solve()
+    assert abs(first_cost - s2.trace()[0].objective) <= 1e-9 * max(1.0, abs(first_cost))
+    sol.close()
