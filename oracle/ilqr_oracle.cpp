@@ -57,6 +57,7 @@ struct OrcSolver {
     int outer_iterations, potrf_info, rollouts;
     double gradient_norm;
     OrcTrace* trace; int trace_cap, trace_len; int cur_outer;
+    double last_delta = 0.0;                        // ∇Lᵀ·Δz of the last forward_pass! (src/forward_pass.jl:20)
 };
 
 extern "C" void orc_default_options(OrcOptions* o) {
@@ -422,22 +423,30 @@ static int potrf_U(double* A, int m) {
     }
     return 0;
 }
-// LAPACK dpotrs('U'): solve UᵀU X = B in place, B is m×nrhs.
+// LAPACK dpotrs('U'): solve UᵀU X = B in place, B is m×nrhs. dpotrs = two dtrsm calls; OpenBLAS's trsm kernels
+// invert the diagonal once and MULTIPLY by it (tests/test_lapack_boundary.py holds this against scipy's real
+// dpotrs: bitwise for m = 1, within a few ulp of max|X| for larger m, where OpenBLAS's FMA kernels round differently).
 static void potrs_U(const double* U, int m, double* B, int nrhs) {
+    double rd[ORC_MAX_NC];
+    for (int i = 0; i < m; ++i) rd[i] = 1.0 / U[i * m + i];
     for (int c = 0; c < nrhs; ++c) {
         double* b = B + c * m;
         for (int i = 0; i < m; ++i) {           // Uᵀ y = b (forward)
             double v = b[i];
             for (int l = 0; l < i; ++l) v -= U[i * m + l] * b[l];
-            b[i] = v / U[i * m + i];
+            b[i] = v * rd[i];
         }
         for (int i = m - 1; i >= 0; --i) {      // U x = y (backward)
             double v = b[i];
             for (int l = i + 1; l < m; ++l) v -= U[l * m + i] * b[l];
-            b[i] = v / U[i * m + i];
+            b[i] = v * rd[i];
         }
     }
 }
+
+// the two LAPACK stand-ins, exported so that tests can hold them against scipy's real dpotrf / dpotrs
+extern "C" int orc_potrf_U(double* A, int m) { return potrf_U(A, m); }
+extern "C" void orc_potrs_U(const double* U, int m, double* B, int nrhs) { potrs_U(U, m, B, nrhs); }
 
 // --------------------------------------------------------- backward_pass.jl
 extern "C" void orc_backward_pass(OrcSolver* s) {
@@ -569,6 +578,7 @@ extern "C" void orc_forward_pass(OrcSolver* s) {
         trajectory_sensitivities(s);
         for (size_t i = 0; i < s->gradient.size(); ++i) delta_grad_product += s->gradient[i] * s->trajectory[i];
     }
+    s->last_delta = delta_grad_product;                 // bookkeeping for the parity tests (not in the reference)
     s->step_size = 1.0;                                 // (:26)
     int iteration = 1;
     while (s->step_size >= s->opt.min_step_size) {      // (:28)
@@ -691,6 +701,14 @@ extern "C" void orc_set_trace(OrcSolver* s, OrcTrace* buf, int capacity) {
     s->trace = buf; s->trace_cap = capacity; s->trace_len = 0;
 }
 extern "C" int orc_trace_len(const OrcSolver* s) { return s->trace_len; }
+extern "C" double orc_last_delta(const OrcSolver* s) { return s->last_delta; }
+extern "C" void orc_set_active_set(OrcSolver* s, const double* a) {
+    for (int i = 0; i < s->coff[s->T]; ++i) s->active[i] = a[i] != 0.0 ? 1 : 0;
+}
+// SolverData scalars written directly (parity tests that start a stage from a given state)
+extern "C" void orc_set_scalars(OrcSolver* s, double objective, double max_violation, double step_size, int status) {
+    s->objective = objective; s->max_violation = max_violation; s->step_size = step_size; s->status = status != 0;
+}
 
 extern "C" double* orc_buffer(OrcSolver* s, const char* name, int* len) {
 #define BUF(nm, vec) if (!std::strcmp(name, nm)) { if (len) *len = (int)(vec).size(); return (vec).data(); }

@@ -138,6 +138,13 @@ void orc_get_stats(const OrcSolver* s, OrcStats* st);
 /* trace: set capacity before solve; records one row per inner iteration */
 void orc_set_trace(OrcSolver* s, OrcTrace* buf, int capacity);
 int orc_trace_len(const OrcSolver* s);
+/* parity-test helpers: delta_grad_product of the last forward_pass! (src/forward_pass.jl:20); direct write of
+ * the SolverData scalars; the LAPACK stand-ins used by the backward pass (dpotrf('U') / dpotrs('U'), column-major) */
+double orc_last_delta(const OrcSolver* s);
+void orc_set_active_set(OrcSolver* s, const double* a /* C doubles, 0 / 1 */);
+void orc_set_scalars(OrcSolver* s, double objective, double max_violation, double step_size, int status);
+int orc_potrf_U(double* A, int m);
+void orc_potrs_U(const double* U, int m, double* B, int nrhs);
 
 /* ---- built-in model zoo (oracle/models.cpp): hand-written functions with
  * forward-mode dual-number Jacobians, following the reference's examples. */

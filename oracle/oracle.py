@@ -86,6 +86,16 @@ def lib():
         L.orc_set_trace.argtypes = [C.c_void_p, C.POINTER(OrcTrace), C.c_int]
         L.orc_trace_len.argtypes = [C.c_void_p]
         L.orc_trace_len.restype = C.c_int
+        L.orc_last_delta.argtypes = [C.c_void_p]
+        L.orc_last_delta.restype = C.c_double
+        L.orc_set_active_set.argtypes = [C.c_void_p, c_double_p]
+        L.orc_set_active_set.restype = None
+        L.orc_set_scalars.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.orc_set_scalars.restype = None
+        L.orc_potrf_U.argtypes = [c_double_p, C.c_int]
+        L.orc_potrf_U.restype = C.c_int
+        L.orc_potrs_U.argtypes = [c_double_p, C.c_int, c_double_p, C.c_int]
+        L.orc_potrs_U.restype = None
         L.orc_solve_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(OrcOptions),
                                       C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(OrcStats)]
         L.orc_solve_batch.restype = C.c_int
@@ -178,6 +188,10 @@ class Solver:
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
 
     def set_buffer(self, name, values):
+        if name == "active_set":       # Vector{Int} in the reference: its own setter (orc_buffer hands out a copy)
+            v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+            lib().orc_set_active_set(self.h, _p(v))
+            return
         n = C.c_int(0)
         p = lib().orc_buffer(self.h, name.encode(), C.byref(n))
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
