@@ -157,6 +157,15 @@ int ilqr_get_stats(ilqr_handle* h, ilqr_stats* stats);
 int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len);
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out);
 int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in);
+/* solver.policy.action_value.* — src/data/policy.jl:58-64: "Qx","Qu","Qxx","Quu","Qux" (read-only through
+ * ilqr_get_buffer). The fused solve keeps them in registers; after this call the backward-pass STAGE
+ * (ILQR_STAGE_BACKWARD_PASS, ILQR_STAGE_ILQR_SOLVE) also stores them to HBM. */
+int ilqr_enable_action_value_buffers(ilqr_handle* h);
+/* Index of a named SolverData scalar inside the "_scalars" buffer: "objective","max_violation","step_size","status",
+ * "iterations","gradient_norm","outer_iterations","potrf_info","rollouts","done" (host-stepped AL loop: instance met
+ * the constraint tolerance), "delta_grad_product" (∇Lᵀ·Δz of the last forward_pass!, src/forward_pass.jl:20),
+ * "trace_len" (rows the last solve wrote to the trace), "count" (length of "_scalars"). -1 if unknown. */
+int ilqr_scalar_slot(const char* name);
 
 /* Kernel variant of ilqr_solve: 0 = auto (default: the latency kernel — two waves per instance, all iteration
  * state in LDS — while the batch fits the chip (one instance per SIMD), the throughput kernel — one wave per

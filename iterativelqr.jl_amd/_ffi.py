@@ -59,6 +59,8 @@ SYMBOLS = {
     "ilqr_buffer_len": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]),
     "ilqr_get_buffer": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
     "ilqr_set_buffer": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
+    "ilqr_enable_action_value_buffers": (C.c_int, [C.c_void_p]),
+    "ilqr_scalar_slot": (C.c_int, [C.c_char_p]),
     "ilqr_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "ilqr_enable_trace": (C.c_int, [C.c_void_p, C.c_int32]),
     "ilqr_get_trace": (C.c_int, [C.c_void_p, c_double_p]),

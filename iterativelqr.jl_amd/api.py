@@ -32,22 +32,48 @@ def _p(a):
     return a.ctypes.data_as(_ffi.c_double_p)
 
 
+MODEL_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-mllvm", "-amdgpu-mfma-vgpr-form",   # MFMA results straight into VGPRs (no AGPR copies)
+               "-Wno-unused-parameter"]
+
+
+def _toolchain_hash():
+    """Everything besides the model source that ends up in a model module: the kernel templates it instantiates
+    (csrc/*.hpp), the C-ABI header and the compile flags. A cached module built against other headers would be
+    launched with a KArgs / Layout it misreads."""
+    import hashlib
+    h = hashlib.sha256(" ".join(MODEL_FLAGS).encode())
+    for d, pat in ((_ffi.CSRC, ".hpp"), (_ffi.INCLUDE, ".h")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(pat):
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def compile_model(name, dynamics, cost_stage, cost_term, con_stage=None, con_term=None):
-    """Symbolic model objects -> generated device code -> model module (.so), cached by source hash."""
+    """Symbolic model objects -> generated device code -> model module (.so).
+
+    Returns (registered_name, path). The registered name carries a hash of the generated source AND of the kernel
+    headers / flags, so two different problems traced under the same user name never share a registry entry or a
+    cached module, and a header change invalidates every cached module."""
+    import hashlib
     sname, src = codegen.generate_model_source(name, dynamics, cost_stage, cost_term, con_stage, con_term)
-    tag = codegen.source_hash(src)
+    tag = hashlib.sha256((src + _toolchain_hash()).encode()).hexdigest()[:16]
+    uname = "%s_%s" % (name, tag)
+    src = src.replace("struct %s {" % sname, "struct %s_%s {" % (sname, tag), 1)
+    src = src.replace('NAME = "%s";' % name, 'NAME = "%s";' % uname, 1)
     cache = os.path.join(_ffi.LIB_DIR, "models")
     os.makedirs(cache, exist_ok=True)
-    so = os.path.join(cache, "libilqr_model_%s_%s.so" % (name, tag))
+    so = os.path.join(cache, "libilqr_model_%s.so" % uname)
     if not os.path.exists(so):
-        hip = os.path.join(cache, "model_%s_%s.hip" % (name, tag))
+        hip = os.path.join(cache, "model_%s.hip" % uname)
         with open(hip, "w") as f:
-            f.write('#include "ilqr_device.hpp"\n' + src + "ILQR_DEFINE_MODEL(%s)\n" % sname)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-mllvm", "-amdgpu-mfma-vgpr-form",   # MFMA results straight into VGPRs (no AGPR copies)
-                               "-Wno-unused-parameter", "-I", _ffi.CSRC, hip, "-o", so,
+            f.write('#include "ilqr_device.hpp"\n' + src + "ILQR_DEFINE_MODEL(%s_%s)\n" % (sname, tag))
+        tmp = so + ".tmp%d" % os.getpid()
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + MODEL_FLAGS + ["-I", _ffi.CSRC, hip, "-o", tmp,
                                "-L", _ffi.LIB_DIR, "-lilqr_hip", "-Wl,-rpath," + _ffi.LIB_DIR])
-    return so
+        os.replace(tmp, so)
+    return uname, so
 
 
 class Solver:
@@ -70,9 +96,9 @@ class Solver:
             self.num_user_parameter = low["num_user_parameter"]
             self.constraint_rows = low["constraint_rows"]
             self.state_dims, self.action_dims = low["state_dims"], low["action_dims"]
-            model_library = compile_model(name, low["dynamics"], low["cost_stage"], low["cost_term"],
-                                          low["con_stage"], low["con_term"])
-            model, horizon = name, T
+            model, model_library = compile_model(name, low["dynamics"], low["cost_stage"], low["cost_term"],
+                                                 low["con_stage"], low["con_term"])
+            horizon = T
             constrained = constraints is not None
         else:
             constrained = True if constraints is None else bool(constraints)
@@ -143,7 +169,7 @@ class Solver:
         self.run_stage_("al_begin")
         for _ in range(int(self.options.max_dual_updates)):
             self.run_stage_("al_outer")
-            if bool((self.buffer("_scalars")[:, 15] != 0.0).all()):     # every instance met the tolerance
+            if bool((self.buffer("_scalars")[:, _ffi.lib().ilqr_scalar_slot(b"done")] != 0.0).all()):   # every instance met the tolerance
                 break
             augmented_lagrangian_callback_(self)
 
@@ -170,6 +196,17 @@ class Solver:
         st = (_ffi.Stats * self.B)()
         _ffi.check(_ffi.lib().ilqr_get_stats(self._h, st))
         return {f: np.array([getattr(s, f) for s in st]) for f, _ in _ffi.Stats._fields_ if f != "reserved"}
+
+    def enable_action_value_buffers_(self):
+        """Have the backward-pass stage also store policy.action_value.* (Qx, Qu, Qxx, Quu, Qux) to HBM."""
+        _ffi.check(_ffi.lib().ilqr_enable_action_value_buffers(self._h))
+
+    def scalar(self, name):
+        """One named SolverData scalar per instance (see ilqr_scalar_slot), e.g. "delta_grad_product"."""
+        i = _ffi.lib().ilqr_scalar_slot(name.encode())
+        if i < 0:
+            raise KeyError(name)
+        return self.buffer("_scalars")[:, i]
 
     def buffer(self, name):
         n = C.c_size_t(0)
@@ -204,10 +241,8 @@ class Solver:
 
     def print_trace(self, instance=0):
         """What the reference prints per inner iteration when options.verbose (src/solve.jl:39-44), for one instance."""
-        rows = self.trace()[instance]
+        rows = self.trace()[instance][:int(self.scalar("trace_len")[instance])]
         for outer, inner, J, g, v, a, status, _ in rows:
-            if inner == 0:
-                break
             print("iter:                  %d\n"
                   "             cost:                  %r\n"
                   "\t\t\t gradient_norm:         %r\n"

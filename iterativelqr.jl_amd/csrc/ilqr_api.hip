@@ -76,7 +76,14 @@ struct ilqr_handle {
     int trace_cap;
     int variant;          // 0 auto, 1 latency kernel (1 wave/SIMD, all-LDS), 2 throughput kernel (slim)
     int num_simds;
+    double* qv;           // optional action-value buffers Qx, Qu, Qxx, Quu, Qux (allocated on first use by a getter)
+    ilqr::QLayout QL;
+    // lazy part of ilqr_reset for large (HBM-resident) models: the megabyte-sized per-instance arrays are zeroed only
+    // when something could observe them before the solve kernel rewrites them
+    bool jh_dirty;        // fx, fu, gxx, guu, gux hold pre-reset values (ilqr_solve zeroes / overwrites them itself)
+    bool P_dirty;         // P, p hold pre-reset values (only the backward-pass STAGE kernel writes them)
     std::vector<BufferDesc> buffers;
+    std::vector<BufferDesc> qbuffers;
 };
 
 namespace {
@@ -86,6 +93,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.ws = h->ws; a.L = h->L; a.B = h->B; a.constrained = h->constrained; a.stage = 0; a.opt = h->opt;
     a.x1 = nullptr; a.u_in = nullptr;
     a.trace = h->trace; a.trace_cap = h->trace_cap;
+    a.qv = h->qv; a.QL = h->QL;
     return a;
 }
 
@@ -106,6 +114,32 @@ void fill_buffers(ilqr_handle* h) {
         {"parameters", L.w, T * L.nw},
         {"_scalars", L.scal, ilqr::S_COUNT},
     };
+    const ilqr::QLayout& Q = h->QL;
+    h->qbuffers = {
+        {"Qx", Q.Qx, N * n}, {"Qu", Q.Qu, N * m}, {"Qxx", Q.Qxx, N * n * n}, {"Quu", Q.Quu, N * m * m}, {"Qux", Q.Qux, N * m * n},
+    };
+}
+
+const BufferDesc* find_qbuffer(const ilqr_handle* h, const char* name) {
+    for (auto& b : h->qbuffers)
+        if (!std::strcmp(b.name, name)) return &b;
+    return nullptr;
+}
+
+// the deferred part of ilqr_reset (see ilqr_handle::jh_dirty / P_dirty)
+int settle_reset(ilqr_handle* h) {
+    if (!h->jh_dirty && !h->P_dirty) return ILQR_OK;
+    const ilqr::Layout& L = h->L;
+    const size_t pitch = (size_t)L.stride * 8;
+    if (h->jh_dirty) {
+        HIP_TRY(hipMemset2DAsync((char*)h->ws + (size_t)L.fx * 8, pitch, 0, (size_t)(L.P - L.fx) * 8, (size_t)h->B, h->stream));
+        h->jh_dirty = false;                 // (S_JAC_CONST was cleared with the scalars by ilqr_reset)
+    }
+    if (h->P_dirty) {
+        HIP_TRY(hipMemset2DAsync((char*)h->ws + (size_t)L.P * 8, pitch, 0, (size_t)(L.scal - L.P) * 8, (size_t)h->B, h->stream));
+        h->P_dirty = false;
+    }
+    return ILQR_OK;
 }
 
 const BufferDesc* find_buffer(const ilqr_handle* h, const char* name) {
@@ -117,6 +151,7 @@ const BufferDesc* find_buffer(const ilqr_handle* h, const char* name) {
 int copy_out(ilqr_handle* h, const BufferDesc* bd, double* out) {
     if (bd->len == 0) return ILQR_OK;
     HIP_TRY(hipSetDevice(h->device));
+    if (bd->offset >= h->L.fx && bd->offset < h->L.scal) { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy2D(out, (size_t)bd->len * 8, h->ws + bd->offset, (size_t)h->L.stride * 8,
                         (size_t)bd->len * 8, (size_t)h->B, hipMemcpyDeviceToHost));
@@ -126,6 +161,7 @@ int copy_out(ilqr_handle* h, const BufferDesc* bd, double* out) {
 int copy_in(ilqr_handle* h, const BufferDesc* bd, const double* in) {
     if (bd->len == 0) return ILQR_OK;
     HIP_TRY(hipSetDevice(h->device));
+    if (bd->offset >= h->L.fx && bd->offset < h->L.scal) { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy2D(h->ws + bd->offset, (size_t)h->L.stride * 8, in, (size_t)bd->len * 8,
                         (size_t)bd->len * 8, (size_t)h->B, hipMemcpyHostToDevice));
@@ -159,7 +195,11 @@ int ilqr_default_options(ilqr_options* o) {
 }
 
 int ilqr_register_model(const ilqr_model_vtable* vt) {
-    if (!vt || !vt->name) return ILQR_ERR_INVALID;
+    if (!vt) return ILQR_ERR_INVALID;
+    // a module built against other headers would be handed a KArgs / Layout it misreads: refuse it
+    if (vt->abi_version != ILQR_MODEL_ABI_VERSION || vt->kargs_bytes != (int)sizeof(ilqr::KArgs))
+        return fail(ILQR_ERR_MODEL, "model module was built against a different library version (ABI mismatch): rebuild it");
+    if (!vt->name) return ILQR_ERR_INVALID;
     auto& r = registry();
     for (auto& e : r)
         if (!std::strcmp(e->name, vt->name)) { e = vt; return ILQR_OK; }
@@ -191,6 +231,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
     h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024;
+    h->qv = nullptr; h->QL = ilqr::make_qlayout(vt->nx, vt->nu, d->horizon); h->jh_dirty = false; h->P_dirty = false;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
     if (h->lds_bytes > 160 * 1024) {
@@ -229,6 +270,7 @@ int ilqr_destroy(ilqr_handle* h) {
     if (h->d_x1) hipFree(h->d_x1);
     if (h->d_u) hipFree(h->d_u);
     if (h->trace) hipFree(h->trace);
+    if (h->qv) hipFree(h->qv);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return ILQR_OK;
@@ -256,7 +298,15 @@ int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw, i
 int ilqr_reset(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->vt->nw == 0) {
+    if (ilqr::is_large_model(h->vt->nx, h->vt->nu) && h->vt->nw == 0) {
+        // HBM-resident models: zero the trajectories, gradients, gains, duals and scalars now; the megabyte-sized
+        // Jacobian / Hessian / value arrays are zeroed by the solve kernel itself (src/solve.jl:9-10) or, when
+        // a getter, setter or stage call could observe them first, by settle_reset()
+        const size_t pitch = (size_t)h->L.stride * 8;
+        HIP_TRY(hipMemset2DAsync(h->ws, pitch, 0, (size_t)h->L.fx * 8, (size_t)h->B, h->stream));
+        HIP_TRY(hipMemset2DAsync((char*)h->ws + (size_t)h->L.scal * 8, pitch, 0, pitch - (size_t)h->L.scal * 8, (size_t)h->B, h->stream));
+        h->jh_dirty = true; h->P_dirty = true;
+    } else if (h->vt->nw == 0) {
         HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
     } else {
         // keep the parameters θ (they belong to the problem, not to the solver state)
@@ -312,18 +362,22 @@ int ilqr_solve(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     ilqr::KArgs a = make_args(h);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, h->stream));
+    a.qv = nullptr;
+    if (h->trace)      // rows of an earlier, longer solve must not survive
+        HIP_TRY(hipMemsetAsync(h->trace, 0, (size_t)h->B * h->trace_cap * ilqr::TRACE_W * 8, h->stream));
+    h->jh_dirty = false;   // the kernel rewrites the Jacobians and zeroes the Hessians itself (src/solve.jl:9-16)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto drop = [&](int rc) { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); return rc; };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, h->stream) != hipSuccess)
+        return drop(fail(ILQR_ERR_HIP, "hipEventCreate/Record failed"));
     // batches that do not fit one wave per SIMD take the throughput kernel (two waves per SIMD)
     const bool slim = h->vt->launch_solve_slim != nullptr &&
                       (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
     if (slim) {
         if (h->vt->launch_solve_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
-            return fail(ILQR_ERR_HIP, "solve (throughput variant) launch failed");
-    } else if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "solve launch failed");
-    HIP_TRY(hipEventRecord(e1, h->stream));
+            return drop(fail(ILQR_ERR_HIP, "solve (throughput variant) launch failed"));
+    } else if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve launch failed"));
+    if (hipEventRecord(e1, h->stream) != hipSuccess) return drop(fail(ILQR_ERR_HIP, "hipEventRecord failed"));
     h->timing.emplace_back(e0, e1);
     if (h->timing.size() > 4096) {     // long-running callers that never read the timing: keep the newest half
         for (size_t i = 0; i < 2048; ++i) { hipEventDestroy(h->timing[i].first); hipEventDestroy(h->timing[i].second); }
@@ -335,9 +389,15 @@ int ilqr_solve(ilqr_handle* h) {
 int ilqr_run_stage(ilqr_handle* h, int32_t stage) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
     ilqr::KArgs a = make_args(h);
     a.stage = stage;
-    if (h->vt->launch_stage(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "stage launch failed");
+    if (stage != ILQR_STAGE_BACKWARD_PASS && stage != ILQR_STAGE_ILQR_SOLVE) a.qv = nullptr;
+    // the stage runs in the mapping selected by ilqr_set_kernel_variant (2 = throughput: one wave per instance)
+    if (h->variant == 2 && h->vt->launch_stage_slim != nullptr) {
+        if (h->vt->launch_stage_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
+            return fail(ILQR_ERR_HIP, "stage (throughput variant) launch failed");
+    } else if (h->vt->launch_stage(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "stage launch failed");
     HIP_TRY(hipStreamSynchronize(h->stream));
     return ILQR_OK;
 }
@@ -384,12 +444,46 @@ int ilqr_get_stats(ilqr_handle* h, ilqr_stats* st) {
 int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len) {
     if (!h || !name || !len) return fail(ILQR_ERR_INVALID, "null argument");
     const BufferDesc* bd = find_buffer(h, name);
+    if (!bd) bd = find_qbuffer(h, name);
     if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
     *len = (size_t)bd->len;
     return ILQR_OK;
 }
+int ilqr_enable_action_value_buffers(ilqr_handle* h) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (h->qv) return ILQR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->B * (size_t)h->QL.stride * 8;
+    HIP_TRY(hipMalloc((void**)&h->qv, bytes));
+    HIP_TRY(hipMemsetAsync(h->qv, 0, bytes, h->stream));
+    return ILQR_OK;
+}
+
+int ilqr_scalar_slot(const char* name) {
+    static const struct { const char* n; int i; } slots[] = {
+        {"objective", ilqr::S_OBJECTIVE}, {"max_violation", ilqr::S_MAX_VIOLATION}, {"step_size", ilqr::S_STEP_SIZE},
+        {"status", ilqr::S_STATUS}, {"iterations", ilqr::S_ITERATIONS}, {"gradient_norm", ilqr::S_GRADIENT_NORM},
+        {"outer_iterations", ilqr::S_OUTER_ITERATIONS}, {"potrf_info", ilqr::S_POTRF_INFO}, {"rollouts", ilqr::S_ROLLOUTS},
+        {"states_eq_nominal", ilqr::S_STATES_EQ_NOMINAL}, {"profile", ilqr::S_PROF}, {"done", ilqr::S_DONE},
+        {"delta_grad_product", ilqr::S_DELTA}, {"trace_len", ilqr::S_TRACE_LEN}, {"count", ilqr::S_COUNT},
+    };
+    if (!name) return -1;
+    for (auto& s_ : slots)
+        if (!std::strcmp(s_.n, name)) return s_.i;
+    return -1;
+}
+
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out) {
     if (!h || !name || !out) return fail(ILQR_ERR_INVALID, "null argument");
+    if (const BufferDesc* qd = find_qbuffer(h, name)) {
+        if (!h->qv) return fail(ILQR_ERR_INVALID, "action-value buffers are off: call ilqr_enable_action_value_buffers first");
+        if (qd->len == 0) return ILQR_OK;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy2D(out, (size_t)qd->len * 8, h->qv + qd->offset, (size_t)h->QL.stride * 8,
+                            (size_t)qd->len * 8, (size_t)h->B, hipMemcpyDeviceToHost));
+        return ILQR_OK;
+    }
     const BufferDesc* bd = find_buffer(h, name);
     if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
     return copy_out(h, bd, out);

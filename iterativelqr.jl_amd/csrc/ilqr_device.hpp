@@ -46,6 +46,8 @@ struct KArgs {
     const double* u_in;
     double* trace;       // optional per-iteration trace [B][trace_cap][TRACE_W] (null = off)
     int trace_cap;
+    double* qv;          // optional action-value buffers [B][QL.stride] (backward-pass stage kernel only; null = off)
+    QLayout QL;
 };
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
@@ -137,6 +139,9 @@ struct Inst {
     double *lds;           // large path: LDS staging area (the workspace itself stays in HBM)
     double *trace;         // per-iteration trace rows of this instance (what `verbose` prints, src/solve.jl:40-45)
     int trace_cap, trace_len;
+    double *Q;             // HBM: this instance's block of the optional Qx, Qu, Qxx, Quu, Qux buffers (null = not stored)
+    QLayout QL;
+    double delta;          // delta_grad_product of the last forward_pass! (src/forward_pass.jl:20)
     const double* gzero;   // HBM: a 0.0
     int T, N, C, lane, wave;
     double objective, max_violation, step_size, gradient_norm;
@@ -710,6 +715,11 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
                 if (vmn) I.K[t * m * n + c * m + r] = K;
 #endif
                 if (STORE_VALUE && vnn) I.P[t * n * n + c * n + r] = Pn;
+                if (STORE_VALUE && I.Q != nullptr) {                    // policy.action_value.* (src/data/policy.jl:58-64)
+                    if (vnn) I.Q[I.QL.Qxx + t * n * n + c * n + r] = Qxx;
+                    if (vmn) I.Q[I.QL.Qux + t * m * n + c * m + r] = Qux;
+                    if (vmm) I.Q[I.QL.Quu + t * m * m + c * m + r] = Quu;
+                }
             }
             if constexpr (ROLE == 1) {                                  // hand Quu, Qux, ux_tmp to the vector chain
                 wring[slot * 48 * swr] = Quu; wring[(slot * 48 + 16) * swr] = Qux; wring[(slot * 48 + 32) * swr] = uxt;
@@ -736,6 +746,10 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
                 if (vm1) { I.Lu[t * m + r] = Qu; I.k[t * m + r] = k; }
 #endif
                 if (STORE_VALUE && vn1) I.p[t * n + r] = pn;
+                if (STORE_VALUE && I.Q != nullptr) {
+                    if (vn1) I.Q[I.QL.Qx + t * n + r] = Qx;
+                    if (vm1) I.Q[I.QL.Qu + t * m + r] = Qu;
+                }
             }
             p = pn;
         }
@@ -996,6 +1010,7 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     // trajectory_sensitivities (src/data/methods.jl:42-54) fused with the product
     // gradientᵀ·Δz (:20): on the MFMA path it rides along the first rollout below.
     double delta = 0.0;
+    I.delta = 0.0;
     I.step_size = 1.0;                                                // (:26)
     int iteration = 1;
     while (I.step_size >= opt.min_step_size) {                        // (:28)
@@ -1003,7 +1018,7 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
         const bool want_delta = MF && iteration == 1 && opt.line_search == 1;
         double d = 0.0;
         rollout_bang<M>(I, I.step_size, want_delta, d);               // (:34)
-        if (want_delta) delta = d;
+        if (want_delta) { delta = d; I.delta = d; }
         cost_bang<M>(I, true, constrained);                           // (:36)
         const double J = I.objective;
         if (J <= J_prev + c1 * I.step_size * delta) {                 // (:44) NaN ⇒ reject
@@ -1129,6 +1144,8 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.lds = smem;
     I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;
+    I.Q = a.qv ? a.qv + (size_t)b * (size_t)a.QL.stride : nullptr; I.QL = a.QL;
+    I.delta = I.scal[S_DELTA];
     if constexpr (is_large<M>::value) {
         // large path: every buffer stays in the HBM workspace, LDS is staging only
         I.xb = g + L.xb; I.ub = g + L.ub; I.x = g + L.x; I.u = g + L.u;
@@ -1174,6 +1191,7 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
         I.scal[S_STATUS] = (double)I.status; I.scal[S_ITERATIONS] = (double)I.iterations;
         I.scal[S_OUTER_ITERATIONS] = (double)I.outer_iterations; I.scal[S_POTRF_INFO] = (double)I.potrf_info;
         I.scal[S_ROLLOUTS] = (double)I.rollouts; I.scal[S_STATES_EQ_NOMINAL] = (double)I.states_eq_nominal;
+        I.scal[S_DELTA] = I.delta;
 #ifdef ILQR_PROFILE
         for (int i = 0; i < PROF_N; ++i) I.scal[S_PROF + i] = I.prof[i];
 #endif
@@ -1194,6 +1212,7 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2
         solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0);
         ILQR_PROF_END(I, PROF_OTHER);   // total; phases are subtracted on the host
     }
+    if (I.lane == 0 && I.wave == 0) I.scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
     inst_writeback<M>(I, a, smem, b);
 }
 
@@ -1208,10 +1227,12 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_slim(KArgs a) {
     inst_setup<MS>(I, a, smem, b);
     I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0;
     solve_loops<MS, false>(I, a.opt, a.constrained != 0, a.constrained != 0);
+    if (I.lane == 0) I.scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
     inst_writeback<MS>(I, a, smem, b);
 }
 
-// single stages for parity tests (STORE_VALUE: P, p are written to HBM)
+// single stages for parity tests (STORE_VALUE: P, p and, when enabled, Qx..Qux are written to HBM); instantiated for
+// the latency mapping (M) and, for small models, the throughput mapping (Slim<M>)
 template <class M>
 __global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2) void stage_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1237,7 +1258,7 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2
             for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
             for (int i = I.lane; i < I.N * M::NU; i += 64) I.Lu[i] = 0.0;
             for (int i = I.lane; i < I.C; i += 64) { I.lam[i] = 0.0; I.rho[i] = a.opt.initial_constraint_penalty; }
-            if (I.lane == 0) I.scal[S_DONE] = 0.0;
+            if (I.lane == 0 && I.wave == 0) I.scal[S_DONE] = 0.0;
             __syncthreads();
         } break;
         case ILQR_STAGE_AL_OUTER: {      // one pass of the loop body src/solve.jl:105-122 (callback runs on the host)
@@ -1245,7 +1266,7 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2
             solve_loops<M, false>(I, a.opt, true, false);             // ilqr_solve!            (:109)
             cost_bang<M>(I, false, true);                             // cost!(mode = :nominal) (:113)
             if (I.max_violation <= a.opt.constraint_tolerance) {      // (:117)
-                if (I.lane == 0) I.scal[S_DONE] = 1.0;
+                if (I.lane == 0 && I.wave == 0) I.scal[S_DONE] = 1.0;
             } else {
                 al_update<M>(I, a.opt);                               // (:120-122)
             }
@@ -1286,7 +1307,10 @@ __global__ __launch_bounds__(64) void init_rollout_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
+#define ILQR_MODEL_ABI_VERSION 2   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
+    int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
+    int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against
     const char* name;
     int nx, nu, nw, ncs, nct;
     unsigned long long ineq_s, ineq_t;
@@ -1294,6 +1318,7 @@ extern "C" struct ilqr_model_vtable {
     int (*launch_stage)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);
     int (*launch_init)(const ilqr::KArgs* a, void* stream);
     int (*launch_solve_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
+    int (*launch_stage_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
 };
 
 namespace ilqr {
@@ -1326,14 +1351,27 @@ struct ModelModule {
             return -1;
         }
     }
+    static int launch_stage_slim(const KArgs* a, size_t lds, void* stream) {
+        if constexpr (!is_large<M>::value) {
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<Slim<M>>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+            hipLaunchKernelGGL(stage_kernel<Slim<M>>, dim3(a->B), dim3(64), lds, (hipStream_t)stream, *a);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        } else {
+            return -1;
+        }
+    }
     static int launch_init(const KArgs* a, void* stream) {
         hipLaunchKernelGGL(init_rollout_kernel<M>, dim3((a->B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     static const ilqr_model_vtable* vtable() {
-        static const ilqr_model_vtable vt = {M::NAME, M::NX, M::NU, M::NW, M::NCS, M::NCT, M::INEQ_S, M::INEQ_T,
+        static const ilqr_model_vtable vt = {ILQR_MODEL_ABI_VERSION, (int)sizeof(KArgs),
+                                             M::NAME, M::NX, M::NU, M::NW, M::NCS, M::NCT, M::INEQ_S, M::INEQ_T,
                                              &launch_solve, &launch_stage, &launch_init,
-                                             is_large<M>::value ? nullptr : &launch_solve_slim};
+                                             is_large<M>::value ? nullptr : &launch_solve_slim,
+                                             is_large<M>::value ? nullptr : &launch_stage_slim};
         return &vt;
     }
 };

@@ -239,7 +239,7 @@ __device__ __forceinline__ void gradients_large(Inst<M>& I, bool constrained) {
 // (odd leading dimensions, transposition = stride pattern, no bounds checks), then the MFMAs issue back to back;
 // Qxx never leaves wave 1's accumulators; the cost Hessians are prefetched in the D-layout of the tiles they are
 // added to, by the wave that owns those tiles.
-struct RiccatiArgs { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int N; };
+struct RiccatiArgs { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int N; gdbl* Q; QLayout QL; };
 struct RiccatiOut { double gradient_norm; int potrf_info; double prof[6]; };
 
 template <class M, bool STORE_VALUE>
@@ -258,6 +258,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
     I.k = uniform_ptr(A.k); I.Lx = uniform_ptr(A.Lx); I.Lu = uniform_ptr(A.Lu); I.P = uniform_ptr(A.P); I.p = uniform_ptr(A.p);
     I.potrf_info = 0;
     for (int q = 0; q < 6; ++q) I.prof[q] = 0.0;
+    gdbl* const Qv = STORE_VALUE ? A.Q : nullptr;           // optional action-value buffers (stage kernel only)
+    const QLayout QL = A.QL;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = __builtin_amdgcn_readfirstlane(A.N), li = lane & 15, lk = lane >> 4;
     const bool w0 = wave == 0;
@@ -407,6 +409,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
                     }
             }
             wave_lds_fence();                                             // this wave's own Quu, Qux writes
+            if (STORE_VALUE && Qv != nullptr) {                           // policy.action_value.* (src/data/policy.jl:58-64)
+                for (int e = lane; e < m * n; e += 64) Qv[QL.Qux + (size_t)t * m * n + e] = sQux[(e / m) * ldm + e % m];
+                for (int e = lane; e < m * m; e += 64) Qv[QL.Quu + (size_t)t * m * m + e] = sQuu[(e / m) * ldm + e % m];
+                if (lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
+            }
             ILQR_SUB_MARK(I, 2);
             // potrf('U') on wave-uniform registers (info ignored, :68-69)
             double Uc[m * m], Ur[m];
@@ -440,6 +447,18 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
             tiles_mac<TN, TN, n4, 1, ld, 1, ld>(qxx, Aop, Arow, sFx, li, lk);
 #pragma unroll
             for (int q = 0; q < TN * TN; ++q) qxx[q] = qxx[q] + rgxx[q];
+            if (STORE_VALUE && Qv != nullptr) {
+                if (lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int c = 0; c < TN; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
+                            if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = qxx[a * TN + c][r];
+                        }
+            }
             fetch_late(t > 0 ? t - 1 : 0);
         }
         __syncthreads();                                                  // (3) K, k in LDS; T no longer needed
@@ -526,7 +545,7 @@ template <class M, bool STORE_VALUE>
 __device__ __forceinline__ void backward_pass_large(Inst<M>& I) {
     RiccatiArgs A{as_global(I.fx), as_global(I.fu), as_global(I.gx), as_global(I.gu), as_global(I.gxx), as_global(I.guu),
                   as_global(I.gux), as_global(I.K), as_global(I.k), as_global(I.Lx), as_global(I.Lu), as_global(I.P),
-                  as_global(I.p), I.N};
+                  as_global(I.p), I.N, as_global(I.Q), I.QL};
     const RiccatiOut o = backward_pass_large_fn<M, STORE_VALUE>(A);
     I.gradient_norm = o.gradient_norm;
     if (o.potrf_info != 0 && I.potrf_info == 0) I.potrf_info = o.potrf_info;

@@ -12,9 +12,12 @@ namespace ilqr {
 // scalar slots (stored as doubles) at Layout::scal
 enum {
     S_OBJECTIVE = 0, S_MAX_VIOLATION, S_STEP_SIZE, S_STATUS, S_ITERATIONS, S_GRADIENT_NORM,
-    S_OUTER_ITERATIONS, S_POTRF_INFO, S_ROLLOUTS, S_STATES_EQ_NOMINAL, S_PROF = 10,
-    S_DONE = 15,  // host-stepped AL loop only: instance finished (shares the last profiling slot)
+    S_OUTER_ITERATIONS, S_POTRF_INFO, S_ROLLOUTS, S_STATES_EQ_NOMINAL,
+    S_PROF = 10,        // ..15: per-phase cycle counters of an ILQR_PROFILE build
     S_JAC_CONST = 16,   // large path: the constant entries of this instance's fx/fu buffers are in place
+    S_DONE = 17,        // host-stepped AL loop only: instance finished
+    S_DELTA = 18,       // delta_grad_product = ∇Lᵀ·Δz of the last forward_pass! (src/forward_pass.jl:20)
+    S_TRACE_LEN = 19,   // rows of the per-iteration trace written by the last solve
     S_COUNT = 24
 };
 
@@ -35,6 +38,22 @@ struct Layout {
 };
 
 inline __host__ __device__ int pad2(int v) { return (v + 1) & ~1; }   // keep 16-B alignment
+
+// Optional action-value buffers Qx, Qu, Qxx, Quu, Qux (src/data/policy.jl:58-64), written by the backward-pass STAGE
+// kernel only (parity tests; the fused solve keeps them in registers). One block of `stride` doubles per instance.
+struct QLayout { int Qx, Qu, Qxx, Quu, Qux, stride; };
+inline __host__ __device__ QLayout make_qlayout(int nx, int nu, int T) {
+    QLayout q;
+    const int N = T - 1;
+    int o = 0;
+    q.Qx = o; o += pad2(N * nx);
+    q.Qu = o; o += pad2(N * nu);
+    q.Qxx = o; o += pad2(N * nx * nx);
+    q.Quu = o; o += pad2(N * nu * nu);
+    q.Qux = o; o += pad2(N * nu * nx);
+    q.stride = (o + 15) & ~15;
+    return q;
+}
 
 // models with nx > 4 or nu > 4 take the HBM-resident large path (ilqr_device_large.hpp)
 inline __host__ __device__ bool is_large_model(int nx, int nu) { return nx > 4 || nu > 4; }

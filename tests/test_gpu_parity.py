@@ -1,7 +1,8 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
 
 Tolerances (fp64): stage level 1e-11 relative (rounding only: FMA contraction,
-device libm, reduction order); whole solve |Δx|,|Δu| ≤ 1e-6, |ΔK| ≤ 1e-5·max|K|
+device libm, reduction order); whole solve |Δx|,|Δu| ≤ 1e-7, |ΔK| ≤ 5e-7·max|K| (10x the observed
+1.1e-8 / 2.4e-8, profiles/r01_final_parity.txt), control flow identical on ≥ 99 % of instances (observed 100 %)
 for instances whose control flow (iteration counts) matches the oracle's.
 """
 import os
@@ -144,8 +145,8 @@ def _whole_solve(pkg, oracle, config, B, min_match):
     dx = np.abs(x - ref["x"]).reshape(B, -1).max(1); du = np.abs(u - ref["u"]).reshape(B, -1).max(1)
     Kmax = np.abs(ref["K"]).reshape(B, -1).max(1)
     dK = np.abs(K - ref["K"]).reshape(B, -1).max(1) / np.maximum(Kmax, 1.0)
-    assert dx[same_f].max() <= 1e-6 and du[same_f].max() <= 1e-6, (dx[same_f].max(), du[same_f].max())
-    assert dK[same_f].max() <= 1e-5, dK[same_f].max()
+    assert dx[same_f].max() <= 1e-7 and du[same_f].max() <= 1e-7, (dx[same_f].max(), du[same_f].max())
+    assert dK[same_f].max() <= 5e-7, dK[same_f].max()
     assert np.allclose(st["objective"][same_f], rs["objective"][same_f], rtol=1e-8)
     assert np.allclose(st["max_violation"][same_f], rs["max_violation"][same_f], rtol=1e-6, atol=1e-10)
     assert (st["potrf_info"] == rs["potrf_info"])[same].all()
@@ -157,22 +158,22 @@ def _whole_solve(pkg, oracle, config, B, min_match):
 
 
 def test_particle_whole_solve(pkg, oracle):
-    _whole_solve(pkg, oracle, "particle", 64, 0.95)
+    _whole_solve(pkg, oracle, "particle", 64, 0.99)
 
 
 def test_acrobot_whole_solve_t51(pkg, oracle):
-    r = _whole_solve(pkg, oracle, "acrobot51", 64, 0.9)
+    r = _whole_solve(pkg, oracle, "acrobot51", 64, 0.99)
     assert (np.abs(r["x"][:, -1, :] - [np.pi, 0, 0, 0]).max(1) < 5e-3).all()      # test/acrobot.jl:114
 
 
 def test_acrobot_whole_solve_headline(pkg, oracle):
     """BASELINE configs[1]: acrobot T=101, batch=1024."""
-    r = _whole_solve(pkg, oracle, "acrobot", 1024, 0.9)
+    r = _whole_solve(pkg, oracle, "acrobot", 1024, 0.99)
     assert (np.abs(r["x"][:, -1, :] - [np.pi, 0, 0, 0]).max(1) < 5e-3).mean() > 0.99
 
 
 def test_car_whole_solve(pkg, oracle):
-    r = _whole_solve(pkg, oracle, "car", 256, 0.9)
+    r = _whole_solve(pkg, oracle, "car", 256, 0.99)
     x, u = r["x"], r["u"]
     # test/car.jl:74-79 on instance 0 (the reference's deterministic initialisation)
     e = x[0, :-1, :2] - 0.5
@@ -183,7 +184,7 @@ def test_car_whole_solve(pkg, oracle):
 
 
 def test_car_goal_whole_solve(pkg, oracle):
-    _whole_solve(pkg, oracle, "car_goal", 256, 0.9)
+    _whole_solve(pkg, oracle, "car_goal", 256, 0.99)
 
 
 def test_resolve_is_deterministic(pkg):
@@ -201,7 +202,7 @@ def test_resolve_is_deterministic(pkg):
 
 def test_car_full_config_batch_4096(pkg, oracle):
     """BASELINE configs[2]: car T=51 with the full constraint set, batch=4096 on one GPU."""
-    r = _whole_solve(pkg, oracle, "car", 4096, 0.9)
+    r = _whole_solve(pkg, oracle, "car", 4096, 0.99)
     st = r["st"]
     assert (st["max_violation"] <= 5e-3).mean() > 0.99
 
@@ -231,11 +232,11 @@ def test_acrobot_shard_of_65536_properties(pkg, oracle):
     idx = np.unique(np.r_[bad, np.arange(0, B, 257)])
     ref = oracle.solve_batch(model, T, x1[idx], ub[idx], nthreads=8)
     same = (st["iterations"][idx] == ref["stats"]["iterations"]) & (st["rollouts"][idx] == ref["stats"]["rollouts"])
-    assert same.mean() > 0.9
+    assert same.mean() >= 0.99
     assert same[np.isin(idx, np.nonzero(diverged)[0])].all()          # NaN instances: identical control flow
     assert ((st["potrf_info"][idx] != 0) == (ref["stats"]["potrf_info"] != 0))[same].all()
     fin = same & ~diverged[idx]
-    assert np.abs(x[idx][fin] - ref["x"][fin]).max() < 1e-6
+    assert np.abs(x[idx][fin] - ref["x"][fin]).max() < 1e-7
     sol.close()
     sub = slice(100, 164)
     small = pkg.Solver(model=model, horizon=T, batch=64, options=pkg.Options(verbose=0))
@@ -339,8 +340,8 @@ def test_parameters_car_obs(pkg, oracle):
     x, u = sol.get_trajectory(); st = sol.stats()
     ref = oracle.solve_batch(model, T, x1, ub, w=w, nthreads=8)
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.9
-    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    assert same.mean() >= 0.99
+    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
     far = oracle.solve_batch(model, T, x1, ub, w=np.full_like(w, 9.0), nthreads=8)
     assert (np.abs(far["x"] - ref["x"]).reshape(B, -1).max(1) > 1e-6).mean() > 0.5   # the parameters matter
     # the obstacle constraint is met w.r.t. each instance's own (moving) obstacle
@@ -374,7 +375,7 @@ def test_user_defined_model_plugin_path(pkg, oracle):
     sol.initialize_rollout_(x1, ub); sol.solve_()
     x, u = sol.get_trajectory(); st = sol.stats()
     ref = oracle.solve_batch("particle", T, x1, ub, nthreads=4)
-    assert (st["iterations"] == ref["stats"]["iterations"]).mean() >= 0.9
+    assert (st["iterations"] == ref["stats"]["iterations"]).mean() >= 0.99
     same = st["iterations"] == ref["stats"]["iterations"]
     assert np.abs(x - ref["x"])[same].max() < 1e-8
     builtin = pkg.Solver(model="particle", horizon=T, batch=B, options=pkg.Options(verbose=0))
@@ -397,9 +398,9 @@ def test_synth32_whole_solve(pkg, oracle):
     ref = oracle.solve_batch(model, T, x1, ub, nthreads=8)
     rs = ref["stats"]
     same = (st["iterations"] == rs["iterations"]) & (st["outer_iterations"] == rs["outer_iterations"]) & (st["rollouts"] == rs["rollouts"])
-    assert same.mean() >= 0.75, (st["iterations"], rs["iterations"])
-    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
-    assert (np.abs(K - ref["K"])[same].max() / np.abs(ref["K"]).max()) < 1e-5
+    assert same.all(), (st["iterations"], rs["iterations"])
+    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
+    assert (np.abs(K - ref["K"])[same].max() / np.abs(ref["K"]).max()) < 5e-7
     assert (np.abs(u[same]) <= 1.0 + 5e-3).all()          # the action box holds at the solution
     sol.close()
 
@@ -419,8 +420,8 @@ def test_synth32_shard_of_4096(pkg, oracle):
     idx = np.arange(0, B, 8)
     ref = oracle.solve_batch(model, T, x1[idx], ub[idx], nthreads=8)
     same = (st["iterations"][idx] == ref["stats"]["iterations"]) & (st["rollouts"][idx] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.9
-    assert np.abs(x[idx] - ref["x"])[same].max() < 1e-6
+    assert same.mean() >= 0.99
+    assert np.abs(x[idx] - ref["x"])[same].max() < 1e-7
     sol.close()
 
 
@@ -464,7 +465,7 @@ def test_long_horizon_above_64k_lds(pkg, oracle):
     ref = oracle.solve_batch("acrobot", T, x1, ub, options=oracle.default_options(max_dual_updates=2, max_iterations=15), nthreads=6)
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
     assert same.mean() >= 0.8
-    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
     sol.close()
 
 
@@ -487,10 +488,10 @@ def test_throughput_kernel_variant(pkg, oracle, config, B):
     ref = oracle.solve_batch(model, T, x1, ub, w=w, nthreads=8)
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
     fin = same & np.isfinite(ref["x"]).reshape(B, -1).all(1)
-    assert same.mean() >= 0.9
-    assert np.abs(x - ref["x"])[fin].max() < 1e-6 and np.abs(u - ref["u"])[fin].max() < 1e-6
+    assert same.mean() >= 0.99
+    assert np.abs(x - ref["x"])[fin].max() < 1e-7 and np.abs(u - ref["u"])[fin].max() < 1e-7
     agree = st["iterations"] == st2["iterations"]
-    assert agree.mean() >= 0.95
+    assert agree.mean() >= 0.99
     assert np.abs(x - x2)[agree & fin].max() < 1e-7
 
 
@@ -519,7 +520,7 @@ def test_host_stepped_al_loop_with_callback(pkg):
     # the stepped loop runs the same device functions from another kernel: same results up to the
     # compiler's FMA-contraction choices in the two inlining contexts
     same = (sf["iterations"] == ss["iterations"]) & (sf["rollouts"] == ss["rollouts"])
-    assert same.mean() >= 0.9 and (sf["outer_iterations"] == ss["outer_iterations"])[same].all()
+    assert same.mean() >= 0.99 and (sf["outer_iterations"] == ss["outer_iterations"])[same].all()
     assert np.abs(xf - xs)[same].max() < 1e-7 and np.abs(uf - us)[same].max() < 1e-7
     assert len(calls) == ss["outer_iterations"].max() - 1        # no callback after the final (converged) pass
     moved = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
@@ -564,9 +565,9 @@ def test_time_varying_stage_objects(pkg, oracle):
     sol.solve_()
     x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.9, same.mean()
-    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
-    assert np.abs(K - ref["K"])[same].max() <= 1e-5 * np.abs(ref["K"]).max()
+    assert same.mean() >= 0.99, same.mean()
+    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
+    assert np.abs(K - ref["K"])[same].max() <= 5e-7 * np.abs(ref["K"]).max()
     assert np.allclose(st["objective"][same], ref["stats"]["objective"][same], rtol=1e-8)
     assert np.allclose(st["max_violation"][same], ref["stats"]["max_violation"][same], atol=1e-8)
     # rows of the switched-off constraint kinds: zero violation, zero multiplier
@@ -610,9 +611,9 @@ def test_large_path_odd_dimensions_and_terminal_constraint(pkg, oracle):
     x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
     ref = oracle.solve_batch("synth12", T, x1, ub, options=oracle.default_options(**kw), nthreads=4)
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.9, same.mean()
-    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
-    assert np.abs(K - ref["K"])[same].max() <= 1e-5 * np.abs(ref["K"]).max()
+    assert same.mean() >= 0.99, same.mean()
+    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
+    assert np.abs(K - ref["K"])[same].max() <= 5e-7 * np.abs(ref["K"]).max()
     assert np.allclose(st["max_violation"][same], ref["stats"]["max_violation"][same], atol=1e-7)
     sol.close()
 
