@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: trajectories/sec, acrobot T=101, batch=1024 per GPU (BASELINE.json).
 
-One step = one pass of the hot path over one batch: fresh-solver reset, open-loop
-rollout initialisation from device-resident (x1, ū), and the whole AL/iLQR solve
-of every instance (`solve!`), all on the GPU. Inputs are resident in HBM before
-the timed region starts.
+One step = one pass of the hot path over one batch: fresh-solver reset, open-loop rollout initialisation from
+device-resident (x1, ū), and the whole AL/iLQR solve of every instance (`solve!`), all on the GPU. Inputs are
+resident in HBM before the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          # N > 1: this process starts N ranks itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-The batch shards embarrassingly: every rank solves its own 1024 instances with no
-data-path collective (weak scaling); the only collectives are the timing barrier
-and a MAX over ranks of the elapsed time.
+The batch shards embarrassingly: every rank solves its own 1024 instances with no data-path collective (weak
+scaling); the only collectives are the timing barrier, a MAX over ranks of the elapsed time and an all-gather of
+the per-rank figures. `--gpus N` without a torchrun environment launches the N ranks from here, BEFORE this
+process touches the GPU, and fails if fewer than N devices are visible. Under torchrun, `--gpus` must equal
+WORLD_SIZE.
 """
 import argparse
 import json
 import os
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -54,7 +58,7 @@ def host_cores():
     return n
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -62,70 +66,180 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
     ap.add_argument("--config", default="acrobot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure HBM traffic of the solve kernel live")
     ap.add_argument("--distinct-shards", action="store_true",
                     help="rank r solves instances [r*B, (r+1)*B) of one big synthetic batch instead of the same B instances "
                          "on every rank (weak scaling then also measures how unlucky the worst shard's slowest instance is)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
-    args = ap.parse_args()
+    ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput"])
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
-    import torch
+
+# ------------------------------------------------------------------------------------------------ PMC traffic
+def pmc_child(args):
+    """Body of the rocprofv3 child passes: the same solves as the timed steps, through the C-ABI with host inputs
+    (no torch: the counters are per kernel dispatch, the init path does not matter)."""
     from ilqr_amd_loader import load_package
     pkg = load_package()
+    model, T, x1, ub = pkg.workloads.make_inputs(args.config, args.batch)
+    sol = pkg.Solver(model=model, horizon=T, batch=args.batch, options=pkg.Options(verbose=0))
+    sol.set_kernel_variant_(args.variant)
+    for _ in range(max(1, args.steps)):
+        sol.reset_()
+        sol.initialize_rollout_(x1, ub)
+        sol.solve_()
+    sol.close()
 
+
+def measure_traffic(args, kernel_prefix="void ilqr::solve_kernel"):
+    """HBM bytes per launch of the solve kernel from rocprofv3 PMC counters, collected the way
+    MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), each with
+    --kernel-trace only; both counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
+    reads, so it is doubled. Returns (dict, None) or (None, reason)."""
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(prefix="ilqr_pmc_", dir="/tmp") as d:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config,
+                   "--batch", str(args.batch), "--steps", "2", "--variant", args.variant]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, "rocprofv3 %s pass failed to run: %s" % (counter, e)
+            if p.returncode != 0:
+                return None, "rocprofv3 %s pass exited %d: %s" % (counter, p.returncode, p.stdout.decode()[-300:])
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None, "rocprofv3 %s pass wrote no database" % counter
+            try:
+                cur = sqlite3.connect(dbs[0]).cursor()
+                rows = list(cur.execute("select kernel_name, sum(value), count(*) from counters_collection "
+                                        "where counter_name = ? group by kernel_name", (counter,)))
+            except sqlite3.Error as e:
+                return None, "cannot read %s from the rocprofv3 database: %s" % (counter, e)
+            rows = [r for r in rows if "solve_kernel" in r[0]]
+            if not rows:
+                return None, "no solve_kernel dispatch in the %s pass" % counter
+            name, tot, n = max(rows, key=lambda r: r[1])
+            res[counter] = tot / n
+            res["kernel"] = name
+            res["dispatches"] = n
+    fetch_b, write_b = 2.0 * res["FETCH_SIZE"] * 1024.0, res["WRITE_SIZE"] * 1024.0
+    return {"fetch_bytes": fetch_b, "write_bytes": write_b, "traffic_bytes_per_launch": fetch_b + write_b,
+            "fetch_kib_raw": res["FETCH_SIZE"], "write_kib_raw": res["WRITE_SIZE"], "kernel": res["kernel"],
+            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate child passes of this bench run "
+                      "(2 launches each); KiB -> bytes; FETCH_SIZE x2 (gfx950 wide-read correction); WRITE_SIZE uncalibrated"}, None
+
+
+# ------------------------------------------------------------------------------------------------ stub (CPU tests)
+class _StubSolver:
+    """Stands in for the GPU solver in the CPU test of the multi-rank path (ILQR_BENCH_STUB=1): same call sequence,
+    the 'solve' is a sleep that depends on the rank so that MAX-over-ranks is observable."""
+
+    def __init__(self, rank, batch):
+        self.rank, self.B, self.nx, self.nu, self.nc_stage, self.nc_term = rank, batch, 4, 1, 0, 4
+
+    def reset_(self): pass
+    def initialize_rollout_device_(self, a, b): pass
+    def initialize_rollout_(self, a, b): pass
+    def set_kernel_variant_(self, v): pass
+    def solve_(self, sync=True): time.sleep(0.002 * (self.rank + 1))
+    def synchronize(self): pass
+    def timing(self): return 2.0 * (self.rank + 1), 1
+    def timing_reset(self): pass
+    def get_trajectory(self): return None
+    def get_policy(self): return None
+    def close(self): pass
+
+    def stats(self):
+        it = np.full(self.B, 10 + self.rank)
+        return {"iterations": it, "rollouts": it + 1, "outer_iterations": np.full(self.B, 2),
+                "max_violation": np.zeros(self.B)}
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def worker(args):
+    stub = os.environ.get("ILQR_BENCH_STUB") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d — launch with `python bench.py --gpus N` (it starts the ranks "
+                         "itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    import torch
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
     dist = None
     # test hook: ILQR_BENCH_SHARE_DEVICE=1 lets several ranks share GPU 0 over gloo, to exercise the
     # multi-rank code path on a one-GPU box; the real runs use one GPU per rank over RCCL
     share = os.environ.get("ILQR_BENCH_SHARE_DEVICE") == "1"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    cpu_group = share or stub
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        if not share and torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     gpu = 0 if share else local_rank
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(gpu)
-        if share:
+        if cpu_group:
             dist.init_process_group("gloo")
         else:
+            torch.cuda.set_device(gpu)
             dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
-    torch.cuda.set_device(gpu)
-    dev = torch.device("cuda", gpu)
-    local_rank = gpu
+        backend = dist.get_backend()
+    if not stub:
+        torch.cuda.set_device(gpu)
+    dev = None if stub else torch.device("cuda", gpu)
+    cdev = "cpu" if cpu_group else dev          # where the collectives' tensors live
 
     B = args.batch
     # weak scaling with IDENTICAL per-GPU work by default: a step lasts as long as the slowest instance of the batch
     # (iteration counts are data dependent: 500 for the slowest of these 1024 instances, 381..649 for the slowest of
     # other shards), so distinct shards would fold that data lottery into the scaling figure
-    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(rank * B if args.distinct_shards else 0))
-    d_x1 = torch.from_numpy(x1).to(dev)
-    d_u = torch.from_numpy(ub).to(dev)
-    sols = [pkg.Solver(model=model, horizon=T, batch=B, device=local_rank, options=pkg.Options(verbose=0))
-            for _ in range(max(1, args.inflight))]
+    lo, _ = pkg.distributed.shard_range(rank, B)
+    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if args.distinct_shards else 0))
+    if stub:
+        sols = [_StubSolver(rank, B)]
+        d_x1 = d_u = None
+    else:
+        d_x1 = torch.from_numpy(x1).to(dev)
+        d_u = torch.from_numpy(ub).to(dev)
+        sols = [pkg.Solver(model=model, horizon=T, batch=B, device=gpu, options=pkg.Options(verbose=0))
+                for _ in range(max(1, args.inflight))]
     sol = sols[0]
-    if len(sols) > 1:      # several batches in flight: which kernel fills the SIMDs freed by early finishers best
+    for s_ in sols:
+        s_.set_kernel_variant_(args.variant)
+    if len(sols) > 1 and args.variant == "auto":   # several batches in flight: which kernel fills the SIMDs freed by early finishers best
         for s_ in sols:
             s_.set_kernel_variant_(os.environ.get("ILQR_INFLIGHT_VARIANT", "throughput"))
-    torch.cuda.synchronize()
     counter = [0]
 
     def step():
         s = sols[counter[0] % len(sols)]
         counter[0] += 1
         s.reset_()
-        s.initialize_rollout_device_(d_x1.data_ptr(), d_u.data_ptr())
+        s.initialize_rollout_device_(d_x1.data_ptr() if d_x1 is not None else 0, d_u.data_ptr() if d_u is not None else 0)
         s.solve_(sync=False)
 
     def barrier():
         for s in sols:
             s.synchronize()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not stub:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -137,42 +251,26 @@ def main():
         step()
     for s_ in sols:
         s_.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    if not stub:
+        torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pkg.distributed.max_over_ranks(my_elapsed, dist, cdev)
 
     kernel_ms, launches = sol.timing()
     st = sol.stats()
+    it_sum, it_max = float(st["iterations"].sum()), float(st["iterations"].max())
+    per_rank = pkg.distributed.gather_over_ranks([1e3 * my_elapsed / args.steps, kernel_ms, it_sum, it_max], dist, cdev)
+    if rank != 0:
+        for s_ in sols:
+            s_.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    # the same step with the boundary fed HOST buffers: x1, ū over PCIe in, x, u, K, k over PCIe out
-    # (reported beside `value`, never as `value`)
-    h0 = time.perf_counter()
-    host_steps = 3
-    for _ in range(host_steps):
-        sol.reset_()
-        sol.initialize_rollout_(x1, ub)
-        sol.solve_(sync=True)
-        sol.get_trajectory()
-        sol.get_policy()
-    host_elapsed = (time.perf_counter() - h0) / host_steps
-    n_, m_ = sol.nx, sol.nu
-    io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))
-    C = (T - 1) * sol.nc_stage + sol.nc_term
-    abytes = float(algorithmic_bytes(sol.nx, sol.nu, T, C, st["iterations"].astype(np.float64),
-                                     st["rollouts"].astype(np.float64)).sum())
-    achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    rank_ms = [r[0] for r in per_rank]
     value = world * B * args.steps / elapsed
-    traffic = None
-    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs, see profiles/)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        traffic = pmc.get("%s:%d" % (args.config, B), {}).get("traffic_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
-
     out = {
         "metric": "trajectories/sec (whole node), acrobot T=101 batch=1024/GPU",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,47 +278,126 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s (nx=%d, nu=%d, T=%d) AL-iLQR solve!, batch=%d per GPU, fp64, faithful reference semantics"
                                % (args.config, sol.nx, sol.nu, T, B),
-                   "global_batch": world * B, "horizon": T, "parallelism": "batch-shard x%d (no collective), %s" % (world, "distinct shards" if args.distinct_shards else "same 1024 instances per GPU"),
-                   "batches_in_flight": len(sols)},
+                   "global_batch": world * B, "horizon": T,
+                   "parallelism": "batch-shard x%d (no collective), %s" % (world, "distinct shards" if args.distinct_shards else "same %d instances per GPU" % B),
+                   "batches_in_flight": len(sols), "kernel_variant": args.variant},
+        "ranks": {"world_size": world, "collective_backend": backend, "group_world_size": (dist.get_world_size() if dist is not None else 1),
+                  "ms_per_step_per_rank": rank_ms, "slowest_rank": int(np.argmax(rank_ms)),
+                  "solve_kernel_ms_per_rank": [r[1] for r in per_rank],
+                  "launcher": os.environ.get("ILQR_BENCH_LAUNCHER", "external (torchrun)" if world > 1 else "single process"),
+                  "shared_device_test_hook": share, "stub": stub},
         "solve_stats": {"inner_iterations_mean": float(st["iterations"].mean()),
+                        "iterations_max": it_max,       # the kernel lasts as long as its slowest instance
+                        "iterations_max_per_rank": [r[3] for r in per_rank],
                         "rollouts_mean": float(st["rollouts"].mean()),
                         "outer_iterations_mean": float(st["outer_iterations"].mean()),
                         "converged_frac": float((st["max_violation"] <= 5e-3).mean()),
-                        "trajectory_iterations_per_s": float(world * st["iterations"].sum() * args.steps / elapsed)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "solve_kernel<Model_%s>" % model, "kernel_ms_avg": kernel_ms, "launches": launches,
-                     "algorithmic_bytes_per_launch": abytes,
-                     # pure I/O of a fully fused solve (x1, ū in; x, u, K, k out): how far below the
-                     # stage-materialised model a resident solve sits
-                     "io_lower_bound_bytes_per_launch": io_bytes,
-                     "io_lower_bound_GBs": io_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0},
-        "host_boundary": {"value": B / host_elapsed, "unit": "trajectories/s",
-                          "note": "one rank, inputs from host memory and x, u, K, k copied back (PCIe-inclusive)"},
+                        "trajectory_iterations_per_s": float(sum(r[2] for r in per_rank) * args.steps / elapsed)},
     }
+    if not stub:
+        n_, m_ = sol.nx, sol.nu
+        io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))
+        C = (T - 1) * sol.nc_stage + sol.nc_term
+        abytes = float(algorithmic_bytes(sol.nx, sol.nu, T, C, st["iterations"].astype(np.float64),
+                                         st["rollouts"].astype(np.float64)).sum())
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "basis": "ALGORITHMIC bytes of SURVEY §8(d) (stage-materialised model) / measured kernel time: a modelled figure, "
+                         "the fused kernel keeps most of these bytes in LDS (see counter_frac and actual_bound)",
+                "kernel": "solve_kernel<Model_%s>" % model, "kernel_ms_avg": kernel_ms, "launches": launches,
+                "algorithmic_bytes_per_launch": abytes,
+                # pure I/O of a fully fused solve (x1, ū in; x, u, K, k out): how far below the
+                # stage-materialised model a resident solve sits
+                "io_lower_bound_bytes_per_launch": io_bytes,
+                "io_lower_bound_GBs": io_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0}
+        if world == 1 and not args.no_pmc:
+            for s_ in sols:
+                s_.synchronize()
+            tr, why = measure_traffic(args)
+            if tr is not None:
+                roof["traffic"] = tr["traffic_bytes_per_launch"]
+                roof["traffic_detail"] = tr
+                roof["counter_GBs"] = tr["traffic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+                roof["counter_frac"] = roof["counter_GBs"] / HBM_PEAK_GBS
+                roof["traffic_over_algorithmic"] = tr["traffic_bytes_per_launch"] / abytes
+            else:
+                roof["traffic_unmeasured_reason"] = why
+        try:     # instruction-issue model of the critical path (tools/issue_model.py, from the ISA of this build)
+            im = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json"))).get("%s" % args.config)
+            if im and kernel_ms > 0 and args.variant in ("auto", "latency") and B <= 1024:
+                rollouts_per_iter = float(st["rollouts"].sum()) / max(1.0, it_sum)
+                clk = im["clk_per_issue"]
+                per_iter_clk = (T - 1) * (im["rollout_step_instr"] * rollouts_per_iter + im["riccati_step_instr"]) * clk \
+                    + im["per_iteration_other_clk"]
+                floor_ms = it_max * per_iter_clk / (im["clock_ghz"] * 1e6)
+                roof["actual_bound"] = "fp64 instruction issue / latency of the serial chain of the SLOWEST instance"
+                roof["issue_model"] = dict(im, iterations_max=it_max, rollouts_per_iteration=rollouts_per_iter,
+                                           predicted_floor_ms=floor_ms, achieved_over_floor=kernel_ms / floor_ms)
+        except (OSError, ValueError, KeyError):
+            pass
+        out["roofline"] = roof
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
-        threads = host_cores()
-        sample = min(B, 64 * threads)
-        c0 = time.perf_counter()
-        O.solve_batch(model, T, x1[:sample], ub[:sample], nthreads=threads, want_policy=False)
-        c1 = time.perf_counter() - c0
-        one = min(sample, 48)
-        c0 = time.perf_counter()
-        O.solve_batch(model, T, x1[:one], ub[:one], nthreads=1, want_policy=False)
-        c_one = time.perf_counter() - c0
-        out["cpu_baseline"] = {"value": sample / c1, "unit": "trajectories/s", "cores": threads, "kind": "port",
-                               "single_thread_value": one / c_one,
-                               "sample": "first %d of the %d instances of this workload, C++ oracle "
-                                         "(literal restatement of the Julia reference, which cannot run here), "
-                                         "OpenMP over instances, %.1f s wall" % (sample, B, c1)}
-    if rank == 0:
-        print(json.dumps(out))
+        if world == 1:
+            # the same step with the boundary fed HOST buffers: x1, ū over PCIe in, x, u, K, k over PCIe out
+            # (reported beside `value`, never as `value`)
+            h0 = time.perf_counter()
+            host_steps = 3
+            for _ in range(host_steps):
+                sol.reset_()
+                sol.initialize_rollout_(x1, ub)
+                sol.solve_(sync=True)
+                sol.get_trajectory()
+                sol.get_policy()
+            host_elapsed = (time.perf_counter() - h0) / host_steps
+            out["host_boundary"] = {"value": B / host_elapsed, "unit": "trajectories/s",
+                                    "note": "one rank, inputs from host memory and x, u, K, k copied back (PCIe-inclusive)"}
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            threads = host_cores()
+            sample = min(B, 64 * threads)
+            c0 = time.perf_counter()
+            O.solve_batch(model, T, x1[:sample], ub[:sample], nthreads=threads, want_policy=False)
+            c1 = time.perf_counter() - c0
+            one = min(sample, 48)
+            c0 = time.perf_counter()
+            O.solve_batch(model, T, x1[:one], ub[:one], nthreads=1, want_policy=False)
+            c_one = time.perf_counter() - c0
+            out["cpu_baseline"] = {"value": sample / c1, "unit": "trajectories/s", "cores": threads, "kind": "port",
+                                   "single_thread_value": one / c_one,
+                                   "sample": "first %d of the %d instances of this workload, C++ oracle "
+                                             "(literal restatement of the Julia reference, which cannot run here), "
+                                             "OpenMP over instances, %.1f s wall" % (sample, B, c1)}
+    print(json.dumps(out), flush=True)
     for s_ in sols:
         s_.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.pmc_child:
+        return pmc_child(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launcher: N fresh ranks, started before this process has made any HIP call
+        from ilqr_amd_loader import load_package
+        pkg = load_package()
+        os.environ["ILQR_BENCH_LAUNCHER"] = "bench.py --gpus %d (subprocess per rank)" % args.gpus
+        try:
+            rc, out0 = pkg.distributed.launch_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus,
+                                                    share_device=os.environ.get("ILQR_BENCH_SHARE_DEVICE") == "1",
+                                                    stub=os.environ.get("ILQR_BENCH_STUB") == "1", timeout=3600)
+        except RuntimeError as e:
+            raise SystemExit("bench.py: %s" % e)
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        if rc != 0:
+            raise SystemExit("bench.py: a rank exited with code %d" % rc)
+        return
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,47 @@
+"""`bench.py --gpus N` launches N ranks itself (one process per GPU) — exercised on CPU with gloo and a stub
+solve (ILQR_BENCH_STUB=1): same launcher, rendezvous, barrier, MAX-over-ranks and per-rank gather code as on GPUs."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    return subprocess.run([sys.executable, BENCH] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+
+def test_gpus_2_launches_two_ranks_over_gloo():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8"], ILQR_BENCH_STUB="1")
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE json line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16
+    r = out["ranks"]
+    assert r["world_size"] == 2 and r["group_world_size"] == 2 and r["collective_backend"] == "gloo"
+    assert "bench.py --gpus 2" in r["launcher"]
+    assert len(r["ms_per_step_per_rank"]) == 2 and r["slowest_rank"] == 1          # the stub's rank 1 sleeps twice as long
+    assert out["ms_per_step"] >= max(r["ms_per_step_per_rank"]) - 1e-9             # MAX over ranks
+    assert r["solve_kernel_ms_per_rank"] == [2.0, 4.0]
+    assert abs(out["value"] - 16 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]   # whole-job units / max time
+    assert out["solve_stats"]["iterations_max_per_rank"] == [10.0, 11.0]
+
+
+def test_gpus_n_refuses_when_fewer_devices_are_visible():
+    """No GPU in this container: asking for 2 must fail loudly, not report a 1-GPU number as n_gpus = 2."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p.returncode != 0
+    assert "GPU(s) are visible" in p.stderr.decode()
+
+
+def test_world_size_mismatch_is_an_error():
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], ILQR_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr.decode()

@@ -6,8 +6,8 @@ import sys
 
 def main():
     kt = sqlite3.connect(sys.argv[1]).cursor()
-    print("# rocprofv3 --kernel-trace --stats summary (durations in ns)")
-    print("%-70s %6s %16s %14s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+    print("# rocprofv3 --kernel-trace --stats summary (top_kernels view: durations in MICROSECONDS; the per-dispatch avg further down is in ns)")
+    print("%-70s %6s %16s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in kt.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         print("%-70s %6d %16.0f %14.1f %8.3f" % (name, calls, total, avg, pct))
     print()
