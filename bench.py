@@ -327,12 +327,14 @@ def worker(args):
             im = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json"))).get("%s" % args.config)
             if im and kernel_ms > 0 and args.variant in ("auto", "latency") and B <= 1024:
                 rollouts_per_iter = float(st["rollouts"].sum()) / max(1.0, it_sum)
-                clk = im["clk_per_issue"]
-                per_iter_clk = (T - 1) * (im["rollout_step_instr"] * rollouts_per_iter + im["riccati_step_instr"]) * clk \
+                per_iter_clk = (T - 1) * (im["rollout_step_occupancy_clk"] * rollouts_per_iter + im["riccati_step_occupancy_clk"]) \
                     + im["per_iteration_other_clk"]
+                slots_iter = (T - 1) * (im["rollout_step_instr"] * rollouts_per_iter + im["riccati_step_instr"])
                 floor_ms = it_max * per_iter_clk / (im["clock_ghz"] * 1e6)
-                roof["actual_bound"] = "fp64 instruction issue / latency of the serial chain of the SLOWEST instance"
+                roof["actual_bound"] = "fp64 instruction issue + dependent latency of the serial chain of the SLOWEST instance"
                 roof["issue_model"] = dict(im, iterations_max=it_max, rollouts_per_iteration=rollouts_per_iter,
+                                           issue_slots_per_iteration=slots_iter,
+                                           measured_clk_per_issue_slot=kernel_ms * im["clock_ghz"] * 1e6 / (it_max * slots_iter),
                                            predicted_floor_ms=floor_ms, achieved_over_floor=kernel_ms / floor_ms)
         except (OSError, ValueError, KeyError):
             pass

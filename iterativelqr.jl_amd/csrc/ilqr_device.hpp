@@ -125,6 +125,13 @@ __device__ __forceinline__ void load_w(const double* W, int t, double (&w)[cdim<
 #define ILQR_PROF_END(I, slot) do {} while (0)
 #endif
 enum { PROF_COST = 0, PROF_GRAD, PROF_BACKWARD, PROF_DELTA, PROF_ROLLOUT, PROF_OTHER, PROF_N };
+// -DILQR_ISA_MARKERS (analysis builds only, tools/issue_model.py): comment markers at the head of every timestep body of the
+// serial loops, so that the loops can be found and their per-step instruction counts read off the assembly
+#ifdef ILQR_ISA_MARKERS
+#define ILQR_ISA_MARK(name, role) asm volatile("; ILQR_MARK " name " %0" ::"i"(role))
+#else
+#define ILQR_ISA_MARK(name, role) do {} while (0)
+#endif
 
 // Per-instance context. LDS pointers first, then HBM pointers, then the
 // wave-uniform SolverData scalars (src/data/solver.jl:4-18) kept in registers.
@@ -660,6 +667,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         return Y * -1.0;                                                // K .*= -1, k .*= -1
     };
     auto riccati_step = [&](const Opnd& o, int t, int slot) {
+        ILQR_ISA_MARK("riccati_step", ROLE);
         const double gxx = o.gxx, guu = o.guu, gux = o.gux, fx = o.fx, fu = o.fu, gx = o.gx, gu = o.gu;
         double Qxx = 0.0, Qux, Quu, Qx = 0.0, Qu = 0.0, K, k = 0.0, uxt;
         if constexpr (MAT) {
@@ -855,6 +863,7 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     const double* pLx = (MF && vn1) ? I.Lx + r : I.zs;            const int sLx = (MF && vn1) ? n : 0;
     const double* pLu = (MF && vm1) ? I.Lu + r : I.zs;
     auto step = [&](const Ops& o, int t, const double (&xin)[n], double (&xout)[n]) {
+        ILQR_ISA_MARK("rollout_step", MF ? 1 : 0);
         // sensitivity recursion: operand loads first (their latency hides under the policy evaluation)
         double KT = 0.0, fxT = 0.0, fuT = 0.0, kc = 0.0, Lxc = 0.0, Luc = 0.0;
         if constexpr (MF) {
@@ -934,6 +943,7 @@ __device__ double delta_small(Inst<M>& I) {
 #pragma unroll
     for (int i = 0; i < n; ++i) zx[i] = 0.0;
     for (int t = 0; t < I.N; ++t) {
+        ILQR_ISA_MARK("delta_step", 0);
         double du[m];
 #pragma unroll
         for (int i = 0; i < m; ++i) {                                   // Δu = k + K Δx

@@ -1,0 +1,182 @@
+"""Instruction-issue model of the latency kernel's critical path, from the ISA of THIS build.
+
+    python tools/issue_model.py [config ...]      # writes profiles/issue_model.json, prints the loop table
+
+What bounds solve_kernel<Model_acrobot> at batch 1024 is not HBM (counter traffic = 0.6 % of peak) but the serial
+instruction stream of each instance's slowest wave: a lone wave issues one fp64 VALU instruction every ~12 shader
+clocks whether or not it depends on the previous one (tools/probes/probe_mfma.hip, profiles/r01_probes_fp64_latency_dvfs.txt:
+dependent 14.0, independent 13.0 clk/op one wave per SIMD; 12.3 clk at two waves per SIMD, the headline residency),
+so the kernel is bound by the instruction stream of the critical wave, not by bytes.  This script compiles csrc/builtin_models.hip to assembly,
+finds the serial time loops of solve_kernel<Model_X> through comment markers (-DILQR_ISA_MARKERS) and LLVM's loop
+annotations, and counts the instructions ISSUED per timestep on wave 0 by class (s_nop N counts N+1 idle states).
+bench.py turns them into the SIMD-occupancy floor of the slowest instance's critical wave
+(roofline.issue_model.predicted_floor_ms, achieved_over_floor)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "iterativelqr.jl_amd", "csrc")
+MANGLED = {"acrobot": "_ZN4ilqr12solve_kernelI13Model_acrobotEEvNS_5KArgsE",
+           "car": "_ZN4ilqr12solve_kernelI9Model_carEEvNS_5KArgsE"}
+HORIZON_UNROLL = 2          # both time loops are unrolled by two (ping-pong operand sets)
+# SIMD occupancy of one wave64 instruction, in shader clocks (MI355X_MICROARCH.md: SIMD-32, fp32 VALU 2 clk; fp64 vector
+# peak 78.6 TFLOP/s = 16 DP lanes per clk per SIMD -> 4 clk; v_mfma_f64_4x4x4 = 4 blocks x 64 FMA at the same DP rate -> 16 clk;
+# scalar / branch / wait instructions 1 clk; s_nop N = N + 1 idle states)
+OCC = {"valu_f64": 4.0, "mfma": 16.0, "valu_other": 2.0, "dpp_perm": 2.0, "lds": 2.0, "vmem": 2.0, "salu": 1.0, "waitcnt": 1.0, "nop_states": 1.0}
+CLOCK_GHZ = 2.38            # sustained shader clock with 1024 such workgroups resident (probe_clock.hip)
+
+
+def assembly():
+    out = "/tmp/ilqr_builtin_models.s"
+    src = os.path.join(CSRC, "builtin_models.hip")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(CSRC, "models", f) for f in os.listdir(os.path.join(CSRC, "models"))]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                               "--cuda-device-only", "-DILQR_ISA_MARKERS", "-S", "-I", CSRC, src, "-o", out], stderr=subprocess.DEVNULL)
+    return open(out).read().splitlines()
+
+
+def function_body(lines, mangled):
+    start = next(i for i, ln in enumerate(lines) if ln.startswith(mangled + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    return lines[start:end + 1]
+
+
+def loops(body):
+    """(first, last) line indices of innermost loops: a branch to a label defined above it, with no other loop inside."""
+    labels = {}
+    for i, ln in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            labels[m.group(1)] = i
+    spans = []
+    for i, ln in enumerate(body):
+        m = re.match(r"\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", ln) or re.match(r"\s+s_branch\s+(\.LBB\d+_\d+)", ln)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            spans.append((labels[m.group(1)], i))
+    inner = [s for s in spans if not any(o != s and s[0] <= o[0] and o[1] <= s[1] for o in spans)]
+    return inner
+
+
+def classify(body, span):
+    c = {"total": 0, "valu_f64": 0, "valu_other": 0, "mfma": 0, "salu": 0, "lds": 0, "vmem": 0, "nop_states": 0, "waitcnt": 0, "dpp_perm": 0}
+    for ln in body[span[0]:span[1] + 1]:
+        t = ln.strip()
+        if not t or t.startswith((";", ".")) or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        if op == "s_nop":
+            c["nop_states"] += int(t.split()[1]) + 1
+            c["total"] += 1
+            continue
+        c["total"] += 1
+        if op.startswith("v_mfma"):
+            c["mfma"] += 1
+        elif op.startswith("v_") and ("f64" in op or op in ("v_div_scale_f64", "v_div_fmas_f64", "v_div_fixup_f64")):
+            c["valu_f64"] += 1
+        elif op.startswith("v_") and ("dpp" in t or "permlane" in op or "readlane" in op or "readfirstlane" in op):
+            c["dpp_perm"] += 1
+        elif op.startswith("v_"):
+            c["valu_other"] += 1
+        elif op.startswith("ds_"):
+            c["lds"] += 1
+        elif op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+            c["vmem"] += 1
+        elif op == "s_waitcnt":
+            c["waitcnt"] += 1
+        elif op.startswith("s_"):
+            c["salu"] += 1
+    return c
+
+
+def block_loops(body):
+    """Per line: (loop header id, depth) of the basic block it belongs to, from LLVM's own loop annotations
+    ('; in Loop: Header=BBf_h Depth=d' on member blocks, '; =>This [Inner] Loop Header: Depth=d' on headers)."""
+    owner = [None] * len(body)
+    cur = None
+    i = 0
+    while i < len(body):
+        ln = body[i]
+        m = re.match(r"^(?:\.LBB\d+_(\d+)|; %bb\.(\d+)):\s*(?:;(.*))?$", ln)
+        if m:
+            bid = m.group(1) or m.group(2)
+            cm = m.group(3) or ""
+            j = i + 1
+            while j < len(body) and re.match(r"^\s+;", body[j]) and "Loop" in body[j]:
+                cm += " " + body[j]
+                j += 1
+            mm = re.search(r"in Loop: Header=BB\d+_(\d+) Depth=(\d+)", cm)
+            hh = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", cm)
+            if hh:
+                cur = (bid, int(hh.group(1)))
+            elif mm:
+                cur = (mm.group(1), int(mm.group(2)))
+            else:
+                cur = None
+        owner[i] = cur
+        i += 1
+    return owner
+
+
+def marked_loop(body, marker):
+    """The deepest loop that holds `marker` comments: instruction counts of its own blocks (child loops — cold slow
+    paths such as the huge-argument trig reduction — excluded) and the number of step copies in its body."""
+    owner = block_loops(body)
+    marks = [i for i, ln in enumerate(body) if marker in ln and owner[i] is not None]
+    if not marks:
+        raise RuntimeError("marker %r not inside any loop" % marker)
+    loop = max((owner[i] for i in marks), key=lambda o: o[1])
+    k = sum(1 for i in marks if owner[i] == loop)
+    lines = [body[i] for i in range(len(body)) if owner[i] == loop]
+    return classify(lines, (0, len(lines) - 1)), k
+
+
+def model_for(config, lines):
+    body = function_body(lines, MANGLED[config])
+    rol, krol = marked_loop(body, "ILQR_MARK rollout_step 0")          # wave 0's rollout (two-wave kernel: no MFMA ride-along)
+    ric, kric = marked_loop(body, "ILQR_MARK riccati_step 1")          # ROLE 1: matrix chain on wave 0
+    vec, kvec = marked_loop(body, "ILQR_MARK riccati_step 2")          # ROLE 2: vector chain on wave 1
+    dlt, kdlt = marked_loop(body, "ILQR_MARK delta_step 0")            # wave 1, beside the first rollout
+    table = [dict(rol, kind="rollout (wave 0)", steps=krol), dict(ric, kind="riccati matrix chain (wave 0)", steps=kric),
+             dict(vec, kind="riccati vector chain (wave 1)", steps=kvec), dict(dlt, kind="delta sweep (wave 1)", steps=kdlt)]
+    slots = lambda c, k: (c["total"] + c["nop_states"]) / k
+    occ = lambda c, k: sum(OCC[key] * c[key] for key in OCC) / k
+    return {
+        "kernel": "solve_kernel<Model_%s>, wave 0 (the instance's critical wave)" % config,
+        "rollout_step_instr": slots(rol, krol), "riccati_step_instr": slots(ric, kric),
+        "wave1_riccati_step_instr": slots(vec, kvec), "wave1_delta_step_instr": slots(dlt, kdlt),
+        "rollout_loop": dict(rol, steps_in_body=krol), "riccati_loop": dict(ric, steps_in_body=kric),
+        "rollout_step_occupancy_clk": occ(rol, krol), "riccati_step_occupancy_clk": occ(ric, kric),
+        "occupancy_clk_per_instruction": OCC, "clock_ghz": CLOCK_GHZ,
+        "per_iteration_other_clk": 14000.0,
+        "note": "issue slots per timestep = (instructions + s_nop idle states of the loop holding the step marker, cold child loops "
+                "excluded) / step copies in that loop body (-DILQR_ISA_MARKERS analysis build of the same sources). The floor is the "
+                "SIMD OCCUPANCY of the critical wave's stream (perfect instruction-level overlap, no dependency stalls): what is left "
+                "between it and the measured time are the dependent latencies of the serial chain (fp64 FMA 14 clk, MFMA 24-32 clk, "
+                "division 82 clk, LDS 65 clk dependent — profiles/r01_probes_fp64_latency_dvfs.txt). "
+                "per_iteration_other_clk = cost pass + wave 0's share of the linearisation + copies "
+                "(profiles/r01_final_phase_cycles.txt: 0.8 % + 3.4 % + 1.5 % of an iteration)",
+    }, table
+
+
+def main():
+    lines = assembly()
+    out = {}
+    for config in (sys.argv[1:] or ["acrobot", "car"]):
+        m, table = model_for(config, lines)
+        out[config] = m
+        print("== %s: serial loops of the solve kernel (per loop body)" % config)
+        for t in table:
+            print("  %-32s steps/body %d  total %4d  f64 %4d  mfma %3d  valu %3d  dpp/perm %3d  lds %3d  vmem %3d  salu %3d  wait %2d  nop-states %3d"
+                  % (t["kind"], t["steps"], t["total"], t["valu_f64"], t["mfma"], t["valu_other"], t["dpp_perm"], t["lds"], t["vmem"], t["salu"],
+                     t["waitcnt"], t["nop_states"]))
+        print("  -> wave 0 per timestep: rollout %.0f issue slots = %.0f clk of SIMD occupancy, Riccati matrix chain %.0f issue slots = %.0f clk"
+              % (m["rollout_step_instr"], m["rollout_step_occupancy_clk"], m["riccati_step_instr"], m["riccati_step_occupancy_clk"]))
+    json.dump(out, open(os.path.join(ROOT, "profiles", "issue_model.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
