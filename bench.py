@@ -74,7 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
-    ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed"])
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 

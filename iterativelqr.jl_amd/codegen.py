@@ -153,6 +153,11 @@ def _extract_trig(exprs):
     return exprs, defs
 
 
+# lanes that cooperate on one dependency level of trig arguments / reciprocals: a whole wave for large models, a 16-lane
+# row for small ones (so that the packed kernel can run their rollout with four instances per wave)
+COOP_GROUP = 64
+
+
 def _group_reciprocals(repl):
     """CSE nodes of the form sym = 1/base that do not depend on each other, in groups of 2..64 (coop blocks only)."""
     defs = dict(repl)
@@ -173,7 +178,7 @@ def _group_reciprocals(repl):
             continue
         g = [(si, bi)]
         for sj, bj in recs[i + 1:]:
-            if sj in used or len(g) >= 64:
+            if sj in used or len(g) >= COOP_GROUP:
                 continue
             if all(sj not in deps(sk) and sk not in deps(sj) for sk, _ in g):
                 g.append((sj, bj))
@@ -237,7 +242,7 @@ def _emit_block(outputs, prefix, coop=False):
             items = rounds[r]
             # up to 4 arguments: one per lane of every quad, results handed back by DPP quad broadcasts
             # (stay in VGPRs); 5..64 arguments: one per lane of the wave, results by v_readlane (SGPRs).
-            chunks = [items] if len(items) <= 64 else [items[i:i + 64] for i in range(0, len(items), 64)]
+            chunks = [items] if len(items) <= COOP_GROUP else [items[i:i + COOP_GROUP] for i in range(0, len(items), COOP_GROUP)]
             for chunk in chunks:
                 if len(chunk) == 1:
                     continue   # a lone argument: plain (wave-uniform) sincos below
@@ -413,6 +418,8 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     ineq_s = sum(1 << (i - 1) for i in con_stage.indices_inequality)
     ineq_t = sum(1 << (i - 1) for i in con_term.indices_inequality)
     sname = "Model_" + name
+    global COOP_GROUP
+    COOP_GROUP = 16 if (n <= 4 and m <= 4) else 64
     L = []
     L.append("// GENERATED by iterativelqr.jl_amd/codegen.py — do not edit.")
     L.append("// Device model functions (value + symbolic derivatives), column-major outputs.")
@@ -544,6 +551,13 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
            con_term if nct else dynamics, con_term, nct, False, False)
     L.append("};")
     src = "\n".join(L) + "\n"
+    # the cooperative rollout code is generic over HOW a value travels from one lane of the cooperating group to all of
+    # them: ilqr::WaveBC (whole wave, v_readlane) in the latency / throughput kernels, ilqr::Row16BC (16-lane rows,
+    # ds_swizzle) in the packed kernel that runs four instances per wave
+    src = src.replace("ilqr::wave_bcast<", "BC::template bcast<")
+    for fn in ("dyn_wave", "dyn_rem_wave"):
+        src = src.replace("__device__ __forceinline__ static void %s(" % fn,
+                          "template <class BC = ilqr::WaveBC> __device__ __forceinline__ static void %s(" % fn)
     return sname, src
 
 

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -74,7 +75,8 @@ struct ilqr_handle {
     double* d_u;   // staging for host-pointer initialize_rollout
     double* trace;
     int trace_cap;
-    int variant;          // 0 auto, 1 latency kernel (1 wave/SIMD, all-LDS), 2 throughput kernel (slim)
+    int variant;          // 0 auto, 1 latency kernel (all-LDS, 2 waves per instance), 2 throughput kernel (slim), 3 packed kernel (4 instances per wave, no LDS)
+    bool lds_fits;        // the LDS-resident kernels can hold this horizon (otherwise only the packed kernel runs it)
     int num_simds;
     double* qv;           // optional action-value buffers Qx, Qu, Qxx, Quu, Qux (allocated on first use by a getter)
     ilqr::QLayout QL;
@@ -234,10 +236,12 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->qv = nullptr; h->QL = ilqr::make_qlayout(vt->nx, vt->nu, d->horizon); h->jh_dirty = false; h->P_dirty = false;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
-    if (h->lds_bytes > 160 * 1024) {
+    h->lds_fits = h->lds_bytes <= 160 * 1024;
+    if (!h->lds_fits && vt->launch_solve_packed == nullptr) {
+        // the reference has no horizon limit (src/data/problem.jl:25-46); here only the streaming (packed) kernel is free of one
         delete h;
-        return fail(ILQR_ERR_LDS, "per-instance working set exceeds the 160 KiB LDS of a gfx950 CU "
-                                  "(LDS-resident wave-per-instance kernel); reduce the horizon");
+        return fail(ILQR_ERR_LDS, "per-instance working set exceeds the 160 KiB LDS of a gfx950 CU and this model has no "
+                                  "streaming (packed) kernel (nx <= 4, nu <= 2 only); reduce the horizon");
     }
     // from here on every failure must release the handle
     auto bail = [&](hipError_t e, const char* what) {
@@ -370,10 +374,19 @@ int ilqr_solve(ilqr_handle* h) {
     auto drop = [&](int rc) { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); return rc; };
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, h->stream) != hipSuccess)
         return drop(fail(ILQR_ERR_HIP, "hipEventCreate/Record failed"));
-    // batches that do not fit one wave per SIMD take the throughput kernel (two waves per SIMD)
-    const bool slim = h->vt->launch_solve_slim != nullptr &&
+    // auto: the latency kernel while the batch fits the chip (one instance per SIMD); larger batches take the packed
+    // kernel (four instances per wave, workspace streamed from HBM / L2) when the model has one (nx <= 4, nu <= 2),
+    // the throughput kernel otherwise.
+    // Horizons whose LDS-resident set exceeds 160 KiB run on the packed kernel only.
+    const bool can_pack = h->vt->launch_solve_packed != nullptr;
+    const bool packed = can_pack && (h->variant == 3 || !h->lds_fits || (h->variant == 0 && h->B > h->num_simds));
+    const bool slim = !packed && h->vt->launch_solve_slim != nullptr &&
                       (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
-    if (slim) {
+    if (!packed && !h->lds_fits) return drop(fail(ILQR_ERR_LDS, "this horizon only runs on the packed kernel"));
+    if (packed) {
+        if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);      // phase-timing hook, see ilqr_device_packed.hpp
+        if (h->vt->launch_solve_packed(&a, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (packed variant) launch failed"));
+    } else if (slim) {
         if (h->vt->launch_solve_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
             return drop(fail(ILQR_ERR_HIP, "solve (throughput variant) launch failed"));
     } else if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve launch failed"));
@@ -390,6 +403,7 @@ int ilqr_run_stage(ilqr_handle* h, int32_t stage) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
+    if (!h->lds_fits) return fail(ILQR_ERR_LDS, "stage kernels are LDS-resident: this horizon only runs through ilqr_solve (packed kernel)");
     ilqr::KArgs a = make_args(h);
     a.stage = stage;
     if (stage != ILQR_STAGE_BACKWARD_PASS && stage != ILQR_STAGE_ILQR_SOLVE) a.qv = nullptr;
@@ -500,7 +514,11 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
 }
 
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
-    if (!h || variant < 0 || variant > 2) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency) or 2 (throughput)");
+    if (!h || variant < 0 || variant > 3) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency), 2 (throughput) or 3 (packed)");
+    if (variant == 3 && h->vt->launch_solve_packed == nullptr)
+        return fail(ILQR_ERR_INVALID, "the packed variant exists for models with nx <= 4, nu <= 2 only");
+    if ((variant == 1 || variant == 2) && !h->lds_fits)
+        return fail(ILQR_ERR_LDS, "this horizon exceeds the LDS-resident kernels: only the packed variant can run it");
     if (variant == 2 && h->vt->launch_solve_slim == nullptr)
         return fail(ILQR_ERR_INVALID, "the throughput variant exists for small models (nx, nu <= 4) only");
     h->variant = variant;

@@ -1314,10 +1314,11 @@ __global__ __launch_bounds__(64) void init_rollout_kernel(KArgs a) {
 }
 
 }  // namespace ilqr
+#include "ilqr_device_packed.hpp"
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 2   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+#define ILQR_MODEL_ABI_VERSION 3   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against
@@ -1329,6 +1330,7 @@ extern "C" struct ilqr_model_vtable {
     int (*launch_init)(const ilqr::KArgs* a, void* stream);
     int (*launch_solve_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
     int (*launch_stage_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
+    int (*launch_solve_packed)(const ilqr::KArgs* a, void* stream);                   // four instances per wave, no LDS; null unless nx <= 4, nu <= 2
 };
 
 namespace ilqr {
@@ -1372,6 +1374,14 @@ struct ModelModule {
             return -1;
         }
     }
+    static int launch_solve_packed(const KArgs* a, void* stream) {
+        if constexpr (packed_ok<M>::value) {
+            hipLaunchKernelGGL(solve_kernel_packed<M>, dim3((a->B + 3) / 4), dim3(64), sizeof(double) * pk::PkLds<M>::total, (hipStream_t)stream, *a);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        } else {
+            return -1;
+        }
+    }
     static int launch_init(const KArgs* a, void* stream) {
         hipLaunchKernelGGL(init_rollout_kernel<M>, dim3((a->B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -1381,7 +1391,8 @@ struct ModelModule {
                                              M::NAME, M::NX, M::NU, M::NW, M::NCS, M::NCT, M::INEQ_S, M::INEQ_T,
                                              &launch_solve, &launch_stage, &launch_init,
                                              is_large<M>::value ? nullptr : &launch_solve_slim,
-                                             is_large<M>::value ? nullptr : &launch_stage_slim};
+                                             is_large<M>::value ? nullptr : &launch_stage_slim,
+                                             packed_ok<M>::value ? &launch_solve_packed : nullptr};
         return &vt;
     }
 };

@@ -1,0 +1,1005 @@
+// Packed kernel for small models (nx <= 4, nu <= 2): FOUR problem instances per wavefront, no LDS.
+//
+// Why: at one instance per wave every issued instruction does one instance's worth of work (the serial phases are
+// wave-uniform arithmetic: <= 16 useful lanes in the MFMA Riccati step, 1 in the rollout chain), and the SIMDs saturate
+// at ~2.5 such waves each — so beyond ~2 k resident instances the latency / throughput kernels serialise in rounds.
+// The LDS-resident working set (20-39 KB per instance) is what caps the residency. Here
+//   * the whole per-instance workspace stays in the HBM block of ilqr_layout.hpp (L2 / Infinity-Cache resident for the
+//     BASELINE batches) and is STREAMED: every serial loop walks time in one direction and fetches its operands one
+//     step ahead into registers, so no array needs to live on chip — and the horizon is no longer bounded by the
+//     160 KiB LDS of a CU;
+//   * v_mfma_f64_4x4x4 works on its four blocks at once: block beta = (lane >> 2) & 3 carries the Riccati recursion of
+//     instance beta of the wave (element (r, c) on lane c + 4*beta + 16*r);
+//   * the time-parallel phases (cost, linearisation) and the rollout use the ROW mapping: instance q = lane >> 4 owns
+//     the 16 lanes of row q; the cooperative dynamics (one sincos / one division sequence for all arguments of a
+//     dependency level) exchange values inside a row with ds_swizzle (ilqr::Row16BC);
+//   * the reference's per-instance control flow (AL outer loop, iLQR inner loop, Armijo trials) becomes a per-instance
+//     STATE MACHINE: the wave cycles  [outer-loop transitions] -> [line-search trial] -> [linearise + Riccati]  and an
+//     instance takes part in a phase when its state asks for it (predicated stores). An instance that rejects a trial
+//     simply sits out the following linearisation; nobody waits for anybody else inside a wave beyond that.
+// Same arithmetic as the other two kernels up to the association of a few sums (tree reductions over 16 lanes instead of
+// 64) and the solve of k sharing K's division through spare rows instead of a spare block.
+//
+// Reference functions reproduced: see ilqr_device.hpp (same citations, paths relative to /root/reference).
+#pragma once
+
+namespace ilqr {
+
+template <class M> struct packed_ok { static constexpr bool value = (M::NX <= 4 && M::NU <= 2); };
+
+#ifndef ILQR_PK_FUSED
+#define ILQR_PK_FUSED 1      // 0: separate linearisation / Riccati / sensitivity sweeps through HBM (the first version; kept for A/B runs)
+#endif
+
+namespace pk {
+
+enum { ST_INIT = 0, ST_FORWARD = 1, ST_OUTER = 2, ST_DONE = 3 };
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
+// sum / NaN-propagating max over the 16 lanes of a row (rows = instances in the row mapping)
+__device__ __forceinline__ double row_sum(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double row_max(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = (w > v || w != w) ? w : v; }
+    return v;
+}
+// bit q of the result = predicate of instance q (taken from the first lane of its row)
+__device__ __forceinline__ unsigned row_mask(bool p) {
+    const unsigned long long b = __ballot(p);
+    return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull));
+}
+// v_permlane32_swap(v, v) = {[lo lo], [hi hi]}: rows 2, 3 <- rows 0, 1 (first result) or rows 0, 1 <- rows 2, 3 (second)
+__device__ __forceinline__ double from_lane_minus32(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+__device__ __forceinline__ double from_lane_plus32(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// Per-lane view of the wave's four instances.
+template <class M>
+struct PInst {
+    // row mapping (instance q = lane >> 4, j = lane & 15): workspace block of this lane's instance
+    double* g;
+    // block mapping (instance beta = (lane >> 2) & 3, element (r, c) = (lane >> 4, lane & 3))
+    double* gb;
+    Layout L;
+    int lane, q, j, beta, r, c;
+    bool valid_row, valid_blk;
+    double* trace;
+    int trace_cap;
+    // SolverData of the row's instance, replicated over its 16 lanes
+    double objective, max_violation, step_size, gradient_norm, obj_prev, J_prev, delta, delta_next;
+    int status, iterations, outer, it, trial, rollouts, potrf_info, states_eq_nominal, trace_len, state, needB, leaving;
+};
+
+// ------------------------------------------------------------------ cost! (row mapping, one timestep per lane of a row)
+// X / U: offsets of the trajectory inside the instance block. upd_J / upd_viol are per-lane (per-instance) predicates.
+template <class M>
+__device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol, bool constrained, double& J_out, double& viol_out) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    const Layout& L = I.L;
+    const int T = L.T, N = T - 1;
+    const double* X = I.g + Xo; const double* U = I.g + Uo;
+    double* cbuf = I.g + L.c; double* act = I.g + L.act;
+    const double* lamb = I.g + L.lam; const double* rho = I.g + L.rho;
+    const double* W = I.g + L.w;
+    double Jp = 0.0, vp = 0.0;
+    for (int t = (upd_J || upd_viol) ? I.j : T; t < T; t += 16) {
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(W, t, w);
+        double xt[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) xt[i] = X[t * n + i];
+        if (t < N) {
+            double ut[m];
+#pragma unroll
+            for (int i = 0; i < m; ++i) ut[i] = U[t * m + i];
+            if (upd_J) Jp += M::cost_s(xt, ut, w);
+            if constexpr (ncs > 0) {
+                if (constrained) {
+                    double cv[ncs];
+                    M::con_s(xt, ut, w, cv);
+                    const int off = t * ncs;
+                    if (upd_J) {
+                        double dot = 0.0, pen = 0.0;
+#pragma unroll
+                        for (int i = 0; i < ncs; ++i) {
+                            const double lam = lamb[off + i];
+                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
+                            act[off + i] = inactive ? 0.0 : 1.0;
+                            dot += lam * cv[i];
+                            if (!inactive) pen += 0.5 * rho[off + i] * (cv[i] * cv[i]);
+                        }
+                        Jp += dot;
+                        Jp += pen;
+                    }
+                    if (upd_viol) {
+#pragma unroll
+                        for (int i = 0; i < ncs; ++i) {
+                            cbuf[off + i] = cv[i];
+                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
+                        }
+                    }
+                }
+            }
+        } else {
+            if (upd_J) Jp += M::cost_t(xt, w);
+            if constexpr (nct > 0) {
+                if (constrained) {
+                    double cv[nct];
+                    M::con_t(xt, w, cv);
+                    const int off = N * ncs;
+                    if (upd_J) {
+                        double dot = 0.0, pen = 0.0;
+#pragma unroll
+                        for (int i = 0; i < nct; ++i) {
+                            const double lam = lamb[off + i];
+                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
+                            act[off + i] = inactive ? 0.0 : 1.0;
+                            dot += lam * cv[i];
+                            if (!inactive) pen += 0.5 * rho[off + i] * (cv[i] * cv[i]);
+                        }
+                        Jp += dot;
+                        Jp += pen;
+                    }
+                    if (upd_viol) {
+#pragma unroll
+                        for (int i = 0; i < nct; ++i) {
+                            cbuf[off + i] = cv[i];
+                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    J_out = row_sum(Jp);
+    viol_out = row_max(vp);
+    __syncthreads();
+}
+
+// cost!(data, problem, mode) for the instances with `act` set — src/data/methods.jl:13-30 (Q2: the violations buffer
+// and max_violation are always taken at problem.states; one pass when states == nominal bitwise).
+template <class M>
+__device__ void cost_bang(PInst<M>& I, bool act, bool mode_current, bool constrained) {
+    const Layout& L = I.L;
+    const bool one_pass = mode_current || I.states_eq_nominal || !constrained;
+    {
+        double J, v;
+        cost_pass<M>(I, mode_current ? L.x : L.xb, mode_current ? L.u : L.ub, act, act && one_pass, constrained, J, v);
+        if (act) {
+            I.objective = J;
+            if (one_pass && constrained) I.max_violation = v;
+        }
+    }
+    const bool second = act && !one_pass;
+    if (__any(second)) {
+        double J, v;
+        cost_pass<M>(I, L.x, L.u, false, second, constrained, J, v);
+        if (second) I.max_violation = v;
+    }
+}
+
+// -------------------------------------------------------------- gradients! (row mapping, one timestep per lane of a row)
+// Everything streams to the HBM block, so only what changes is touched: the Jacobians are written (`.=`), the cost
+// Hessians and the Gauss-Newton AL terms accumulate (`.+=`, Q1) through the generated accumulators that visit only the
+// structurally non-zero entries (M::cost_*_hess_acc, M::al_s / M::al_t — adding an exact 0.0 is the identity).
+template <class M>
+__device__ void gradients(PInst<M>& I, bool act, bool constrained) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    const Layout& L = I.L;
+    const int T = L.T, N = T - 1;
+    double* g = I.g;
+    if (act) {
+        for (int t = I.j; t < T; t += 16) {                              // Hessians accumulate: each timestep exactly once
+            double w[cdim<M::NW>::v];
+            load_w<M::NW>(g + L.w, t, w);
+            double xt[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xt[i] = g[L.xb + t * n + i];
+            double* gxx = g + L.gxx + t * n * n;
+            if (t < N) {
+                double ut[m];
+#pragma unroll
+                for (int i = 0; i < m; ++i) ut[i] = g[L.ub + t * m + i];
+                M::dyn_jac_mem(xt, ut, w, g + L.fx + t * n * n, g + L.fu + t * n * m);     // `.=`  (src/dynamics.jl:45-46)
+                double gx[n], gu[m];
+                M::cost_s_grad(xt, ut, w, gx, gu);                                          // `.=`  (src/costs.jl:61,65)
+                double* guu = g + L.guu + t * m * m;
+                double* gux = g + L.gux + t * m * n;
+                M::cost_s_hess_acc(xt, ut, w, gxx, guu, gux);                               // `.+=` (src/costs.jl:74-80)
+                if constexpr (ncs > 0) {
+                    if (constrained) {                                                      // src/gradients.jl:54-80
+                        double ct[ncs], ir[ncs];
+                        const int off = t * ncs;
+#pragma unroll
+                        for (int i = 0; i < ncs; ++i) {
+                            ir[i] = g[L.rho + off + i] * g[L.act + off + i];
+                            ct[i] = g[L.lam + off + i] + ir[i] * g[L.c + off + i];
+                        }
+                        M::al_s(xt, ut, w, ct, ir, gx, gu, gxx, guu, gux);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < n; ++i) g[L.gx + t * n + i] = gx[i];
+#pragma unroll
+                for (int i = 0; i < m; ++i) g[L.gu + t * m + i] = gu[i];
+            } else {
+                double gx[n];
+                M::cost_t_grad(xt, w, gx);
+                M::cost_t_hess_acc(xt, w, gxx);
+                if constexpr (nct > 0) {
+                    if (constrained) {
+                        double ct[nct], ir[nct];
+                        const int off = N * ncs;
+#pragma unroll
+                        for (int i = 0; i < nct; ++i) {
+                            ir[i] = g[L.rho + off + i] * g[L.act + off + i];
+                            ct[i] = g[L.lam + off + i] + ir[i] * g[L.c + off + i];
+                        }
+                        M::al_t(xt, w, ct, ir, gx, gxx);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < n; ++i) g[L.gx + t * n + i] = gx[i];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------- backward_pass! + lagrangian_gradient! on all four MFMA blocks
+// Block beta runs the recursion of instance beta (the one-wave recursion of ilqr_device.hpp, ROLE 0). The right-hand side
+// of k shares K's triangular solve through the spare rows m..2m-1 of the block (K occupies rows 0..m-1).
+// act_blk: per-lane predicate (instance beta takes part). Returns the per-instance ‖∇L‖∞ and potrf info in the ROW mapping.
+template <class M>
+__device__ void backward_pass(PInst<M>& I, unsigned mask, double& gnorm_row, int& info_row) {
+    constexpr int n = M::NX, m = M::NU;
+    static_assert(n <= 4 && m <= 2, "packed Riccati step: nx <= 4, nu <= 2");
+    const Layout& L = I.L;
+    const int lane = I.lane, r = I.r, c = I.c, N = L.T - 1;
+    const bool on = I.valid_blk && ((mask >> I.beta) & 1u);
+    double* g = I.gb;
+    const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n, vmm = on && r < m && c < m;
+    const bool vn1 = on && c == 0 && r < n, vm1 = on && c == 0 && r < m;
+    const double* zero = g + L.gzero;
+    double* trash = g + L.gzero + 1;
+    // operand pointers: base + t * stride (non-negative offsets), padding lanes read the block's 0.0 with stride 0
+    const double* bfx = vnn ? g + L.fx + c * n + r : zero;    const int sfx = vnn ? n * n : 0;
+    const double* bfu = vnm ? g + L.fu + c * n + r : zero;    const int sfu = vnm ? n * m : 0;
+    const double* bgx = vn1 ? g + L.gx + r : zero;            const int sgx = vn1 ? n : 0;
+    const double* bgu = vm1 ? g + L.gu + r : zero;            const int sgu = vm1 ? m : 0;
+    const double* bxx = vnn ? g + L.gxx + c * n + r : zero;   const int sxx = vnn ? n * n : 0;
+    const double* buu = vmm ? g + L.guu + c * m + r : zero;   const int suu = vmm ? m * m : 0;
+    const double* bux = vmn ? g + L.gux + c * m + r : zero;   const int sux = vmn ? m * n : 0;
+    double* qK = vmn ? g + L.K + c * m + r : trash;           const int sK = vmn ? m * n : 0;
+    double* qk = vm1 ? g + L.k + r : trash;                   const int sk = vm1 ? m : 0;
+    double* qLu = vm1 ? g + L.Lu + r : trash;
+    double* qLx = vn1 ? g + L.Lx + r : trash;                 const int sLx = vn1 ? n : 0;
+
+    double P = vnn ? g[L.gxx + N * n * n + c * n + r] : 0.0;            // P[H] .= gxx[H]  (:39)
+    double p = vn1 ? g[L.gx + N * n + r] : 0.0;                         // p[H] .= gx[H]   (:40)
+    double gmax = 0.0;
+    int pinfo = 0;
+    struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
+    auto fetch = [&](Opnd& o, int tp) {
+        o.gxx = bxx[tp * sxx]; o.guu = buu[tp * suu]; o.gux = bux[tp * sux];
+        o.fx = bfx[tp * sfx]; o.fu = bfu[tp * sfu]; o.gx = bgx[tp * sgx]; o.gu = bgu[tp * sgu];
+    };
+    const int rr = (m == 2) ? (r & 1) : 0;                              // row inside a right-hand-side set
+    // potrs('U') of the right-hand sides held as Y(r, c): K in rows 0..m-1, k (column 0) in rows m..2m-1   (:70-75)
+    auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
+        if (m == 1 && info == 0) {
+            Y = Y / Uc[0];                                              // see ilqr_device.hpp: 1x1 shortcut
+        } else {
+#pragma unroll
+            for (int i = 0; i < m; ++i) {                               // U^T y = b
+#pragma unroll
+                for (int l = 0; l < i; ++l) {
+                    const double yl = from_lane_minus16_odd_rows(Y);    // m == 2: row 1 <- row 0, row 3 <- row 2
+                    const double v = Y - Uc[i * m + l] * yl;
+                    Y = (rr == i) ? v : Y;
+                }
+                const double qv = Y * Ur[i];
+                Y = (rr == i) ? qv : Y;
+            }
+#pragma unroll
+            for (int i = m - 1; i >= 0; --i) {                          // U x = y
+#pragma unroll
+                for (int l = i + 1; l < m; ++l) {
+                    const double xl = from_lane_plus16_even_rows(Y);    // m == 2: row 0 <- row 1, row 2 <- row 3
+                    const double v = Y - Uc[l * m + i] * xl;
+                    Y = (rr == i) ? v : Y;
+                }
+                const double qv = Y * Ur[i];
+                Y = (rr == i) ? qv : Y;
+            }
+        }
+        return Y * -1.0;                                                // K .*= -1, k .*= -1
+    };
+    const int blk0 = (lane & 12);                                       // lane of element (0, 0) of this block
+    auto riccati_step = [&](const Opnd& o, int t) {
+        ILQR_ISA_MARK("riccati_step", 3);
+        const double fx = o.fx, fu = o.fu;
+        // (:52-64)
+        const double W = mfma444(P, fx, 0.0);
+        const double Wu = mfma444(P, fu, 0.0);
+        const double Qxx = mfma444(W, fx, o.gxx);
+        const double Qux = mfma444(Wu, fx, o.gux);
+        const double Quu = mfma444(Wu, fu, o.guu);
+        const double Qx = mfma444(fx, p, o.gx);                         // (:44-49)
+        const double Qu = mfma444(fu, p, o.gu);
+        // potrf('U') of the block's Quu: element (i, j) lives on lane j + 4*beta + 16*i   (:68-69)
+        double Uc[m * m];
+#pragma unroll
+        for (int jj = 0; jj < m; ++jj)
+#pragma unroll
+            for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;
+        int info = 0;
+        double Ur[m];
+        if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
+        else info = potrf_U<m>(Uc, Ur);
+        if (m == 1 && info != 0) potrf_U<m>(Uc, Ur);
+        if (info != 0 && pinfo == 0) pinfo = info;
+        // right-hand sides: Qux in rows 0..m-1, Qu (column 0) moved down into rows m..2m-1
+        const double Qu_dn = (m == 1) ? from_lane_minus16_odd_rows(Qu) : from_lane_minus32(Qu);
+        const bool krow = (r >= m && r < 2 * m && c == 0);
+        const double Y = solve(krow ? Qu_dn : Qux, Uc, Ur, info);
+        const double K = (r < m) ? Y : 0.0;                             // rows >= m of K must read as zero in the products
+        const double kY = krow ? Y : 0.0;
+        const double k_up = (m == 1) ? from_lane_plus16_even_rows(kY) : from_lane_plus32(kY);   // back to rows 0..m-1, column 0
+        const double k = (r < m && c == 0) ? k_up : 0.0;
+        const double uxt = mfma444(Quu, K, 0.0);                        // ux_tmp = Quu K   (:79)
+        double Pn = mfma444(K, uxt, 0.0);                               // (:81-84)
+        Pn = mfma444(K, Qux, Pn);
+        Pn = mfma444(Qux, K, Pn);
+        Pn += Qxx;
+        double pn = mfma444(uxt, k, 0.0);                               // (:86-89)
+        pn = mfma444(K, Qu, pn);
+        pn = mfma444(Qux, k, pn);
+        pn += Qx;
+        const double Lx = Qx - pn;                                      // src/solve.jl:73-81
+        gmax = nanmax(gmax, fabs(Lx));
+        gmax = nanmax(gmax, fabs(Qu));
+        qK[t * sK] = K; qk[t * sk] = k; qLu[t * sk] = Qu; qLx[t * sLx] = Lx;
+        P = Pn; p = pn;
+    };
+    Opnd A, B;
+    if (N > 0) fetch(A, N - 1);
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {                                            // (:42)
+        fetch(B, t - 1);
+        riccati_step(A, t);
+        if (t >= 2) fetch(A, t - 2);
+        riccati_step(B, t - 1);
+    }
+    if (t == 0) riccati_step(A, 0);
+    // ‖∇L‖∞ over the block (padding lanes carry exact zeros), then block -> row mapping (instance q = block q)
+    double gm = (on && c == 0) ? gmax : 0.0;
+    { double w_; w_ = __shfl_xor(gm, 16); gm = nanmax(gm, w_); w_ = __shfl_xor(gm, 32); gm = nanmax(gm, w_); }
+    gnorm_row = shfl_d(gm, 4 * I.q);
+    info_row = __shfl(pinfo, 4 * I.q);
+    __syncthreads();
+}
+
+// ------------------------------------------------- gradients! FUSED into backward_pass! (the B phase of the state machine)
+// The Riccati recursion walks time backwards in chunks of 16 steps. Each chunk is first linearised time-parallel in the ROW
+// mapping (lane j of row q: timestep 16*chunk + j of instance q) — dynamics Jacobians and cost gradients go to a 13 KB LDS
+// buffer of the wave and never touch HBM, the accumulated Hessians are updated in place in the HBM block (Q1) — and then
+// consumed by the four MFMA blocks. HBM sees x̄, ū (read), the Hessians (read-modify-write, then an L2-hit read) and
+// K, k, ∇L (write): 46 KB per instance and iteration for the acrobot instead of 106 KB for separate sweeps.
+// The Armijo slope  Δ = ∇Lᵀ·Δz  (src/forward_pass.jl:19-20, src/data/methods.jl:42-54) rides along as the ADJOINT of the
+// sensitivity recursion — with  w_t = ∇L_u,t + fu_tᵀ ν_{t+1},  ν_t = ∇L_x,t + fx_tᵀ ν_{t+1} + K_tᵀ w_t,  ν_H = 0:
+// Δ = Σ_t w_tᵀ k_t  — the same bilinear form summed in the opposite order (four MFMAs per step on operands that are in
+// registers anyway), which saves the forward sweep over fx, fu, K, k, ∇L altogether.
+template <class M>
+struct PkLds {
+    static constexpr int n = M::NX, m = M::NU;
+    static constexpr int SFX = (n * n) | 1, SFU = (n * m) | 1, SGX = n | 1, SGU = m | 1;      // odd strides: conflict-free lane-per-step writes
+    static constexpr int FX = 0, FU = FX + 16 * SFX, GX = FU + 16 * SFU, GU = GX + 16 * SGX, IB = GU + 16 * SGU;
+    static constexpr int TERM = 4 * IB, ZERO = TERM + 4 * n, total = ZERO + 2;
+};
+
+// One stage timestep of gradients!: a real function, so that the (large) symbolic Jacobian code gets its own register
+// allocation instead of pushing the Riccati state of the caller into scratch.
+struct LinArgs { double* gr; int xb, ub, w, gxx, guu, gux, rho, act, lam, c, t, lds_row, j, constrained; };
+template <class M>
+__attribute__((noinline)) __device__ void linearise_stage(LinArgs a) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS;
+    typedef PkLds<M> LD;
+    extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+    double* gr = a.gr;
+    double* lrow = pk_lds + a.lds_row;
+    const int t = a.t;
+    double w[cdim<M::NW>::v];
+    load_w<M::NW>(gr + a.w, t, w);
+    double xt[n], ut[m];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xt[i] = gr[a.xb + t * n + i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) ut[i] = gr[a.ub + t * m + i];
+    M::dyn_jac_mem(xt, ut, w, lrow + LD::FX + a.j * LD::SFX, lrow + LD::FU + a.j * LD::SFU);   // `.=` (src/dynamics.jl:45-46)
+    double gx[n], gu[m];
+    M::cost_s_grad(xt, ut, w, gx, gu);                                                          // `.=` (src/costs.jl:61,65)
+    double* gxx = gr + a.gxx + t * n * n;
+    double* guu = gr + a.guu + t * m * m;
+    double* gux = gr + a.gux + t * m * n;
+    M::cost_s_hess_acc(xt, ut, w, gxx, guu, gux);                                               // `.+=` (src/costs.jl:74-80)
+    if constexpr (ncs > 0) {
+        if (a.constrained) {                                                                    // src/gradients.jl:54-80
+            double ct[ncs], ir[ncs];
+            const int off = t * ncs;
+#pragma unroll
+            for (int i = 0; i < ncs; ++i) {
+                ir[i] = gr[a.rho + off + i] * gr[a.act + off + i];
+                ct[i] = gr[a.lam + off + i] + ir[i] * gr[a.c + off + i];
+            }
+            M::al_s(xt, ut, w, ct, ir, gx, gu, gxx, guu, gux);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) lrow[LD::GX + a.j * LD::SGX + i] = gx[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) lrow[LD::GU + a.j * LD::SGU + i] = gu[i];
+}
+
+template <class M>
+__device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool constrained,
+                                  double& gnorm_row, int& info_row, double& delta_row) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    typedef PkLds<M> LD;
+    static_assert(n <= 4 && m <= 2, "packed Riccati step: nx <= 4, nu <= 2");
+    extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+    const Layout& L = I.L;
+    const int lane = I.lane, r = I.r, c = I.c, N = L.T - 1;
+    const bool on = I.valid_blk && ((mask >> I.beta) & 1u);
+    double* gr = I.g;                       // row mapping block
+    double* g = I.gb;                       // block mapping block
+    double* lrow = pk_lds + I.q * LD::IB;
+    const double* lblk = pk_lds + I.beta * LD::IB;
+    if (lane == 0) { pk_lds[LD::ZERO] = 0.0; pk_lds[LD::ZERO + 1] = 0.0; }
+    // ---- terminal linearisation (t = N): gx[N] `.=`, gxx[N] `.+=` (src/costs.jl:57-84, src/gradients.jl:54-67)
+    if (act_row && I.j == 0) {
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(gr + L.w, N, w);
+        double xt[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) xt[i] = gr[L.xb + N * n + i];
+        double gx[n];
+        M::cost_t_grad(xt, w, gx);
+        double* gxx = gr + L.gxx + N * n * n;
+        M::cost_t_hess_acc(xt, w, gxx);
+        if constexpr (nct > 0) {
+            if (constrained) {
+                double ct[nct], ir[nct];
+                const int off = N * ncs;
+#pragma unroll
+                for (int i = 0; i < nct; ++i) {
+                    ir[i] = gr[L.rho + off + i] * gr[L.act + off + i];
+                    ct[i] = gr[L.lam + off + i] + ir[i] * gr[L.c + off + i];
+                }
+                M::al_t(xt, w, ct, ir, gx, gxx);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) { pk_lds[LD::TERM + I.q * n + i] = gx[i]; gr[L.gx + N * n + i] = gx[i]; }
+    }
+    __syncthreads();
+    const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n, vmm = on && r < m && c < m;
+    const bool vn1 = on && c == 0 && r < n, vm1 = on && c == 0 && r < m;
+    const double* zero = g + L.gzero;
+    double* trash = g + L.gzero + 1;
+    const double* lz = pk_lds + LD::ZERO;
+    // LDS operands of the chunk (per-lane base + step * stride; padding lanes read the LDS zero with stride 0)
+    const double* lfx = vnn ? lblk + LD::FX + c * n + r : lz;     const int sfx = vnn ? LD::SFX : 0;
+    const double* lfu = vnm ? lblk + LD::FU + c * n + r : lz;     const int sfu = vnm ? LD::SFU : 0;
+    const double* lgx = vn1 ? lblk + LD::GX + r : lz;             const int sgx = vn1 ? LD::SGX : 0;
+    const double* lgu = vm1 ? lblk + LD::GU + r : lz;             const int sgu = vm1 ? LD::SGU : 0;
+    // HBM operands: accumulated Hessians (just updated by this wave: L2 hits), results
+    const double* bxx = vnn ? g + L.gxx + c * n + r : zero;   const int sxx = vnn ? n * n : 0;
+    const double* buu = vmm ? g + L.guu + c * m + r : zero;   const int suu = vmm ? m * m : 0;
+    const double* bux = vmn ? g + L.gux + c * m + r : zero;   const int sux = vmn ? m * n : 0;
+    double* qK = vmn ? g + L.K + c * m + r : trash;           const int sK = vmn ? m * n : 0;
+    double* qk = vm1 ? g + L.k + r : trash;                   const int sk = vm1 ? m : 0;
+    double* qLu = vm1 ? g + L.Lu + r : trash;
+    double* qLx = vn1 ? g + L.Lx + r : trash;                 const int sLx = vn1 ? n : 0;
+
+    double P = vnn ? g[L.gxx + N * n * n + c * n + r] : 0.0;            // P[H] .= gxx[H]  (:39)
+    double p = vn1 ? pk_lds[LD::TERM + I.beta * n + r] : 0.0;           // p[H] .= gx[H]   (:40)
+    double nu = 0.0, dacc = 0.0;                                        // adjoint of the sensitivity recursion, Δ accumulator
+    double gmax = 0.0;
+    int pinfo = 0;
+    const int rr = (m == 2) ? (r & 1) : 0;
+    auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
+        if (m == 1 && info == 0) {
+            Y = Y / Uc[0];
+        } else {
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+#pragma unroll
+                for (int l = 0; l < i; ++l) {
+                    const double yl = from_lane_minus16_odd_rows(Y);
+                    const double v = Y - Uc[i * m + l] * yl;
+                    Y = (rr == i) ? v : Y;
+                }
+                const double qv = Y * Ur[i];
+                Y = (rr == i) ? qv : Y;
+            }
+#pragma unroll
+            for (int i = m - 1; i >= 0; --i) {
+#pragma unroll
+                for (int l = i + 1; l < m; ++l) {
+                    const double xl = from_lane_plus16_even_rows(Y);
+                    const double v = Y - Uc[l * m + i] * xl;
+                    Y = (rr == i) ? v : Y;
+                }
+                const double qv = Y * Ur[i];
+                Y = (rr == i) ? qv : Y;
+            }
+        }
+        return Y * -1.0;
+    };
+    const int blk0 = (lane & 12);
+    struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
+    auto fetch = [&](Opnd& o, int t, int sl) {
+        o.gxx = bxx[t * sxx]; o.guu = buu[t * suu]; o.gux = bux[t * sux];
+        o.fx = lfx[sl * sfx]; o.fu = lfu[sl * sfu]; o.gx = lgx[sl * sgx]; o.gu = lgu[sl * sgu];
+    };
+    auto riccati_step = [&](const Opnd& o, int t) {
+        ILQR_ISA_MARK("riccati_step", 4);
+        const double fx = o.fx, fu = o.fu;
+        const double W = mfma444(P, fx, 0.0);                           // (:52-64)
+        const double Wu = mfma444(P, fu, 0.0);
+        const double Qxx = mfma444(W, fx, o.gxx);
+        const double Qux = mfma444(Wu, fx, o.gux);
+        const double Quu = mfma444(Wu, fu, o.guu);
+        const double Qx = mfma444(fx, p, o.gx);                         // (:44-49)
+        const double Qu = mfma444(fu, p, o.gu);
+        double Uc[m * m];
+#pragma unroll
+        for (int jj = 0; jj < m; ++jj)
+#pragma unroll
+            for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;   // (:68-69)
+        int info = 0;
+        double Ur[m];
+        if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
+        else info = potrf_U<m>(Uc, Ur);
+        if (m == 1 && info != 0) potrf_U<m>(Uc, Ur);
+        if (info != 0 && pinfo == 0) pinfo = info;
+        const double Qu_dn = (m == 1) ? from_lane_minus16_odd_rows(Qu) : from_lane_minus32(Qu);
+        const bool krow = (r >= m && r < 2 * m && c == 0);
+        const double Y = solve(krow ? Qu_dn : Qux, Uc, Ur, info);       // (:70-75)
+        const double K = (r < m) ? Y : 0.0;
+        const double kY = krow ? Y : 0.0;
+        const double k_up = (m == 1) ? from_lane_plus16_even_rows(kY) : from_lane_plus32(kY);
+        const double k = (r < m && c == 0) ? k_up : 0.0;
+        const double uxt = mfma444(Quu, K, 0.0);                        // (:79)
+        double Pn = mfma444(K, uxt, 0.0);                               // (:81-84)
+        Pn = mfma444(K, Qux, Pn);
+        Pn = mfma444(Qux, K, Pn);
+        Pn += Qxx;
+        double pn = mfma444(uxt, k, 0.0);                               // (:86-89)
+        pn = mfma444(K, Qu, pn);
+        pn = mfma444(Qux, k, pn);
+        pn += Qx;
+        const double Lx = Qx - pn;                                      // src/solve.jl:73-81
+        gmax = nanmax(gmax, fabs(Lx));
+        gmax = nanmax(gmax, fabs(Qu));
+        // adjoint sensitivity step: w = ∇L_u + fuᵀν', Δ += wᵀk, ν = ∇L_x + fxᵀν' + Kᵀw
+        const double wv = mfma444(fu, nu, Qu);
+        dacc = mfma444(wv, k, dacc);
+        double nun = mfma444(fx, nu, Lx);
+        nun = mfma444(K, wv, nun);
+        nu = nun;
+        qK[t * sK] = K; qk[t * sk] = k; qLu[t * sk] = Qu; qLx[t * sLx] = Lx;
+        P = Pn; p = pn;
+    };
+    for (int ch = (N + 15) / 16 - 1; ch >= 0; --ch) {
+        const int t0 = 16 * ch, cnt = (N - t0) < 16 ? (N - t0) : 16;
+        // ---- linearise timesteps t0 .. t0 + cnt - 1, one per lane of a row
+        if (act_row && I.j < cnt) {
+            LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + I.j, I.q * LD::IB, I.j, constrained ? 1 : 0};
+            linearise_stage<M>(la);
+        }
+        __syncthreads();
+        // ---- Riccati steps of the chunk, last timestep first   (:42)
+        Opnd A, B;
+        int sl = cnt - 1;
+        fetch(A, t0 + sl, sl);
+        for (; sl >= 1; sl -= 2) {
+            fetch(B, t0 + sl - 1, sl - 1);
+            riccati_step(A, t0 + sl);
+            if (sl >= 2) fetch(A, t0 + sl - 2, sl - 2);
+            riccati_step(B, t0 + sl - 1);
+        }
+        if (sl == 0) riccati_step(A, t0);
+        __syncthreads();                      // the chunk buffer is free again
+    }
+    double gm = (on && c == 0) ? gmax : 0.0;
+    { double w_; w_ = __shfl_xor(gm, 16); gm = nanmax(gm, w_); w_ = __shfl_xor(gm, 32); gm = nanmax(gm, w_); }
+    gnorm_row = shfl_d(gm, 4 * I.q);
+    info_row = __shfl(pinfo, 4 * I.q);
+    delta_row = shfl_d(dacc, 4 * I.q);
+    __syncthreads();
+}
+
+// ------------------------------------------ trajectory_sensitivities + gradient' * dz (block mapping, MFMA forward sweep)
+template <class M>
+__device__ double delta_sweep(PInst<M>& I, unsigned mask) {
+    constexpr int n = M::NX, m = M::NU;
+    const Layout& L = I.L;
+    const int r = I.r, c = I.c, N = L.T - 1;
+    const bool on = I.valid_blk && ((mask >> I.beta) & 1u);
+    const double* g = I.gb;
+    const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n;
+    const bool vn1 = on && c == 0 && r < n, vm1 = on && c == 0 && r < m;
+    const double* zero = g + L.gzero;
+    // transposed operands straight from memory: mfma(A <- X^T, B <- v, C) = X v + C
+    const double* pKT = vnm ? g + L.K + r * m + c : zero;     const int sKT = vnm ? m * n : 0;    // K^T(r,c) = K(c,r)
+    const double* pfxT = vnn ? g + L.fx + r * n + c : zero;   const int sfxT = vnn ? n * n : 0;
+    const double* pfuT = vmn ? g + L.fu + r * n + c : zero;   const int sfuT = vmn ? n * m : 0;
+    const double* pkc = vm1 ? g + L.k + r : zero;             const int skc = vm1 ? m : 0;
+    const double* pLx = vn1 ? g + L.Lx + r : zero;            const int sLx = vn1 ? n : 0;
+    const double* pLu = vm1 ? g + L.Lu + r : zero;
+    struct Ops { double KT, fxT, fuT, kc, Lx, Lu; };
+    auto fetch = [&](Ops& o, int t) {
+        o.KT = pKT[t * sKT]; o.fxT = pfxT[t * sfxT]; o.fuT = pfuT[t * sfuT]; o.kc = pkc[t * skc]; o.Lx = pLx[t * sLx]; o.Lu = pLu[t * skc];
+    };
+    double zx = 0.0, dacc = 0.0;
+    auto step = [&](const Ops& o) {
+        ILQR_ISA_MARK("delta_step", 3);
+        const double zu = mfma444(o.KT, zx, o.kc);                      // Δu = k + K Δx
+        const double fz = mfma444(o.fxT, zx, 0.0);                      // fx Δx
+        dacc = mfma444(o.Lx, zx, dacc);                                 // += ∇L_x · Δx
+        dacc = mfma444(o.Lu, zu, dacc);                                 // += ∇L_u · Δu
+        zx = mfma444(o.fuT, zu, fz);                                    // Δx⁺ = fu Δu + fx Δx
+    };
+    Ops A, B;
+    if (N > 0) fetch(A, 0);
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+        fetch(B, t + 1);
+        step(A);
+        if (t + 2 < N) fetch(A, t + 2);
+        step(B);
+    }
+    if (t < N) step(A);
+    return shfl_d(dacc, 4 * I.q);                                       // element (0,0) of block q -> row q
+}
+
+// ------------------------------------------------------------- rollout! (row mapping, cooperative inside a row)
+// alpha is per instance. Lane j == 0 of an active row stores the trial trajectory.
+template <class M>
+__device__ void rollout(PInst<M>& I, bool act, double alpha) {
+    constexpr int n = M::NX, m = M::NU;
+    const Layout& L = I.L;
+    const int N = L.T - 1;
+    double* g = I.g;
+    const bool wr = act && I.j == 0;
+    double* px = wr ? g + L.x : g + L.gzero + 1;   const int sx = wr ? n : 0;
+    double* pu = wr ? g + L.u : g + L.gzero + 1;   const int su = wr ? m : 0;
+    double xt[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xt[i] = g[L.xb + i];                    // (:19)
+    if (wr) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) g[L.x + i] = xt[i];
+    }
+    struct Ops { double K[m * n], k[m], ub[m], xb[n]; };
+    auto fetch = [&](Ops& o, int t) {
+#pragma unroll
+        for (int i = 0; i < m * n; ++i) o.K[i] = g[L.K + t * m * n + i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) { o.k[i] = g[L.k + t * m + i]; o.ub[i] = g[L.ub + t * m + i]; }
+#pragma unroll
+        for (int i = 0; i < n; ++i) o.xb[i] = g[L.xb + t * n + i];
+    };
+    auto step = [&](const Ops& o, int t, const double (&xin)[n], double (&xout)[n]) {
+        ILQR_ISA_MARK("rollout_step", 3);
+        double ut[m];
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            double v = o.k[i] * alpha;                                  // (:24-25)
+            v += o.ub[i];                                               // (:26)
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < n; ++jj) {
+                a1 += o.K[jj * m + i] * xin[jj];
+                a2 += o.K[jj * m + i] * o.xb[jj];
+            }
+            v += a1;                                                    // (:27)
+            v += -1.0 * a2;                                             // (:28)
+            ut[i] = v;
+        }
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(g + L.w, t, w);
+        M::template dyn_wave<Row16BC>(I.j, xin, ut, w, xout);           // (:29)
+#pragma unroll
+        for (int i = 0; i < m; ++i) pu[t * su + (wr ? i : 0)] = ut[i];
+#pragma unroll
+        for (int i = 0; i < n; ++i) px[(t + 1) * sx + (wr ? i : 0)] = xout[i];
+    };
+    Ops A, B;
+    double xo[n];
+    if (N > 0) fetch(A, 0);
+    int t = 0;
+    for (; t + 1 < N; t += 2) {
+        fetch(B, t + 1);
+        step(A, t, xt, xo);
+        if (t + 2 < N) fetch(A, t + 2);
+        step(B, t + 1, xo, xt);
+    }
+    if (t < N) step(A, t, xt, xo);
+    __syncthreads();
+}
+
+// The fused B phase keeps fx, fu, gx, gu on chip. When an instance LEAVES its inner loop they are written out once, so that
+// jacobian_* / gradient_* in the workspace hold the last linearisation exactly as after the other kernels (and as
+// solver.problem.model / .objective do in the reference). Same functions, same inputs, no Hessian accumulation.
+template <class M>
+__attribute__((noinline)) __device__ void materialise_stage(LinArgs a, int fx_off, int fu_off, int gx_off, int gu_off) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS;
+    double* gr = a.gr;
+    const int t = a.t;
+    double w[cdim<M::NW>::v];
+    load_w<M::NW>(gr + a.w, t, w);
+    double xt[n], ut[m];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xt[i] = gr[a.xb + t * n + i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) ut[i] = gr[a.ub + t * m + i];
+    M::dyn_jac_mem(xt, ut, w, gr + fx_off + t * n * n, gr + fu_off + t * n * m);
+    double gx[n], gu[m];
+    M::cost_s_grad(xt, ut, w, gx, gu);
+    if constexpr (ncs > 0) {
+        if (a.constrained) {
+            double ct[ncs], ir[ncs], dxx[n * n], duu[m * m], dux[m * n];
+            const int off = t * ncs;
+#pragma unroll
+            for (int i = 0; i < ncs; ++i) {
+                ir[i] = gr[a.rho + off + i] * gr[a.act + off + i];
+                ct[i] = gr[a.lam + off + i] + ir[i] * gr[a.c + off + i];
+            }
+#pragma unroll
+            for (int i = 0; i < n * n; ++i) dxx[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < m * m; ++i) duu[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < m * n; ++i) dux[i] = 0.0;
+            M::al_s(xt, ut, w, ct, ir, gx, gu, dxx, duu, dux);       // only the gradient part is kept
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) gr[gx_off + t * n + i] = gx[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) gr[gu_off + t * m + i] = gu[i];
+}
+
+// 16 lanes of a row fill / copy a range of the row's instance block
+template <class M>
+__device__ __forceinline__ void row_fill(PInst<M>& I, bool act, int off, int len, double v) {
+    if (act) for (int i = I.j; i < len; i += 16) I.g[off + i] = v;
+}
+template <class M>
+__device__ __forceinline__ void row_copy(PInst<M>& I, bool act, int dst, int src, int len) {
+    if (act) for (int i = I.j; i < len; i += 16) I.g[dst + i] = I.g[src + i];
+}
+
+}  // namespace pk
+
+// solve!(solver) for four instances per wave — src/solve.jl:1-54, 88-143 as a per-instance state machine
+template <class M>
+__global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS;
+    using namespace pk;
+    PInst<M> I;
+    const Layout& L = a.L;
+    I.L = L;
+    I.lane = threadIdx.x; I.q = I.lane >> 4; I.j = I.lane & 15; I.beta = (I.lane >> 2) & 3; I.r = I.lane >> 4; I.c = I.lane & 3;
+    const int b_row = blockIdx.x * 4 + I.q, b_blk = blockIdx.x * 4 + I.beta;
+    I.valid_row = b_row < a.B; I.valid_blk = b_blk < a.B;
+    I.g = a.ws + (size_t)(I.valid_row ? b_row : a.B - 1) * (size_t)L.stride;
+    I.gb = a.ws + (size_t)(I.valid_blk ? b_blk : a.B - 1) * (size_t)L.stride;
+    I.trace = a.trace ? a.trace + (size_t)(I.valid_row ? b_row : 0) * (size_t)a.trace_cap * TRACE_W : nullptr;
+    I.trace_cap = a.trace_cap; I.trace_len = 0;
+    const ilqr_options& opt = a.opt;
+    const bool constrained = a.constrained != 0, al_outer = constrained;
+    const int T = L.T, N = T - 1, C = L.C;
+    double* scal = I.g + L.scal;
+    I.objective = scal[S_OBJECTIVE]; I.max_violation = scal[S_MAX_VIOLATION]; I.step_size = scal[S_STEP_SIZE];
+    I.gradient_norm = scal[S_GRADIENT_NORM]; I.status = (int)scal[S_STATUS]; I.iterations = (int)scal[S_ITERATIONS];
+    I.states_eq_nominal = (int)scal[S_STATES_EQ_NOMINAL];
+    I.potrf_info = 0; I.rollouts = 0; I.outer = 0; I.delta = 0.0; I.delta_next = 0.0; I.obj_prev = 0.0; I.J_prev = 0.0; I.it = 0; I.trial = 1; I.needB = 0; I.leaving = 0;
+    const bool live = I.valid_row;
+    if (al_outer) {
+        // reset!(solver.data) (src/solve.jl:93); λ ← 0, ρ ← ρ0 (:96-103)
+        I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
+        row_fill<M>(I, live, L.Lx, N * n, 0.0);
+        row_fill<M>(I, live, L.Lu, N * m, 0.0);
+        row_fill<M>(I, live, L.lam, C, 0.0);
+        row_fill<M>(I, live, L.rho, C, opt.initial_constraint_penalty);
+        I.outer = 1;
+    }
+    I.state = live ? ST_INIT : ST_DONE;
+    __syncthreads();
+    const int outer_max = al_outer ? opt.max_dual_updates : 1;
+    if (outer_max < 1) I.state = ST_DONE;
+
+    // Phase-timing hook (tools/packed_phases.py; ILQR_PK_DEBUG in the environment of the library): bit 0 = run exactly
+    // max_iterations cycles in which every instance takes every phase and no trial is accepted (fixed, data-independent
+    // work); bits 1..5 = leave out the delta sweep / linearisation / Riccati pass / rollout / cost pass. Never set in product use.
+    const int dbg = a.stage;
+    int dbg_cycles = 0;
+    for (;;) {
+        if (dbg & 1) {
+            if (dbg_cycles++ >= opt.max_iterations) break;
+            if (live && dbg_cycles > 1) { I.state = ST_FORWARD; I.trial = 1; I.needB = 0; I.it = 1; }
+        }
+        // ------------------------------------------------ A: outer-loop transitions (src/solve.jl:105-126) and ilqr_solve! entry (:9-18)
+        {
+            const bool at_outer = I.state == ST_OUTER;
+            if (__any(at_outer)) {
+                cost_bang<M>(I, at_outer, false, true);                                   // cost!(mode = :nominal)   (:113)
+                const bool conv = at_outer && (I.max_violation <= opt.constraint_tolerance);   // (:117)
+                const bool upd = at_outer && !conv;
+                if (upd) {                                                                // augmented_lagrangian_update! (:120-122)
+                    double* g = I.g;
+                    for (int i = I.j; i < C; i += 16) {
+                        const int ns = N * ncs;
+                        bool ineq;
+                        if (i < ns) ineq = ncs > 0 ? ((M::INEQ_S >> (i % (ncs > 0 ? ncs : 1))) & 1ull) : false;
+                        else ineq = (M::INEQ_T >> (i - ns)) & 1ull;
+                        double lam = g[L.lam + i] + g[L.rho + i] * g[L.c + i];
+                        if (ineq) lam = nanmax(0.0, lam);
+                        g[L.lam + i] = lam;
+                        const double rv = opt.scaling_penalty * g[L.rho + i];
+                        g[L.rho + i] = (rv < opt.max_penalty || rv != rv) ? rv : opt.max_penalty;
+                    }
+                }
+                if (conv || (upd && I.outer >= outer_max)) I.state = ST_DONE;
+                else if (upd) { I.outer += 1; I.state = ST_INIT; }
+                __syncthreads();
+            }
+            const bool at_init = I.state == ST_INIT;
+            if (__any(at_init)) {
+                // reset!(problem.model); reset!(problem.objective)   (:9-10)
+                row_fill<M>(I, at_init, L.fx, N * n * n, 0.0);
+                row_fill<M>(I, at_init, L.fu, N * n * m, 0.0);
+                row_fill<M>(I, at_init, L.gx, T * n, 0.0);
+                row_fill<M>(I, at_init, L.gu, N * m, 0.0);
+                row_fill<M>(I, at_init, L.gxx, T * n * n, 0.0);
+                row_fill<M>(I, at_init, L.guu, N * m * m, 0.0);
+                row_fill<M>(I, at_init, L.gux, N * m * n, 0.0);
+                if (at_init && opt.reset_cache) { I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; }
+                __syncthreads();
+                cost_bang<M>(I, at_init, false, constrained);                             // (:14)
+                if (at_init) { I.it = 0; I.needB = 1; }
+            }
+        }
+        if (!__any(I.state != ST_DONE)) break;
+        // ------------------------------------------------ C: one line-search trial of forward_pass! (src/forward_pass.jl)
+        {
+            const bool fw = I.state == ST_FORWARD;
+            if (__any(fw)) {
+                const bool first = fw && I.trial == 1;
+                if (first) { I.status = 0; I.J_prev = I.objective; I.delta = 0.0; I.step_size = 1.0; }   // (:10, :13, :26)
+                const bool want_delta = first && opt.line_search == 1;
+                const unsigned dmask = row_mask(want_delta);
+#if ILQR_PK_FUSED
+                (void)dmask;
+                if (want_delta) I.delta = I.delta_next;                                   // (:16-20) came out of the backward pass (adjoint form)
+#else
+                if (dmask && !(dbg & 2)) {                                                // (:16-20)
+                    const double d = delta_sweep<M>(I, dmask);
+                    if (want_delta) I.delta = d;
+                }
+#endif
+                // while step_size >= min_step_size && iteration <= 25   (:28-29)
+                const bool go = fw && (I.step_size >= opt.min_step_size) && (I.trial <= 25);
+                if (__any(go)) {
+                    if (!(dbg & 16)) rollout<M>(I, go, I.step_size);                      // (:34)
+                    if (go) { I.rollouts += 1; I.states_eq_nominal = 0; }
+                    if (!(dbg & 32)) cost_bang<M>(I, go, true, constrained);              // (:36)
+                    const bool acc = go && !(dbg & 1) && (I.objective <= I.J_prev + 1.0e-4 * I.step_size * I.delta);   // (:44) NaN ⇒ reject
+                    if (__any(acc)) {                                                     // update_nominal_trajectory!
+                        row_copy<M>(I, acc, L.xb, L.x, T * n);
+                        row_copy<M>(I, acc, L.ub, L.u, N * m);
+                        __syncthreads();
+                    }
+                    if (acc) { I.states_eq_nominal = 1; I.status = 1; I.needB = 1; }
+                    if (go && !acc) { I.step_size *= 0.5; I.trial += 1; }                 // (:51)
+                }
+                // the loop ends without acceptance: the forward pass is over with status = false
+                if (fw && !I.needB && !((I.step_size >= opt.min_step_size) && (I.trial <= 25))) I.needB = 1;
+            }
+        }
+        // ------------------------------------------------ B: gradients! + backward_pass! + lagrangian_gradient!, then src/solve.jl:36-51
+        {
+            const bool nb = I.needB != 0 || ((dbg & 1) && live);
+            const bool lin = nb && (I.it == 0 || opt.line_search != 0);                   // (:16-18), (:27-33)
+            const unsigned bmask = row_mask(lin);
+            if (bmask) {
+                double gn = 0.0; int info = 0;
+#if ILQR_PK_FUSED
+                double dn = 0.0;
+                if (!(dbg & 8)) linearise_riccati<M>(I, lin, bmask, constrained, gn, info, dn);
+                if (lin) I.delta_next = dn;
+#else
+                if (!(dbg & 4)) gradients<M>(I, lin, constrained);
+                if (!(dbg & 8)) backward_pass<M>(I, bmask, gn, info);
+#endif
+                if (lin) {
+                    I.gradient_norm = gn;
+                    if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
+                }
+            }
+            if (nb && !(dbg & 1)) {
+                I.needB = 0;
+                bool end_inner = false;
+                if (I.it == 0) {
+                    I.obj_prev = I.objective;                                             // (:21)
+                    if (opt.max_iterations < 1) end_inner = true;
+                } else {
+                    I.iterations += 1;                                                    // (:39)
+                    if (I.trace != nullptr && I.trace_len < I.trace_cap && I.j == 0) {    // verbose record (:40-45)
+                        double* rw = I.trace + (size_t)I.trace_len * TRACE_W;
+                        rw[0] = (double)(al_outer ? I.outer : 0); rw[1] = (double)I.it; rw[2] = I.objective; rw[3] = I.gradient_norm;
+                        rw[4] = I.max_violation; rw[5] = I.step_size; rw[6] = (double)I.status; rw[7] = (double)I.rollouts;
+                    }
+                    I.trace_len += 1;
+                    if (I.gradient_norm < opt.lagrangian_gradient_tolerance) end_inner = true;               // (:48)
+                    else if (fabs(I.objective - I.obj_prev) < opt.objective_tolerance) end_inner = true;     // (:49)
+                    else {
+                        I.obj_prev = I.objective;
+                        if (!I.status) end_inner = true;                                  // (:50)
+                        else if (I.it >= opt.max_iterations) end_inner = true;            // (:22)
+                    }
+                }
+                if (end_inner) I.state = al_outer ? ST_OUTER : ST_DONE;
+                else { I.it += 1; I.trial = 1; I.state = ST_FORWARD; }
+#if ILQR_PK_FUSED
+                I.leaving = end_inner ? 1 : 0;
+#endif
+            }
+#if ILQR_PK_FUSED
+            if (__any(I.leaving != 0)) {       // write the last linearisation of the inner solve out (terminal gx[N] is already there)
+                if (I.leaving) {
+                    for (int t = I.j; t < N; t += 16) {
+                        LinArgs la{I.g, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t, 0, I.j, constrained ? 1 : 0};
+                        materialise_stage<M>(la, L.fx, L.fu, L.gx, L.gu);
+                    }
+                }
+                I.leaving = 0;
+                __syncthreads();
+            }
+#endif
+        }
+    }
+    __syncthreads();
+    if (live && I.j == 0) {
+        scal[S_OBJECTIVE] = I.objective; scal[S_MAX_VIOLATION] = I.max_violation;
+        scal[S_STEP_SIZE] = I.step_size; scal[S_GRADIENT_NORM] = I.gradient_norm;
+        scal[S_STATUS] = (double)I.status; scal[S_ITERATIONS] = (double)I.iterations;
+        scal[S_OUTER_ITERATIONS] = (double)(al_outer ? I.outer : 0); scal[S_POTRF_INFO] = (double)I.potrf_info;
+        scal[S_ROLLOUTS] = (double)I.rollouts; scal[S_STATES_EQ_NOMINAL] = (double)I.states_eq_nominal;
+        scal[S_DELTA] = I.delta;
+        scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
+    }
+}
+
+}  // namespace ilqr

@@ -89,6 +89,19 @@ __device__ __forceinline__ double wave_bcast(double v) {
     hi = __builtin_amdgcn_readlane(hi, I);
     return __hiloint2double(hi, lo);
 }
+// How the wave-cooperative model code (M::dyn_wave) hands a value from lane I of the cooperating group to every lane of it.
+struct WaveBC {      // group = the whole wave (one instance per wave); result is wave-uniform (SGPRs)
+    template <int I> static __device__ __forceinline__ double bcast(double v) { return wave_bcast<I>(v); }
+};
+struct Row16BC {     // group = a row of 16 lanes (four instances per wave): ds_swizzle bit mode, lane' = (lane & 0x10) | I
+    template <int I> static __device__ __forceinline__ double bcast(double v) {
+        static_assert(I < 16, "a 16-lane row cooperates on at most 16 values");
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_ds_swizzle(lo, 0x10 | (I << 5));
+        hi = __builtin_amdgcn_ds_swizzle(hi, 0x10 | (I << 5));
+        return __hiloint2double(hi, lo);
+    }
+};
 #endif
 
 }  // namespace ilqr

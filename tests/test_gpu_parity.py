@@ -323,9 +323,12 @@ def test_warm_start_resolve_and_minimal_horizon(pkg, oracle):
 
 
 def test_lds_budget_error(pkg):
-    """A horizon whose working set exceeds the 160 KiB LDS is refused loudly (no silent fallback)."""
+    """A horizon whose working set exceeds the 160 KiB LDS is served by the streaming packed kernel only: the
+    LDS-resident stage kernels refuse it loudly (no silent fallback)."""
+    sol = pkg.Solver(model="acrobot", horizon=600, batch=2)
     with pytest.raises(pkg._ffi.IlqrError, match="LDS"):
-        pkg.Solver(model="acrobot", horizon=600, batch=2)
+        sol.run_stage_("gradients")
+    sol.close()
 
 
 def test_parameters_car_obs(pkg, oracle):
@@ -694,3 +697,71 @@ def test_verbose_prints_the_reference_report(pkg, oracle, capsys):
     s2.initialize_states(pr.rollout(x1[0], ub[0])); s2.solve()
     assert abs(first_cost - s2.trace()[0].objective) <= 1e-9 * max(1.0, abs(first_cost))
     sol.close()
+
+
+# ------------------------------------------------------------------ packed kernel (four instances per wave, no LDS)
+@pytest.mark.parametrize("config,B", [("car", 7), ("acrobot51", 6), ("particle", 9), ("car_goal", 13)])
+def test_packed_kernel_ragged_batches(pkg, oracle, config, B):
+    """Batches that do not fill the last wave (B % 4 != 0) on the packed kernel, against the oracle."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.set_kernel_variant_("packed")
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=4)
+    rs = ref["stats"]
+    assert (st["iterations"] == rs["iterations"]).all() and (st["rollouts"] == rs["rollouts"]).all()
+    assert (st["outer_iterations"] == rs["outer_iterations"]).all() and (st["status"] == rs["status"]).all()
+    assert np.abs(x - ref["x"]).max() < 1e-7 and np.abs(u - ref["u"]).max() < 1e-7
+    assert np.abs(K - ref["K"]).max() <= 5e-7 * max(1.0, np.abs(ref["K"]).max())
+    assert np.allclose(st["objective"], rs["objective"], rtol=1e-8)
+    sol.close()
+
+
+def test_packed_kernel_leaves_the_last_linearisation(pkg):
+    """The packed kernel keeps fx, fu, gx, gu on chip while it iterates; when an instance leaves its inner loop they are
+    written out, so the workspace reads like after the LDS-resident kernels (solver.problem.model.jacobian_state ...)."""
+    B = 8
+    model, T, x1, ub = pkg.workloads.make_inputs("car", B)
+    out = {}
+    for v in ("latency", "packed"):
+        sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+        sol.set_kernel_variant_(v); sol.initialize_rollout_(x1, ub); sol.solve_()
+        out[v] = {name: sol.buffer(name) for name in ("jacobian_state", "jacobian_action", "gradient_state", "gradient_action",
+                                                     "hessian_state_state", "hessian_action_action", "hessian_action_state",
+                                                     "K", "k", "gradient_state_lagrangian", "gradient_action_lagrangian",
+                                                     "constraint_dual", "constraint_penalty", "violations", "active_set")}
+        sol.close()
+    for name, a in out["latency"].items():
+        b = out["packed"][name]
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max()), name
+
+
+def test_long_horizon_runs_on_the_packed_kernel(pkg, oracle):
+    """The reference has no horizon limit (src/data/problem.jl:25-46). acrobot T = 601 needs 236 KB per instance in the
+    LDS-resident kernels (> 160 KiB of a CU): the solve goes to the streaming packed kernel, the LDS variants refuse."""
+    B, T = 8, 601
+    rng = np.random.default_rng(11)
+    x1 = np.zeros((B, 4)); ub = 0.5 * rng.standard_normal((B, T - 1, 1))
+    sol = pkg.Solver(model="acrobot", horizon=T, batch=B, options=pkg.Options(verbose=0))
+    with pytest.raises(pkg._ffi.IlqrError, match="packed"):
+        sol.set_kernel_variant_("latency")
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    ref = oracle.solve_batch("acrobot", T, x1, ub, nthreads=8)
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.75, (st["iterations"], ref["stats"]["iterations"])     # 600 steps amplify rounding: a decision may flip
+    assert np.abs(x - ref["x"])[same].max() < 1e-6 and np.abs(u - ref["u"])[same].max() < 1e-6
+    assert (np.abs(x[:, -1, :] - [np.pi, 0, 0, 0]).max(1) < 5e-3)[st["max_violation"] <= 5e-3].all()
+    sol.close()
+
+
+def test_auto_variant_takes_the_packed_kernel_beyond_one_instance_per_simd(pkg):
+    B = 1536
+    model, T, x1, ub = pkg.workloads.make_inputs("car", B)
+    res = []
+    for v in ("auto", "packed"):
+        sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+        sol.set_kernel_variant_(v); sol.initialize_rollout_(x1, ub); sol.solve_()
+        res.append(sol.get_trajectory()[0]); sol.close()
+    assert np.array_equal(res[0], res[1])

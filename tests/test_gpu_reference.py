@@ -31,8 +31,10 @@ def pkg():
     return p
 
 
-def _variants(model):
-    return ["latency"] if model == "synth32" else ["latency", "throughput"]
+def _variants(model, whole_solve=False):
+    if model == "synth32":
+        return ["latency"]
+    return ["latency", "throughput", "packed"] if whole_solve else ["latency", "throughput"]
 
 
 def _set(sol, name, v):
@@ -134,7 +136,7 @@ def test_hip_whole_solve_matches_reference_fixture(pkg, case):
     d = load(case)
     T, model = d["T"], d["model"]
     ref = d["trace"]
-    for variant in _variants(model):
+    for variant in _variants(model, whole_solve=True):
         sol = pkg.Solver(model=model, horizon=T, batch=1, options=pkg.Options(verbose=0))
         sol.set_kernel_variant_(variant)
         sol.enable_trace_(ref.shape[0] + 8)
