@@ -86,7 +86,8 @@ def pmc_child(args):
     from ilqr_amd_loader import load_package
     pkg = load_package()
     model, T, x1, ub = pkg.workloads.make_inputs(args.config, args.batch)
-    sol = pkg.Solver(model=model, horizon=T, batch=args.batch, options=pkg.Options(verbose=0))
+    sol = pkg.Solver(model=model, horizon=T, batch=args.batch,
+                     options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
     sol.set_kernel_variant_(args.variant)
     for _ in range(max(1, args.steps)):
         sol.reset_()
@@ -214,7 +215,8 @@ def worker(args):
     else:
         d_x1 = torch.from_numpy(x1).to(dev)
         d_u = torch.from_numpy(ub).to(dev)
-        sols = [pkg.Solver(model=model, horizon=T, batch=B, device=gpu, options=pkg.Options(verbose=0))
+        sols = [pkg.Solver(model=model, horizon=T, batch=B, device=gpu,
+                           options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
                 for _ in range(max(1, args.inflight))]
     sol = sols[0]
     for s_ in sols:

@@ -35,7 +35,7 @@ struct LargeDims {
     // LDS carve (doubles); must match large_lds_doubles() of ilqr_layout.hpp
     static constexpr int oP = 0, oFx = oP + NP * ld, oT = oFx + NP * ld, oFu = oT + NP * ld, oUh = oFu + MP * ld,
                          oQux = oUh + NP * ldm, oK = oQux + NP * ldm, oUxt = oK + NP * ldm, oQuu = oUxt + NP * ldm,
-                         oVec = oQuu + MP * ldm, total = oVec + 4 * NP + 4 * MP + 8;
+                         oVec = oQuu + MP * ldm, oLay = oVec + 4 * NP + 4 * MP + 8, total = oLay + LAYOUT_LDS_DOUBLES;
 };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -108,26 +108,35 @@ __device__ __forceinline__ gdbl* uniform_ptr(gdbl* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (gdbl*)(((unsigned long long)hi << 32) | lo);
 }
-// what the other large-path phase functions need of one instance
+// What the large-path phase functions need of one instance. They are real calls: a struct of twenty pointers would travel
+// on the stack (scratch), so only the instance's block pointer crosses the call; the Layout is read back from the tail of
+// the dynamic LDS, where the kernel parked it (store_layout_lds), and the pointers are rebuilt wave-uniform in the callee.
 struct LargeArgs {
-    gdbl *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act, *w, *gxx, *guu, *gux, *scal;
+    gdbl *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act, *w, *gxx, *guu, *gux, *P, *p, *scal;
     int T, N;
 };
 template <class M>
-__device__ __forceinline__ LargeArgs large_args(Inst<M>& I) {
-    return LargeArgs{as_global(I.xb), as_global(I.ub), as_global(I.x), as_global(I.u), as_global(I.fx), as_global(I.fu),
-                     as_global(I.gx), as_global(I.gu), as_global(I.K), as_global(I.k), as_global(I.Lx), as_global(I.Lu),
-                     as_global(I.c), as_global(I.lam), as_global(I.rho), as_global(I.act), as_global(I.w),
-                     as_global(I.gxx), as_global(I.guu), as_global(I.gux), as_global(I.scal), I.T, I.N};
+__device__ __forceinline__ void store_layout_lds(const Layout& L) {
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    int* dst = reinterpret_cast<int*>(lds_dyn + LargeDims<M>::oLay);
+    int i = 0;
+#define ILQR_X(f) dst[i++] = L.f;
+    ILQR_LAYOUT_FIELDS(ILQR_X)
+#undef ILQR_X
 }
-__device__ __forceinline__ void uniform_args(LargeArgs& A) {
-    A.xb = uniform_ptr(A.xb); A.ub = uniform_ptr(A.ub); A.x = uniform_ptr(A.x); A.u = uniform_ptr(A.u);
-    A.fx = uniform_ptr(A.fx); A.fu = uniform_ptr(A.fu); A.gx = uniform_ptr(A.gx); A.gu = uniform_ptr(A.gu);
-    A.K = uniform_ptr(A.K); A.k = uniform_ptr(A.k); A.Lx = uniform_ptr(A.Lx); A.Lu = uniform_ptr(A.Lu);
-    A.c = uniform_ptr(A.c); A.lam = uniform_ptr(A.lam); A.rho = uniform_ptr(A.rho); A.act = uniform_ptr(A.act);
-    A.w = uniform_ptr(A.w); A.gxx = uniform_ptr(A.gxx); A.guu = uniform_ptr(A.guu); A.gux = uniform_ptr(A.gux);
-    A.scal = uniform_ptr(A.scal);
-    A.T = __builtin_amdgcn_readfirstlane(A.T); A.N = __builtin_amdgcn_readfirstlane(A.N);
+template <class M>
+__device__ __forceinline__ LargeArgs large_args_from_lds(gdbl* base) {
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    const int* src = reinterpret_cast<const int*>(lds_dyn + LargeDims<M>::oLay);
+    Layout L;
+    int i = 0;
+#define ILQR_X(f) L.f = __builtin_amdgcn_readfirstlane(src[i++]);
+    ILQR_LAYOUT_FIELDS(ILQR_X)
+#undef ILQR_X
+    gdbl* g = uniform_ptr(base);
+    return LargeArgs{g + L.xb, g + L.ub, g + L.x, g + L.u, g + L.fx, g + L.fu, g + L.gx, g + L.gu, g + L.K, g + L.k, g + L.Lx, g + L.Lu,
+                     g + L.c, g + L.lam, g + L.rho, g + L.act, g + L.w, g + L.gxx, g + L.guu, g + L.gux, g + L.P, g + L.p, g + L.scal,
+                     L.T, L.T - 1};
 }
 
 // ---------------------------------------------------------------- gradients! (one timestep per lane)
@@ -135,9 +144,10 @@ __device__ __forceinline__ void uniform_args(LargeArgs& A) {
 // M::JAC_CONST_* and are written by coalesced wave-wide stores; only the M::JAC_NVAR state-dependent entries
 // are evaluated per timestep (M::dyn_jac_var_mem). Same `.=` semantics as src/dynamics.jl:45-46 every call.
 template <class M>
-__attribute__((noinline)) __device__ void gradients_large_fn(LargeArgs A, int constrained) {
+__attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int constrained) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, W = waves_of<M>::value;
-    uniform_args(A);
+    const LargeArgs A = large_args_from_lds<M>(base);
+    constrained = __builtin_amdgcn_readfirstlane(constrained);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = A.T, N = A.N;
     constexpr bool split = M::JAC_NVAR < n * n + n * m;
     if constexpr (split) {
@@ -224,7 +234,7 @@ __attribute__((noinline)) __device__ void gradients_large_fn(LargeArgs A, int co
 template <class M>
 __device__ __forceinline__ void gradients_large(Inst<M>& I, bool constrained) {
     ILQR_PROF_BEGIN();
-    gradients_large_fn<M>(large_args(I), constrained ? 1 : 0);
+    gradients_large_fn<M>(as_global(I.gbase), constrained ? 1 : 0);
     ILQR_PROF_END(I, PROF_GRAD);
 }
 
@@ -239,11 +249,15 @@ __device__ __forceinline__ void gradients_large(Inst<M>& I, bool constrained) {
 // (odd leading dimensions, transposition = stride pattern, no bounds checks), then the MFMAs issue back to back;
 // Qxx never leaves wave 1's accumulators; the cost Hessians are prefetched in the D-layout of the tiles they are
 // added to, by the wave that owns those tiles.
-struct RiccatiArgs { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int N; gdbl* Q; QLayout QL; };
-struct RiccatiOut { double gradient_norm; int potrf_info; double prof[6]; };
+struct RiccatiOut {
+    double gradient_norm; int potrf_info;
+#if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
+    double prof[6];
+#endif
+};
 
 template <class M, bool STORE_VALUE>
-__attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiArgs A) {
+__attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* base, gdbl* Qbase) {
     typedef LargeDims<M> LD;
     constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, ldm = LD::ldm;
     constexpr int n4 = r4(n), m4 = r4(m), TN = NP / 16, TM = MP / 16, NT = 128;
@@ -253,22 +267,22 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
     static_assert(waves_of<M>::value == 2, "the Riccati step is written for two waves per instance");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     struct { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int potrf_info; double prof[6]; } I;
-    I.fx = uniform_ptr(A.fx); I.fu = uniform_ptr(A.fu); I.gx = uniform_ptr(A.gx); I.gu = uniform_ptr(A.gu);
-    I.gxx = uniform_ptr(A.gxx); I.guu = uniform_ptr(A.guu); I.gux = uniform_ptr(A.gux); I.K = uniform_ptr(A.K);
-    I.k = uniform_ptr(A.k); I.Lx = uniform_ptr(A.Lx); I.Lu = uniform_ptr(A.Lu); I.P = uniform_ptr(A.P); I.p = uniform_ptr(A.p);
+    const LargeArgs A = large_args_from_lds<M>(base);
+    I.fx = A.fx; I.fu = A.fu; I.gx = A.gx; I.gu = A.gu; I.gxx = A.gxx; I.guu = A.guu; I.gux = A.gux; I.K = A.K;
+    I.k = A.k; I.Lx = A.Lx; I.Lu = A.Lu; I.P = A.P; I.p = A.p;
     I.potrf_info = 0;
     for (int q = 0; q < 6; ++q) I.prof[q] = 0.0;
-    gdbl* const Qv = STORE_VALUE ? A.Q : nullptr;           // optional action-value buffers (stage kernel only)
-    const QLayout QL = A.QL;
+    gdbl* const Qv = (STORE_VALUE && Qbase != nullptr) ? uniform_ptr(Qbase) : nullptr;   // optional action-value buffers (stage kernel only)
+    const QLayout QL = make_qlayout(n, m, A.T);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = __builtin_amdgcn_readfirstlane(A.N), li = lane & 15, lk = lane >> 4;
+    const int N = A.N, li = lane & 15, lk = lane >> 4;
     const bool w0 = wave == 0;
     double* S = lds_dyn;
     double *sP = S + LD::oP, *sFx = S + LD::oFx, *sT = S + LD::oT, *sFu = S + LD::oFu, *sUh = S + LD::oUh,
            *sQux = S + LD::oQux, *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
     double* sUxt0 = sT;                                                   // wave 0's copy of ûxt (T is dead by then)
     double *sp = S + LD::oVec, *sQx = sp + NP, *sQu = sQx + NP, *sk = sQu + MP, *sOut = sk + MP;
-    for (int e = tid; e < LD::total; e += NT) S[e] = 0.0;                 // the tile padding must read as zero
+    for (int e = tid; e < LD::oLay; e += NT) S[e] = 0.0;                  // the tile padding must read as zero (the Layout copy behind it stays)
     __syncthreads();
     for (int e = tid; e < n * n; e += NT) {                               // P[H] .= gxx[H]  (:39)
         const double v = I.gxx[(size_t)N * n * n + e];
@@ -536,17 +550,16 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(RiccatiAr
     RiccatiOut out;
     out.gradient_norm = sOut[0];
     out.potrf_info = (int)sOut[1];
+#if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
     for (int q = 0; q < 6; ++q) out.prof[q] = I.prof[q];
+#endif
     __syncthreads();
     return out;
 }
 
 template <class M, bool STORE_VALUE>
 __device__ __forceinline__ void backward_pass_large(Inst<M>& I) {
-    RiccatiArgs A{as_global(I.fx), as_global(I.fu), as_global(I.gx), as_global(I.gu), as_global(I.gxx), as_global(I.guu),
-                  as_global(I.gux), as_global(I.K), as_global(I.k), as_global(I.Lx), as_global(I.Lu), as_global(I.P),
-                  as_global(I.p), I.N, as_global(I.Q), I.QL};
-    const RiccatiOut o = backward_pass_large_fn<M, STORE_VALUE>(A);
+    const RiccatiOut o = backward_pass_large_fn<M, STORE_VALUE>(as_global(I.gbase), as_global(I.Q));
     I.gradient_norm = o.gradient_norm;
     if (o.potrf_info != 0 && I.potrf_info == 0) I.potrf_info = o.potrf_info;
 #if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
@@ -694,10 +707,10 @@ __device__ __forceinline__ double delta_large_body(const LargeArgs& A, int lane)
 }
 
 template <class M>
-__attribute__((noinline)) __device__ double forward_sweep_large_fn(LargeArgs A, double alpha, int want_delta) {
+__attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, double alpha, int want_delta) {
     typedef LargeDims<M> LD;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    uniform_args(A);
+    const LargeArgs A = large_args_from_lds<M>(base);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     want_delta = __builtin_amdgcn_readfirstlane(want_delta);
     double* sOut = lds_dyn + LD::oVec + 4 * LD::NP + 4 * LD::MP;
@@ -716,7 +729,7 @@ __attribute__((noinline)) __device__ double forward_sweep_large_fn(LargeArgs A, 
 template <class M>
 __device__ __forceinline__ void rollout_large(Inst<M>& I, double alpha, bool want_delta, double& delta_out) {
     ILQR_PROF_BEGIN();
-    const double d = forward_sweep_large_fn<M>(large_args(I), alpha, want_delta ? 1 : 0);
+    const double d = forward_sweep_large_fn<M>(as_global(I.gbase), alpha, want_delta ? 1 : 0);
     if (want_delta) delta_out = d;
     I.rollouts += 1;
     I.states_eq_nominal = 0;

@@ -57,11 +57,18 @@ inline __host__ __device__ QLayout make_qlayout(int nx, int nu, int T) {
 
 // models with nx > 4 or nu > 4 take the HBM-resident large path (ilqr_device_large.hpp)
 inline __host__ __device__ bool is_large_model(int nx, int nu) { return nx > 4 || nu > 4; }
-// LDS staging of the large path (must match LargeDims<M>::total)
+// LDS staging of the large path (must match LargeDims<M>::total); the tail holds a copy of the Layout so that the
+// phase functions (real calls) take one pointer instead of twenty on the stack
+enum { LAYOUT_LDS_DOUBLES = 24 };
 constexpr __host__ __device__ int large_lds_doubles(int n, int m) {
     const int NP = (n + 15) & ~15, MP = (m + 15) & ~15, ld = NP + 1, ldm = MP + 1;
-    return 3 * NP * ld + MP * ld + 4 * NP * ldm + MP * ldm + 4 * NP + 4 * MP + 8;
+    return 3 * NP * ld + MP * ld + 4 * NP * ldm + MP * ldm + 4 * NP + 4 * MP + 8 + LAYOUT_LDS_DOUBLES;
 }
+
+#define ILQR_LAYOUT_FIELDS(X) X(T) X(nx) X(nu) X(nw) X(ncs) X(nct) X(C) X(xb) X(ub) X(x) X(u) X(fx) X(fu) X(gx) X(gu) X(K) X(k) X(Lx) X(Lu) \
+    X(c) X(lam) X(rho) X(act) X(w) X(zslot) X(lds_doubles) X(lds_doubles_slim) X(ring) X(gxx) X(guu) X(gux) X(P) X(p) X(scal) X(gzero) X(stride)
+enum { LAYOUT_INTS = 36 };
+static_assert(LAYOUT_INTS * 4 <= LAYOUT_LDS_DOUBLES * 8, "layout copy fits its LDS slot");
 
 inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, int nct, int T) {
     Layout L;
