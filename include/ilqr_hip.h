@@ -189,6 +189,32 @@ int ilqr_get_stream(ilqr_handle* h, void** hip_stream);
 int ilqr_timing_reset(ilqr_handle* h);
 int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launches);
 
+/* Dynamics(f, fx, fu, ...) / Cost(...) / Constraint(f, fx, fu, ...) with USER-SUPPLIED callables — src/dynamics.jl:55-60,
+ * src/costs.jl:1-15, src/constraints.jl:54-64 — for hosts without Python (the Julia wrapper hands over what
+ * Symbolics.build_function(..., target = CTarget()) emits; a C program writes it by hand). `source` is C code defining,
+ * each as `ILQR_MODEL_FN void NAME(double* out, const double* x, const double* u, const double* w)` with the reference's
+ * in-place contract (out column-major, pre-zeroed by the caller; u is a dummy for the terminal functions; math.h names
+ * and ilqr::sincos_fast are available):
+ *     dynamics, dynamics_jacobian_state, dynamics_jacobian_action,
+ *     cost_stage, cost_stage_gradient_state, cost_stage_gradient_action, cost_stage_hessian_state_state,
+ *     cost_stage_hessian_action_action, cost_stage_hessian_action_state,
+ *     cost_terminal, cost_terminal_gradient_state, cost_terminal_hessian_state_state,
+ *     constraint_stage, constraint_stage_jacobian_state, constraint_stage_jacobian_action          (only if nc_stage > 0)
+ *     constraint_terminal, constraint_terminal_jacobian_state                                       (only if nc_term > 0)
+ * ineq_stage / ineq_term: bit i set = constraint row i is an inequality (indices_inequality, 0-based).
+ * The library wraps the source (csrc/ilqr_model_adapter.hpp), compiles it for gfx950 with hipcc as a child process (cached
+ * by a hash of the source; ILQR_HIPCC / ILQR_CSRC_DIR override the tool and the kernel headers), loads the module and
+ * returns the name to put into ilqr_problem_desc.model and the module path for ilqr_problem_desc.model_library.
+ * Small models only (nx, nu <= 4); larger ones go through the symbolic generator. */
+typedef struct {
+    const char* name;        /* C identifier */
+    int32_t nx, nu, nw;      /* num_state, num_action, num_parameter */
+    int32_t nc_stage, nc_term;
+    uint64_t ineq_stage, ineq_term;
+    const char* source;
+} ilqr_model_source;
+int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len);
+
 /* Model registry (generated model modules call this from a static initialiser). */
 struct ilqr_model_vtable;
 int ilqr_register_model(const struct ilqr_model_vtable* vt);

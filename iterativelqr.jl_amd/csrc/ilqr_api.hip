@@ -2,10 +2,15 @@
 // kernel launches on a private HIP stream, host<->device accessors.
 // No CPU fallback: without a HIP device ilqr_create fails loudly.
 #include <dlfcn.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <fcntl.h>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -209,6 +214,102 @@ int ilqr_register_model(const ilqr_model_vtable* vt) {
     return ILQR_OK;
 }
 int ilqr_model_count(void) { return (int)registry().size(); }
+
+// Dynamics / Cost / Constraint constructors for hosts without Python: C source of the reference's callables -> model module.
+int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len) {
+    if (!src || !src->name || !src->source || !registered_name || !library_path)
+        return fail(ILQR_ERR_INVALID, "null argument");
+    if (src->nx < 1 || src->nx > 4 || src->nu < 1 || src->nu > 4 || src->nw < 0 || src->nc_stage < 0 || src->nc_stage > 64 ||
+        src->nc_term < 0 || src->nc_term > 64)
+        return fail(ILQR_ERR_INVALID, "ilqr_compile_model: 1 <= nx, nu <= 4, at most 64 constraint rows per stage (larger models go "
+                                      "through the symbolic generator, iterativelqr.jl_amd/codegen.py)");
+    for (const char* c = src->name; *c; ++c)
+        if (!((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_'))
+            return fail(ILQR_ERR_INVALID, "model name must be a C identifier");
+    // where this library lives: <pkg>/lib/libilqr_hip.so, kernels in <pkg>/csrc (ILQR_CSRC_DIR overrides)
+    Dl_info di;
+    if (!dladdr((const void*)&ilqr_compile_model, &di) || !di.dli_fname) return fail(ILQR_ERR_MODEL, "cannot locate libilqr_hip.so");
+    std::string libdir(di.dli_fname);
+    libdir = libdir.substr(0, libdir.find_last_of('/'));
+    const char* env_csrc = std::getenv("ILQR_CSRC_DIR");
+    const std::string csrc = env_csrc ? env_csrc : libdir + "/../csrc";
+    const char* env_hipcc = std::getenv("ILQR_HIPCC");
+    const std::string hipcc = env_hipcc ? env_hipcc : "/opt/rocm/bin/hipcc";
+    // tag = FNV-1a over everything that ends up in the module: source, dimensions, ABI version
+    unsigned long long hsh = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; ++i) { hsh ^= ((const unsigned char*)p)[i]; hsh *= 1099511628211ull; } };
+    mix(src->source, std::strlen(src->source)); mix(src->name, std::strlen(src->name));
+    const long long dims[8] = {src->nx, src->nu, src->nw, src->nc_stage, src->nc_term, (long long)src->ineq_stage, (long long)src->ineq_term,
+                               ILQR_MODEL_ABI_VERSION * 1000 + (long long)sizeof(ilqr::KArgs)};
+    mix(dims, sizeof(dims));
+    char tag[32];
+    std::snprintf(tag, sizeof(tag), "%016llx", hsh);
+    const std::string uname = std::string(src->name) + "_c" + tag;
+    const std::string dir = libdir + "/models";
+    mkdir(dir.c_str(), 0755);
+    const std::string so = dir + "/libilqr_model_" + uname + ".so", hip = dir + "/model_" + uname + ".hip", log = dir + "/model_" + uname + ".log";
+    if (uname.size() + 1 > name_len || so.size() + 1 > path_len) return fail(ILQR_ERR_INVALID, "output buffers too small");
+    struct stat st;
+    if (stat(so.c_str(), &st) != 0) {
+        FILE* f = std::fopen(hip.c_str(), "w");
+        if (!f) return fail(ILQR_ERR_MODEL, "cannot write " + hip);
+        const bool cs = src->nc_stage > 0, ct = src->nc_term > 0;
+        std::fprintf(f, "// GENERATED by ilqr_compile_model — user callables wrapped for the kernels (ilqr_model_adapter.hpp)\n"
+                        "#include \"ilqr_model_adapter.hpp\"\nnamespace user_%s {\n%s\n}\n", tag, src->source);
+        std::fprintf(f, "struct Fns_%s {\n", tag);
+        const char* names[] = {"dynamics", "dynamics_jacobian_state", "dynamics_jacobian_action", "cost_stage", "cost_stage_gradient_state",
+                               "cost_stage_gradient_action", "cost_stage_hessian_state_state", "cost_stage_hessian_action_action",
+                               "cost_stage_hessian_action_state", "cost_terminal", "cost_terminal_gradient_state",
+                               "cost_terminal_hessian_state_state"};
+        for (const char* nm : names)
+            std::fprintf(f, "    ILQR_MODEL_FN void %s(double* o, const double* x, const double* u, const double* w) { user_%s::%s(o, x, u, w); }\n", nm, tag, nm);
+        const char* cnames[] = {"constraint_stage", "constraint_stage_jacobian_state", "constraint_stage_jacobian_action",
+                                "constraint_terminal", "constraint_terminal_jacobian_state"};
+        for (int i = 0; i < 5; ++i) {
+            const bool have = i < 3 ? cs : ct;
+            if (have) std::fprintf(f, "    ILQR_MODEL_FN void %s(double* o, const double* x, const double* u, const double* w) { user_%s::%s(o, x, u, w); }\n", cnames[i], tag, cnames[i]);
+            else std::fprintf(f, "    ILQR_MODEL_FN void %s(double*, const double*, const double*, const double*) {}\n", cnames[i]);
+        }
+        std::fprintf(f, "};\nstruct Model_%s : ilqr::AdaptedModel<Fns_%s, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull> {\n"
+                        "    static constexpr const char* NAME = \"%s\";\n};\nILQR_DEFINE_MODEL(Model_%s)\n",
+                     uname.c_str(), tag, src->nx, src->nu, src->nw, src->nc_stage, src->nc_term,
+                     (unsigned long long)src->ineq_stage, (unsigned long long)src->ineq_term, uname.c_str(), uname.c_str());
+        std::fclose(f);
+        // hipcc as a child process (no shell): same flags as the built-in models
+        const std::string tmp = so + ".tmp" + std::to_string((long)getpid());
+        const std::string inc = "-I" + csrc, lflag = "-L" + libdir, rpath = "-Wl,-rpath," + libdir;
+        std::vector<const char*> argv = {hipcc.c_str(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+                                         "-amdgpu-mfma-vgpr-form", "-Wno-unused-parameter", inc.c_str(), hip.c_str(), "-o", tmp.c_str(),
+                                         lflag.c_str(), "-lilqr_hip", rpath.c_str(), nullptr};
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        posix_spawn_file_actions_adddup2(&fa, 1, 2);
+        pid_t pid = 0;
+        extern char** environ;
+        const int sp = posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, const_cast<char* const*>(argv.data()), environ);
+        posix_spawn_file_actions_destroy(&fa);
+        if (sp != 0) return fail(ILQR_ERR_MODEL, "cannot start " + hipcc + " (set ILQR_HIPCC)");
+        int status = 0;
+        if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+            std::string msg = "hipcc failed for model '" + std::string(src->name) + "', see " + log;
+            if (FILE* lf = std::fopen(log.c_str(), "r")) {
+                char buf[1500];
+                const size_t nr = std::fread(buf, 1, sizeof(buf) - 1, lf);
+                buf[nr] = 0;
+                std::fclose(lf);
+                msg += ":\n" + std::string(buf);
+            }
+            return fail(ILQR_ERR_MODEL, msg);
+        }
+        if (std::rename(tmp.c_str(), so.c_str()) != 0) return fail(ILQR_ERR_MODEL, "cannot move the model module into place");
+    }
+    if (!dlopen(so.c_str(), RTLD_NOW | RTLD_GLOBAL)) return fail(ILQR_ERR_MODEL, std::string("dlopen failed: ") + dlerror());
+    if (!find_model(uname.c_str())) return fail(ILQR_ERR_MODEL, "the compiled module did not register '" + uname + "' (ABI mismatch?)");
+    std::snprintf(registered_name, name_len, "%s", uname.c_str());
+    std::snprintf(library_path, path_len, "%s", so.c_str());
+    return ILQR_OK;
+}
 const char* ilqr_model_name(int32_t i) {
     return (i >= 0 && i < (int)registry().size()) ? registry()[i]->name : nullptr;
 }

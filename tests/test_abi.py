@@ -57,3 +57,47 @@ def test_no_cpu_fallback(pkg):
     assert L.ilqr_create(C.byref(desc), C.byref(h)) < 0
     assert b"unknown model" in L.ilqr_last_error()
     assert L.ilqr_solve(None) < 0 and L.ilqr_get_stats(None, None) < 0
+
+
+class _ModelSource(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
+                ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+
+
+def test_compile_model_from_c_source_without_python_codegen(pkg):
+    """ilqr_compile_model: the reference's user-supplied callables (src/dynamics.jl:55-60, src/costs.jl:1-15,
+    src/constraints.jl:54-64) as C source -> adapter -> hipcc child process -> registered model (cross-compiles here)."""
+    L = pkg._ffi.lib()
+    fn = "ILQR_MODEL_FN void %s(double* o, const double* x, const double* u, const double* w) { %s }\n"
+    src = "".join(fn % kv for kv in [
+        ("dynamics", "o[0] = x[0] + 0.1 * x[1]; o[1] = x[1] + 0.1 * (u[0] - sin(x[0]));"),
+        ("dynamics_jacobian_state", "o[0] = 1.0; o[1] = -0.1 * cos(x[0]); o[2] = 0.1; o[3] = 1.0;"),
+        ("dynamics_jacobian_action", "o[1] = 0.1;"),
+        ("cost_stage", "o[0] = x[0] * x[0] + x[1] * x[1] + 0.1 * u[0] * u[0];"),
+        ("cost_stage_gradient_state", "o[0] = 2.0 * x[0]; o[1] = 2.0 * x[1];"),
+        ("cost_stage_gradient_action", "o[0] = 0.2 * u[0];"),
+        ("cost_stage_hessian_state_state", "o[0] = 2.0; o[3] = 2.0;"),
+        ("cost_stage_hessian_action_action", "o[0] = 0.2;"),
+        ("cost_stage_hessian_action_state", ""),
+        ("cost_terminal", "o[0] = 10.0 * (x[0] * x[0] + x[1] * x[1]);"),
+        ("cost_terminal_gradient_state", "o[0] = 20.0 * x[0]; o[1] = 20.0 * x[1];"),
+        ("cost_terminal_hessian_state_state", "o[0] = 20.0; o[3] = 20.0;"),
+        ("constraint_stage", "o[0] = u[0] - 2.0; o[1] = -2.0 - u[0];"),
+        ("constraint_stage_jacobian_state", ""),
+        ("constraint_stage_jacobian_action", "o[0] = 1.0; o[1] = -1.0;"),
+    ])
+    ms = _ModelSource(b"abi_pendulum", 2, 1, 0, 2, 0, 3, 0, src.encode())
+    name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
+    rc = L.ilqr_compile_model(C.byref(ms), name, 128, path, 1024)
+    assert rc == 0, L.ilqr_last_error().decode()
+    assert name.value.startswith(b"abi_pendulum_c") and os.path.exists(path.value.decode())
+    names = {L.ilqr_model_name(i) for i in range(L.ilqr_model_count())}
+    assert name.value in names
+    # a second call with the same source is served from the cache and registers under the same name
+    name2 = C.create_string_buffer(128)
+    assert L.ilqr_compile_model(C.byref(ms), name2, 128, path, 1024) == 0 and name2.value == name.value
+    # errors come back as messages, not crashes
+    bad = _ModelSource(b"abi_bad", 2, 1, 0, 0, 0, 0, 0, b"this is not C")
+    assert L.ilqr_compile_model(C.byref(bad), name2, 128, path, 1024) < 0 and b"hipcc failed" in L.ilqr_last_error()
+    big = _ModelSource(b"abi_big", 9, 1, 0, 0, 0, 0, 0, b"")
+    assert L.ilqr_compile_model(C.byref(big), name2, 128, path, 1024) < 0

@@ -765,3 +765,17 @@ def test_auto_variant_takes_the_packed_kernel_beyond_one_instance_per_simd(pkg):
         sol.set_kernel_variant_(v); sol.initialize_rollout_(x1, ub); sol.solve_()
         res.append(sol.get_trajectory()[0]); sol.close()
     assert np.array_equal(res[0], res[1])
+
+
+def test_c_host_defines_a_model_and_runs_two_handles_concurrently(pkg, tmp_path):
+    """examples/particle_compile.c: ilqr_compile_model from plain C (the reference's callables as C source -> hipcc child
+    process -> registered model), then the user model and the built-in twin on two handles from two host threads."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "particle_compile")
+    libdir = os.path.join(root, "iterativelqr.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "particle_compile.c"),
+                           "-o", exe, "-L" + libdir, "-lilqr_hip", "-Wl,-rpath," + libdir, "-lm", "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "user-defined model matches the built-in one" in out.stdout
