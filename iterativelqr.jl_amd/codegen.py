@@ -188,6 +188,14 @@ def _group_reciprocals(repl):
     return groups
 
 
+def _select(var, sel, qi, expr):
+    """var = (sel == qi) ? expr : var. For small models the (cheap) expression is evaluated on every lane first and made
+    opaque, so that hipcc emits two v_cndmask instead of an exec-masked branch around one addition."""
+    if COOP_GROUP == 16:
+        return "{ double sel_ = %s; ILQR_OPAQUE(sel_); %s = (%s == %d) ? sel_ : %s; }" % (expr, var, sel, qi, var)
+    return "%s = (%s == %d) ? (%s) : %s;" % (var, sel, qi, expr, var)
+
+
 def _emit_block(outputs, prefix, coop=False):
     """outputs: list of (lhs_string, expr). Returns C statements: CSE temporaries, one
     fused ilqr::sincos_fast per distinct trig argument, then the outputs, in dependency order.
@@ -227,8 +235,10 @@ def _emit_block(outputs, prefix, coop=False):
     for gi, g in enumerate(recip_groups):
         txt = ["double rb%d = %s;" % (gi, _P.doprint(g[0][1]))]
         for qi, (_, base) in enumerate(g[1:], start=1):
-            txt.append("rb%d = (lane == %d) ? (%s) : rb%d;" % (gi, qi, _P.doprint(base), gi))
-        txt.append("const double rr%d = 1.0 / rb%d;" % (gi, gi))
+            txt.append(_select("rb%d" % gi, "lane", qi, _P.doprint(base)))
+        # small models (serial rollout chain of the LDS / packed kernels): v_rcp + two Newton steps instead of the IEEE
+        # division sequence (5 instead of 11 issue slots per group, <= 1 ulp)
+        txt.append(("const double rr%d = ilqr::recip_fast(rb%d);" if COOP_GROUP == 16 else "const double rr%d = 1.0 / rb%d;") % (gi, gi))
         for qi, (sym, _) in enumerate(g):
             txt.append("const double %s = ilqr::wave_bcast<%d>(rr%d);" % (sym, qi, gi))
         nodes.append(({sym for sym, _ in g}, sp.Tuple(*[b for _, b in g]), "\n".join(txt)))
@@ -252,7 +262,7 @@ def _emit_block(outputs, prefix, coop=False):
                 batch_id += 1
                 txt = ["double ta%d = %s;" % (j, _P.doprint(chunk[0][1]))]
                 for qi, (_, e) in enumerate(chunk[1:], start=1):
-                    txt.append("ta%d = (%s == %d) ? (%s) : ta%d;" % (j, sel, qi, _P.doprint(e), j))
+                    txt.append(_select("ta%d" % j, sel, qi, _P.doprint(e)))
                 txt.append("double ts%d, tc%d; ilqr::sincos_fast(ta%d, ts%d, tc%d);" % (j, j, j, j, j))
                 defined, dep = set(), sp.Tuple(*[e for _, e in chunk])
                 for qi, (d, _) in enumerate(chunk):

@@ -19,6 +19,32 @@
 
 namespace ilqr {
 
+// d = a * b + c as ONE three-address v_fma_f64. hipcc selects the two-address v_fmac_f64 for Horner steps and then copies the
+// constant addend into the destination first (a v_mov_b64 per step: ten extra issue slots per sincos on the serial rollout chain).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// value made opaque to the optimiser at this point (keeps a cheap expression out of an exec-masked branch)
+#define ILQR_OPAQUE(v) asm volatile("" : "+v"(v))
+// 1 / x by v_rcp_f64 and two Newton steps (5 instructions, <= 1 ulp for normal x) instead of the IEEE division sequence
+// (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: 11 instructions). Used on the serial rollout chain only.
+__device__ __forceinline__ double recip_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+#else
+ILQR_HD double fma3(double a, double b, double c) { return fma(a, b, c); }
+#define ILQR_OPAQUE(v) do {} while (0)
+ILQR_HD double recip_fast(double x) { return 1.0 / x; }
+#endif
+
 ILQR_HD void sincos_reduced(double r, double& s, double& c) {
     // fdlibm __kernel_sin / __kernel_cos coefficients on |r| <= pi/4
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
@@ -28,17 +54,17 @@ ILQR_HD void sincos_reduced(double r, double& s, double& c) {
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double z = r * r;
-    double ps = fma(z, S6, S5);
-    ps = fma(z, ps, S4);
-    ps = fma(z, ps, S3);
-    ps = fma(z, ps, S2);
-    ps = fma(z, ps, S1);
+    double ps = fma3(z, S6, S5);
+    ps = fma3(z, ps, S4);
+    ps = fma3(z, ps, S3);
+    ps = fma3(z, ps, S2);
+    ps = fma3(z, ps, S1);
     s = fma(r * z, ps, r);
-    double pc = fma(z, C6, C5);
-    pc = fma(z, pc, C4);
-    pc = fma(z, pc, C3);
-    pc = fma(z, pc, C2);
-    pc = fma(z, pc, C1);
+    double pc = fma3(z, C6, C5);
+    pc = fma3(z, pc, C4);
+    pc = fma3(z, pc, C3);
+    pc = fma3(z, pc, C2);
+    pc = fma3(z, pc, C1);
     c = fma(z, fma(z, pc, -0.5), 1.0);       // 1 + z(-1/2 + z*pc): 2 ops instead of fdlibm's 6 (+0.3 ulp)
 }
 
