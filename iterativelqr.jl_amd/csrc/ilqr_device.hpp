@@ -638,9 +638,10 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
     // potrs('U') of one right-hand-side set held as Y(r, c) (rows on lanes 16 apart), given the factor   (:70-75)
     auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
         if (m == 1 && info == 0) {
-            // 1x1: (b / sqrt(q)) / sqrt(q) == b / q up to one rounding; saves a sqrt and a division
-            // (~220 clk) on the serial chain. The literal path below still runs when potrf fails.
-            Y = Y / Uc[0];
+            // 1x1: LAPACK (OpenBLAS trsm) computes (b * (1/sqrt(q))) * (1/sqrt(q)); here b * (1/q) with the reciprocal from
+            // v_rcp_f64 + two Newton steps: within 1.5 ulp of either, without the sqrt and the 11-instruction IEEE division
+            // sequences (~220 clk) on the serial chain. The literal path below still runs when potrf fails.
+            Y = Y * recip_fast(Uc[0]);
         } else {
 #pragma unroll
             for (int i = 0; i < m; ++i) {                               // U^T y = b

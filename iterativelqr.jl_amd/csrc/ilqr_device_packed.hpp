@@ -305,7 +305,7 @@ __device__ void backward_pass(PInst<M>& I, unsigned mask, double& gnorm_row, int
     // potrs('U') of the right-hand sides held as Y(r, c): K in rows 0..m-1, k (column 0) in rows m..2m-1   (:70-75)
     auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
         if (m == 1 && info == 0) {
-            Y = Y / Uc[0];                                              // see ilqr_device.hpp: 1x1 shortcut
+            Y = Y * recip_fast(Uc[0]);                                              // see ilqr_device.hpp: 1x1 shortcut
         } else {
 #pragma unroll
             for (int i = 0; i < m; ++i) {                               // U^T y = b
@@ -527,7 +527,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     const int rr = (m == 2) ? (r & 1) : 0;
     auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
         if (m == 1 && info == 0) {
-            Y = Y / Uc[0];
+            Y = Y * recip_fast(Uc[0]);
         } else {
 #pragma unroll
             for (int i = 0; i < m; ++i) {
