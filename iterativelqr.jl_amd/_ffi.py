@@ -5,7 +5,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libilqr_hip.so")
+# ILQR_LIB: an alternative build of the same library (e.g. the -DILQR_PROFILE build of tools/phase_cycles.py); tools only
+LIB_PATH = os.environ.get("ILQR_LIB") or os.path.join(LIB_DIR, "libilqr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 

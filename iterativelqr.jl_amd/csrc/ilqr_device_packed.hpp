@@ -433,6 +433,11 @@ __attribute__((noinline)) __device__ void linearise_stage(LinArgs a) {
     for (int i = 0; i < n; ++i) xt[i] = gr[a.xb + t * n + i];
 #pragma unroll
     for (int i = 0; i < m; ++i) ut[i] = gr[a.ub + t * m + i];
+    {   // touch the Hessian lines of this timestep: the Riccati steps of the chunk then hit L2 even where the accumulators
+        // below visit no entry of a line (structural zeros)
+        double t0_ = gr[a.gxx + t * n * n], t1_ = gr[a.gxx + t * n * n + n * n - 1], t2_ = gr[a.guu + t * m * m], t3_ = gr[a.gux + t * m * n];
+        asm volatile("" :: "v"(t0_), "v"(t1_), "v"(t2_), "v"(t3_));
+    }
     M::dyn_jac_mem(xt, ut, w, lrow + LD::FX + a.j * LD::SFX, lrow + LD::FU + a.j * LD::SFU);   // `.=` (src/dynamics.jl:45-46)
     double gx[n], gu[m];
     M::cost_s_grad(xt, ut, w, gx, gu);                                                          // `.=` (src/costs.jl:61,65)
@@ -470,7 +475,6 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     const bool on = I.valid_blk && ((mask >> I.beta) & 1u);
     double* gr = I.g;                       // row mapping block
     double* g = I.gb;                       // block mapping block
-    double* lrow = pk_lds + I.q * LD::IB;
     const double* lblk = pk_lds + I.beta * LD::IB;
     if (lane == 0) { pk_lds[LD::ZERO] = 0.0; pk_lds[LD::ZERO + 1] = 0.0; }
     // ---- terminal linearisation (t = N): gx[N] `.=`, gxx[N] `.+=` (src/costs.jl:57-84, src/gradients.jl:54-67)
@@ -734,17 +738,24 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) px[(t + 1) * sx + (wr ? i : 0)] = xout[i];
     };
-    Ops A, B;
+    // operands are fetched TWO steps ahead (three rotating register sets): K, k, ū, x̄ come from HBM / L2 here, and at one
+    // wave per SIMD nothing else hides their latency
+    Ops A, B, C;
     double xo[n];
     if (N > 0) fetch(A, 0);
+    if (N > 1) fetch(B, 1);
     int t = 0;
-    for (; t + 1 < N; t += 2) {
-        fetch(B, t + 1);
+    for (; t + 2 < N; t += 3) {
+        fetch(C, t + 2);
         step(A, t, xt, xo);
-        if (t + 2 < N) fetch(A, t + 2);
+        if (t + 3 < N) fetch(A, t + 3);
         step(B, t + 1, xo, xt);
+        if (t + 4 < N) fetch(B, t + 4);
+        step(C, t + 2, xt, xo);
+#pragma unroll
+        for (int i = 0; i < n; ++i) xt[i] = xo[i];
     }
-    if (t < N) step(A, t, xt, xo);
+    if (t < N) { step(A, t, xt, xo); ++t; if (t < N) step(B, t, xo, xt); }
     __syncthreads();
 }
 
