@@ -10,8 +10,8 @@
 # are passed as (nx, T, B) / (nu, T-1, B) column-major views of the same memory).
 module IterativeLQRAMD
 
-export Options, Solver, initialize_controls!, initialize_states!, initialize_rollout!, set_parameters!,
-       solve!, get_trajectory, get_policy, stats
+export Options, Solver, Dynamics, Cost, Constraint, initialize_controls!, initialize_states!, initialize_rollout!,
+       set_parameters!, solve!, get_trajectory, get_policy, stats, set_kernel_variant!, enable_trace!, trace
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "lib", "libilqr_hip.so"))
 
@@ -144,6 +144,119 @@ function stats(s::Solver)
     st = Vector{Stats}(undef, s.B)
     check(ccall((:ilqr_get_stats, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Stats}), s.handle, st))
     return st
+end
+
+# ------------------------------------------------------------------------------------------------------------
+# Dynamics / Cost / Constraint with the reference's constructors (src/dynamics.jl:16-34, src/costs.jl:17-44,
+# src/constraints.jl:17-43): the user function is traced on Symbolics variables exactly as the reference does, but
+# instead of `eval(build_function(...)[2])` (a Julia closure) the expressions are emitted as C
+# (`Symbolics.build_function(expr, x, u, w; target = Symbolics.CTarget())` — from memory of the Symbolics docs; the
+# image has no Julia, so this half has never run) and handed to `ilqr_compile_model`, which wraps them for the kernels
+# (csrc/ilqr_model_adapter.hpp) and compiles them with hipcc. Requires `using Symbolics` in the caller's environment.
+struct Dynamics;  body::String; num_state::Int; num_action::Int; num_parameter::Int; end
+struct Cost;      body::String; num_state::Int; num_action::Int; num_parameter::Int; end
+struct Constraint; body::String; num_constraint::Int; num_state::Int; num_action::Int; num_parameter::Int
+                   indices_inequality::Vector{Int}; end
+Constraint() = Constraint("", 0, 0, 0, 0, Int[])
+
+# one `ILQR_MODEL_FN void name(double* out, const double* x, const double* u, const double* w)` per expression array
+function c_function(Symbolics, name::String, exprs, x, u, w)
+    src = Symbolics.build_function(exprs, x, u, w; target = Symbolics.CTarget(), fname = name * "_raw",
+                                   lhsname = :out, rhsnames = [:x, :u, :w])
+    return string(src, "\nILQR_MODEL_FN void ", name,
+                  "(double* out, const double* x, const double* u, const double* w) { ", name, "_raw(out, x, u, w); }\n")
+end
+
+function Dynamics(Symbolics, f::Function, num_state::Int, num_action::Int; num_parameter::Int = 0)
+    x = Symbolics.variables(:x, 1:num_state); u = Symbolics.variables(:u, 1:num_action); w = Symbolics.variables(:w, 1:num_parameter)
+    y = num_parameter > 0 ? f(x, u, w) : f(x, u)
+    body = c_function(Symbolics, "dynamics", y, x, u, w) *
+           c_function(Symbolics, "dynamics_jacobian_state", vec(Symbolics.jacobian(y, x)), x, u, w) *
+           c_function(Symbolics, "dynamics_jacobian_action", vec(Symbolics.jacobian(y, u)), x, u, w)
+    Dynamics(body, num_state, num_action, num_parameter)
+end
+
+function Cost(Symbolics, f::Function, num_state::Int, num_action::Int; num_parameter::Int = 0, terminal::Bool = num_action == 0)
+    x = Symbolics.variables(:x, 1:num_state); u = Symbolics.variables(:u, 1:num_action); w = Symbolics.variables(:w, 1:num_parameter)
+    l = num_parameter > 0 ? f(x, u, w) : f(x, u)
+    gx = Symbolics.gradient(l, x); gu = Symbolics.gradient(l, u)
+    p = terminal ? "cost_terminal" : "cost_stage"
+    body = c_function(Symbolics, p, [l], x, u, w) * c_function(Symbolics, p * "_gradient_state", gx, x, u, w) *
+           c_function(Symbolics, p * "_hessian_state_state", vec(Symbolics.jacobian(gx, x)), x, u, w)
+    if !terminal
+        body *= c_function(Symbolics, p * "_gradient_action", gu, x, u, w) *
+                c_function(Symbolics, p * "_hessian_action_action", vec(Symbolics.jacobian(gu, u)), x, u, w) *
+                c_function(Symbolics, p * "_hessian_action_state", vec(Symbolics.jacobian(gu, x)), x, u, w)
+    end
+    Cost(body, num_state, num_action, num_parameter)
+end
+
+function Constraint(Symbolics, f::Function, num_state::Int, num_action::Int; indices_inequality::Vector{Int} = Int[],
+                    num_parameter::Int = 0, terminal::Bool = num_action == 0)
+    x = Symbolics.variables(:x, 1:num_state); u = Symbolics.variables(:u, 1:num_action); w = Symbolics.variables(:w, 1:num_parameter)
+    c = num_parameter > 0 ? f(x, u, w) : f(x, u)
+    p = terminal ? "constraint_terminal" : "constraint_stage"
+    body = c_function(Symbolics, p, c, x, u, w) * c_function(Symbolics, p * "_jacobian_state", vec(Symbolics.jacobian(c, x)), x, u, w)
+    terminal || (body *= c_function(Symbolics, p * "_jacobian_action", vec(Symbolics.jacobian(c, u)), x, u, w))
+    Constraint(body, length(c), num_state, num_action, num_parameter, indices_inequality)
+end
+
+struct ModelSource
+    name::Cstring; nx::Int32; nu::Int32; nw::Int32; nc_stage::Int32; nc_term::Int32
+    ineq_stage::UInt64; ineq_term::UInt64; source::Cstring
+end
+ineq_mask(idx) = reduce(|, (UInt64(1) << (i - 1) for i in idx); init = UInt64(0))
+
+"""
+    Solver(dynamics, costs, constraints; batch, options, name)
+
+`Solver(dynamics, costs, constraints)` of the reference (src/solver.jl:28-46) for a batch: `dynamics[1]`, `costs[1]`,
+`constraints[1]` are the stage objects (uniform over the horizon in this wrapper; distinct per-step objects are lowered by
+the Python host, lowering.py), `costs[end]` / `constraints[end]` the terminal ones.
+"""
+function Solver(dynamics::Vector{Dynamics}, costs::Vector{Cost}, constraints::Vector{Constraint};
+                batch::Integer, options::Options = Options(), name::AbstractString = "user", device::Integer = 0)
+    d, cs, ct = dynamics[1], constraints[1], constraints[end]
+    source = d.body * costs[1].body * costs[end].body * cs.body * ct.body
+    regname = Vector{UInt8}(undef, 128); path = Vector{UInt8}(undef, 1024)
+    GC.@preserve name source begin
+        ms = ModelSource(Base.unsafe_convert(Cstring, name), d.num_state, d.num_action, d.num_parameter,
+                         cs.num_constraint, ct.num_constraint, ineq_mask(cs.indices_inequality), ineq_mask(ct.indices_inequality),
+                         Base.unsafe_convert(Cstring, source))
+        check(ccall((:ilqr_compile_model, LIB[]), Cint, (Ref{ModelSource}, Ptr{UInt8}, Csize_t, Ptr{UInt8}, Csize_t),
+                    ms, regname, length(regname), path, length(path)))
+    end
+    Solver(unsafe_string(pointer(regname)); horizon = length(costs), batch = batch, constrained = true, options = options,
+           device = device, model_library = unsafe_string(pointer(path)))
+end
+
+# solve!(solver; augmented_lagrangian_callback! = cb) — src/solve.jl:88,125: the outer AL loop stepped from the host, one launch
+# per outer iteration (ILQR_STAGE_AL_BEGIN = 7, ILQR_STAGE_AL_OUTER = 8), cb(solver) after every dual update
+function solve!(s::Solver, augmented_lagrangian_callback!::Function)
+    check(ccall((:ilqr_set_options, LIB[]), Cint, (Ptr{Cvoid}, Ref{Options}), s.handle, s.options))
+    check(ccall((:ilqr_run_stage, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, 7))
+    done = ccall((:ilqr_scalar_slot, LIB[]), Cint, (Cstring,), "done")
+    nsc = ccall((:ilqr_scalar_slot, LIB[]), Cint, (Cstring,), "count")
+    sc = Matrix{Float64}(undef, nsc, s.B)
+    for _ in 1:s.options.max_dual_updates
+        check(ccall((:ilqr_run_stage, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, 8))
+        check(ccall((:ilqr_get_buffer, LIB[]), Cint, (Ptr{Cvoid}, Cstring, Ptr{Float64}), s.handle, "_scalars", sc))
+        all(sc[done + 1, :] .!= 0.0) && break
+        augmented_lagrangian_callback!(s)
+    end
+    return nothing
+end
+
+# 0 = auto, 1 = latency, 2 = throughput, 3 = packed (four instances per wave, no horizon limit)
+set_kernel_variant!(s::Solver, v::Integer) = check(ccall((:ilqr_set_kernel_variant, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, v))
+
+# what `verbose` prints per inner iteration (src/solve.jl:40-45), recorded on the device: rows of
+# (outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts) per instance
+enable_trace!(s::Solver, capacity::Integer) = check(ccall((:ilqr_enable_trace, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, capacity))
+function trace(s::Solver, capacity::Integer)
+    out = Array{Float64,3}(undef, 8, capacity, s.B)
+    check(ccall((:ilqr_get_trace, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}), s.handle, out))
+    return out
 end
 
 end # module

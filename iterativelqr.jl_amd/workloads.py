@@ -16,9 +16,11 @@ CONFIGS = {
     # same model and inputs, convergence tolerances tightened to 1e-9 (CONFIG_OPTIONS): BASELINE's setting converges in 1.6
     # inner iterations on average, this one takes ~20 (4..50) — the workload on which the large-model kernels are profiled
     "synth32_tight": ("synth32", 101, True),
+    "synth32_tight11": ("synth32", 101, True),     # tolerances 1e-11: ~76 iterations (17..104), few idle SIMDs at the end
 }
 # per-config solver options (src/options.jl:1-15 fields) that differ from the defaults
-CONFIG_OPTIONS = {"synth32_tight": dict(objective_tolerance=1.0e-9, lagrangian_gradient_tolerance=1.0e-9)}
+CONFIG_OPTIONS = {"synth32_tight": dict(objective_tolerance=1.0e-9, lagrangian_gradient_tolerance=1.0e-9),
+                  "synth32_tight11": dict(objective_tolerance=1.0e-11, lagrangian_gradient_tolerance=1.0e-11)}
 DIMS = {"particle": (2, 1), "acrobot": (4, 1), "car": (3, 2), "car_goal": (3, 2), "car_obs": (3, 2),
         "pendulum_euler": (2, 1), "synth32": (32, 8)}
 
