@@ -5,12 +5,13 @@ The reference keeps a Vector of objects over t (src/solver.jl:11-46, src/data/*.
 step t. The device kernel is specialised at compile time on one Dynamics / stage Cost / stage Constraint, so
 distinct objects are LOWERED here, exactly, onto that template:
 
-  * the K distinct stage objects of a category (by identity, in order of first appearance) become one
-    combined object that takes K extra per-timestep parameters s_k(t) ∈ {0, 1} (one-hot "selectors"):
-        ℓ(x,u,w)  = Σ_k s_k ℓ_k(x,u,w)            f(x,u,w) = Σ_k s_k f_k(x,u,w)
-        c(x,u,w)  = [s_1 c_1(x,u,w); …; s_K c_K(x,u,w)]   (rows concatenated, inequality indices shifted)
-  * products with 0/1 and sums with 0 are exact in IEEE arithmetic, derivatives are taken after the
-    combination, so values, gradients, Jacobians and Hessians of step t are those of object t;
+  * the K distinct stage objects of a category (structurally distinct traced expressions, in order of first appearance)
+    become one combined object that takes K extra per-timestep parameters s_k(t) ∈ {0, 1} (one-hot "selectors"):
+        ℓ(x,u,w)  = Σ_k [s_k ? ℓ_k(x,u,w) : 0]     f(x,u,w) = Σ_k [s_k ? f_k(x,u,w) : 0]
+        c(x,u,w)  = [s_1 ? c_1 : 0; …; s_K ? c_K : 0]     (rows concatenated, inequality indices shifted)
+  * the selection is a ternary in the generated code (sympy Piecewise, carried through every derivative), sums with 0 are
+    exact in IEEE arithmetic, so values, gradients, Jacobians and Hessians of step t are those of object t — also where a
+    switched-off kind would evaluate to NaN / Inf (0 · NaN would poison a product form);
   * the rows of constraint kinds that are switched off at step t read c = 0 with zero Jacobian: their
     multipliers stay 0 (λ ← max(0, λ + ρ·0) or λ + ρ·0, src/augmented_lagrangian.jl:100-108), they add nothing
     to the AL cost, its gradient and Gauss-Newton Hessian (src/augmented_lagrangian.jl:39-66,
@@ -22,19 +23,36 @@ The selectors ride in the parameter trajectory θ_t behind the user's own parame
 arrays (x1, ū, trajectories, gains) are then the padded ones, with `state_dims[t]` / `action_dims[t]` real entries.
 """
 import numpy as np
+import sympy as sp
 
 from .codegen import Constraint, Cost, Dynamics
 
 
+def _key(o):
+    """Structural identity of a traced object: two objects built from the same function (say, `[Constraint(f, ...) for t in
+    range(T - 1)]`) are ONE kind, and every zero-row constraint is the same empty kind — otherwise each would get its own
+    selector column in θ_t."""
+    if isinstance(o, Constraint):
+        if o.num_constraint == 0:
+            return ("constraint", 0)
+        return ("constraint", o.num_constraint, o.num_state, o.num_action, o.num_parameter, tuple(o.evaluate),
+                tuple(o.indices_inequality))
+    if isinstance(o, Cost):
+        return ("cost", o.num_state, o.num_action, o.num_parameter, o.evaluate)
+    return ("dynamics", o.num_next_state, o.num_state, o.num_action, o.num_parameter, tuple(o.evaluate))
+
+
 def _kinds(objs):
-    kinds, index = [], []
+    kinds, keys, index = [], [], []
     for o in objs:
-        for k, q in enumerate(kinds):
-            if q is o:
+        key = _key(o)
+        for k, q in enumerate(keys):
+            if kinds[k] is o or q == key:
                 index.append(k)
                 break
         else:
             kinds.append(o)
+            keys.append(key)
             index.append(len(kinds) - 1)
     return kinds, index
 
@@ -81,8 +99,13 @@ def lower(dynamics, costs, constraints=None):
             if name in blocks:
                 sel[t, blocks[name] - nwu + idx[t]] = 1.0
 
-    def gate(name, k, w):
-        return w[blocks[name] + k] if name in blocks else 1
+    def gate(name, k, w, expr):
+        """expr where kind k of the category is selected at this step, 0 elsewhere — a real SELECT (ternary in the generated
+        code, carried through every derivative), not a product with the selector: 0 · NaN = NaN, and a kind that is
+        switched off may well be outside its domain (sqrt, log, 1/x) at a step where the reference never calls it."""
+        if name not in blocks:
+            return expr
+        return sp.Piecewise((expr, w[blocks[name] + k] > 0.5), (0, True))
 
     # the traced objects all use the same symbols x0.., u0.., w0.. (codegen._variables), so their expressions can be
     # combined directly; the lambdas only pick up the selector symbols
@@ -90,9 +113,9 @@ def lower(dynamics, costs, constraints=None):
     # padded actions get the cost u²/2 so that Quu stays positive definite — block-diagonal with the real block, so
     # its Cholesky and solves leave the real block untouched and return K = 0, k = 0 for the padding (u stays 0);
     # padded states never enter any function, so their rows/columns of fx, Qxx, Qux, P are exactly zero.
-    dyn = Dynamics(lambda x, u, w: [sum(gate("dynamics", k, w) * (d.evaluate[i] if i < d.num_next_state else 0)
+    dyn = Dynamics(lambda x, u, w: [sum(gate("dynamics", k, w, d.evaluate[i] if i < d.num_next_state else 0)
                                         for k, d in enumerate(dk)) for i in range(n)], n, m, nw)
-    cost_stage = Cost(lambda x, u, w: sum(gate("cost", k, w) * (c.evaluate + sum(u[j] * u[j] for j in range(c.num_action, m)) / 2)
+    cost_stage = Cost(lambda x, u, w: sum(gate("cost", k, w, c.evaluate + sum(u[j] * u[j] for j in range(c.num_action, m)) / 2)
                                           for k, c in enumerate(ck)), n, m, nw)
     cost_term_l = Cost(lambda x, u, w: cost_term.evaluate, n, 0, nw)
     con_stage = con_term_l = None
@@ -105,7 +128,7 @@ def lower(dynamics, costs, constraints=None):
         total = sum(q.num_constraint for q in kk)
         assert total <= 64, "at most 64 stage constraint rows over all kinds"
         if total:
-            con_stage = Constraint(lambda x, u, w: [gate("constraint", k, w) * e for k, c in enumerate(kk) for e in c.evaluate],
+            con_stage = Constraint(lambda x, u, w: [gate("constraint", k, w, e) for k, c in enumerate(kk) for e in c.evaluate],
                                    n, m, indices_inequality=ineq, num_parameter=nw)
         else:
             con_stage = Constraint()

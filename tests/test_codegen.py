@@ -247,3 +247,27 @@ def test_time_varying_dimensions_lowering():
         ell = pkg.codegen.sp.sympify(Cs.evaluate).subs(sub)
         pad = sum(Cs.u[j] ** 2 for j in range(m_t[t], 2)) / 2
         assert pkg.codegen.sp.simplify(ell - costs[t].evaluate - pad) == 0          # u²/2 on padded actions only
+
+
+def test_lowering_selects_instead_of_multiplying_and_dedupes_kinds():
+    """A kind that is switched off at a step may be outside its domain there (the reference never calls it): the lowered
+    template must SELECT, not multiply by 0 (0 · NaN = NaN). Objects traced from the same function are one kind."""
+    import sympy as sp
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
+    T = 5
+    dyn = pkg.Dynamics(lambda x, u: [x[0] + 0.1 * u[0]], 1, 1)
+    cost_a = pkg.Cost(lambda x, u: x[0] * x[0] + u[0] * u[0], 1, 1)
+    cost_b = pkg.Cost(lambda x, u: sp.sqrt(x[0] - 5.0) + u[0] * u[0], 1, 1)        # NaN for x0 < 5
+    term = pkg.Cost(lambda x, u: x[0] * x[0], 1, 0)
+    cons = [pkg.Constraint(lambda x, u: [u[0] - 1.0], 1, 1, indices_inequality=[1]) for _ in range(T - 1)] + [pkg.Constraint()]
+    low = pkg.lowering.lower([dyn] * (T - 1), [cost_a, cost_a, cost_b, cost_a, term], cons)
+    assert low["selectors"].shape[1] == 2                            # two cost kinds; the T-1 identical constraints are ONE kind
+    Cs = low["cost_stage"]
+    nwu = low["num_user_parameter"]
+    on_a = {Cs.w[nwu + 0]: 1.0, Cs.w[nwu + 1]: 0.0, Cs.x[0]: 0.5, Cs.u[0]: 2.0}
+    for expr, want in ((Cs.evaluate, 0.25 + 4.0), (Cs.gradient_state[0], 1.0), (Cs.hessian_state_state[0][0], 2.0)):
+        val = complex(sp.sympify(expr).subs(on_a).evalf())
+        assert val.imag == 0.0 and abs(val.real - want) < 1e-14, (expr, val)
+    src = pkg.codegen.generate_model_source("sel", low["dynamics"], low["cost_stage"], low["cost_term"], low["con_stage"], low["con_term"])[1]
+    assert "?" in src                                                # the selection is a ternary in the device code
