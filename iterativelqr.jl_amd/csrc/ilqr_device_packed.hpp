@@ -575,10 +575,18 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         const double Qx = mfma444(fx, p, o.gx);                         // (:44-49)
         const double Qu = mfma444(fu, p, o.gu);
         double Uc[m * m];
+        if constexpr (m == 1) {
+            // Quu(0,0) of the block sits on lane 4*beta: DPP quad broadcast hands it to row 0 (K's row), one v_permlane16_swap
+            // to row 1 (k's row) — no LDS round trip (ds_bpermute) on the serial chain; rows 2, 3 are padding
+            const double q0 = quad_bcast<0>(Quu);
+            const double q1 = from_lane_minus16_odd_rows(q0);
+            Uc[0] = (r & 1) ? q1 : q0;                                                                        // (:68-69)
+        } else {
 #pragma unroll
-        for (int jj = 0; jj < m; ++jj)
+            for (int jj = 0; jj < m; ++jj)
 #pragma unroll
-            for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;   // (:68-69)
+                for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;   // (:68-69)
+        }
         int info = 0;
         double Ur[m];
         if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;

@@ -254,6 +254,12 @@ def test_unconstrained_solver_path(pkg, oracle):
     sol = pkg.Solver(model="pendulum_euler", horizon=T, batch=B, constraints=False, options=pkg.Options(verbose=0))
     sol.initialize_rollout_(x1, ub); sol.solve_()
     x, u = sol.get_trajectory(); st = sol.stats()
+    pk = pkg.Solver(model="pendulum_euler", horizon=T, batch=B, constraints=False, options=pkg.Options(verbose=0))
+    pk.set_kernel_variant_("packed")
+    pk.initialize_rollout_(x1, ub); pk.solve_()
+    assert np.abs(pk.get_trajectory()[0] - x).max() < 1e-9 and (pk.stats()["iterations"] == st["iterations"]).all()
+    assert (pk.stats()["outer_iterations"] == 0).all()
+    pk.close()
     ref = oracle.solve_batch("pendulum_euler", T, x1, ub, nthreads=4)
     assert (st["iterations"] == ref["stats"]["iterations"]).all()
     assert np.abs(x - ref["x"]).max() < 1e-8 and np.abs(u - ref["u"]).max() < 1e-8
@@ -273,8 +279,9 @@ OPTION_SETS = [
 ]
 
 
+@pytest.mark.parametrize("variant", ["auto", "packed"])
 @pytest.mark.parametrize("opts", OPTION_SETS, ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
-def test_options_control_flow(pkg, oracle, opts):
+def test_options_control_flow(pkg, oracle, opts, variant):
     """Every Options field that steers the solve loops (src/options.jl:1-15, src/solve.jl) must steer
     the device loops identically: same iteration / rollout / outer counts and the same trajectories."""
     B, T = 12, 21
@@ -282,6 +289,7 @@ def test_options_control_flow(pkg, oracle, opts):
     x1 = np.zeros((B, 3)); x1[:, :2] = 0.05 * rng.standard_normal((B, 2))
     ub = 1.0e-2 * np.array([1.0, 0.1]) * (1.0 + 0.5 * rng.uniform(-1, 1, (B, T - 1, 1)))
     sol = pkg.Solver(model="car", horizon=T, batch=B, options=pkg.Options(verbose=0, **opts))
+    sol.set_kernel_variant_(variant)
     sol.initialize_rollout_(x1, ub); sol.solve_()
     x, u = sol.get_trajectory(); st = sol.stats()
     ref = oracle.solve_batch("car", T, x1, ub, options=oracle.default_options(**opts), nthreads=4)
@@ -304,6 +312,12 @@ def test_warm_start_resolve_and_minimal_horizon(pkg, oracle):
     sol = pkg.Solver(model="particle", horizon=T, batch=B, options=pkg.Options(verbose=0))
     sol.initialize_rollout_(x1, ub); sol.solve_(); sol.solve_()
     x, u = sol.get_trajectory(); st = sol.stats()
+    pk = pkg.Solver(model="particle", horizon=T, batch=B, options=pkg.Options(verbose=0))      # the same on the packed kernel
+    pk.set_kernel_variant_("packed")
+    pk.initialize_rollout_(x1, ub); pk.solve_(); pk.solve_()
+    xp, up = pk.get_trajectory()
+    assert np.abs(xp - x).max() < 1e-9 and (pk.stats()["iterations"] == st["iterations"]).all()
+    pk.close()
     pr = oracle.Problem("particle", T)
     for b in range(B):
         s = oracle.Solver(pr); s.initialize_controls(ub[b]); s.initialize_states(pr.rollout(x1[b], ub[b]))
