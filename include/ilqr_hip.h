@@ -171,7 +171,7 @@ int ilqr_scalar_slot(const char* name);
  * state in LDS — while the batch fits the chip (one instance per SIMD); the throughput kernel — one wave per
  * instance, two instances per SIMD, Jacobians in HBM/L2 — up to two instances per SIMD; beyond that the packed
  * kernel — FOUR instances per wave on the four blocks of v_mfma_f64_4x4x4, workspace streamed from HBM/L2, no LDS
- * and therefore no horizon limit; nx <= 4, nu <= 2), 1 = latency, 2 = throughput, 3 = packed. All run the same
+ * and therefore no horizon limit; nx, nu <= 4), 1 = latency, 2 = throughput, 3 = packed. All run the same
  * arithmetic up to the association of a few sums. Horizons whose LDS-resident set exceeds the 160 KiB of a CU run
  * on the packed kernel only (ILQR_ERR_LDS for models without one). */
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);

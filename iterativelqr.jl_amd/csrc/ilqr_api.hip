@@ -342,7 +342,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
         // the reference has no horizon limit (src/data/problem.jl:25-46); here only the streaming (packed) kernel is free of one
         delete h;
         return fail(ILQR_ERR_LDS, "per-instance working set exceeds the 160 KiB LDS of a gfx950 CU and this model has no "
-                                  "streaming (packed) kernel (nx <= 4, nu <= 2 only); reduce the horizon");
+                                  "streaming (packed) kernel; reduce the horizon");
     }
     // from here on every failure must release the handle
     auto bail = [&](hipError_t e, const char* what) {
@@ -476,7 +476,7 @@ int ilqr_solve(ilqr_handle* h) {
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, h->stream) != hipSuccess)
         return drop(fail(ILQR_ERR_HIP, "hipEventCreate/Record failed"));
     // auto: the latency kernel while the batch fits the chip (one instance per SIMD); larger batches take the packed
-    // kernel (four instances per wave, workspace streamed from HBM / L2) when the model has one (nx <= 4, nu <= 2),
+    // kernel (four instances per wave, workspace streamed from HBM / L2) when the model has one (nx, nu <= 4),
     // the throughput kernel otherwise.
     // Horizons whose LDS-resident set exceeds 160 KiB run on the packed kernel only.
     const bool can_pack = h->vt->launch_solve_packed != nullptr;
@@ -617,7 +617,7 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
     if (!h || variant < 0 || variant > 3) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency), 2 (throughput) or 3 (packed)");
     if (variant == 3 && h->vt->launch_solve_packed == nullptr)
-        return fail(ILQR_ERR_INVALID, "the packed variant exists for models with nx <= 4, nu <= 2 only");
+        return fail(ILQR_ERR_INVALID, "the packed variant exists for small models (nx, nu <= 4) only");
     if ((variant == 1 || variant == 2) && !h->lds_fits)
         return fail(ILQR_ERR_LDS, "this horizon exceeds the LDS-resident kernels: only the packed variant can run it");
     if (variant == 2 && h->vt->launch_solve_slim == nullptr)

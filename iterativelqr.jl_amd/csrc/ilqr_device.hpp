@@ -1385,7 +1385,7 @@ extern "C" struct ilqr_model_vtable {
     int (*launch_init)(const ilqr::KArgs* a, void* stream);
     int (*launch_solve_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
     int (*launch_stage_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
-    int (*launch_solve_packed)(const ilqr::KArgs* a, void* stream);                   // four instances per wave, no LDS; null unless nx <= 4, nu <= 2
+    int (*launch_solve_packed)(const ilqr::KArgs* a, void* stream);                   // four instances per wave, no LDS; null for large models
 };
 
 namespace ilqr {

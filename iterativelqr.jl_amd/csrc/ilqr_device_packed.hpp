@@ -1,4 +1,4 @@
-// Packed kernel for small models (nx <= 4, nu <= 2): FOUR problem instances per wavefront, no LDS.
+// Packed kernel for small models (nx, nu <= 4): FOUR problem instances per wavefront, no LDS-resident state.
 //
 // Why: at one instance per wave every issued instruction does one instance's worth of work (the serial phases are
 // wave-uniform arithmetic: <= 16 useful lanes in the MFMA Riccati step, 1 in the rollout chain), and the SIMDs saturate
@@ -25,11 +25,7 @@
 
 namespace ilqr {
 
-template <class M> struct packed_ok { static constexpr bool value = (M::NX <= 4 && M::NU <= 2); };
-
-#ifndef ILQR_PK_FUSED
-#define ILQR_PK_FUSED 1      // 0: separate linearisation / Riccati / sensitivity sweeps through HBM (the first version; kept for A/B runs)
-#endif
+template <class M> struct packed_ok { static constexpr bool value = (M::NX <= 4 && M::NU <= 4); };
 
 namespace pk {
 
@@ -195,208 +191,6 @@ __device__ void cost_bang(PInst<M>& I, bool act, bool mode_current, bool constra
     }
 }
 
-// -------------------------------------------------------------- gradients! (row mapping, one timestep per lane of a row)
-// Everything streams to the HBM block, so only what changes is touched: the Jacobians are written (`.=`), the cost
-// Hessians and the Gauss-Newton AL terms accumulate (`.+=`, Q1) through the generated accumulators that visit only the
-// structurally non-zero entries (M::cost_*_hess_acc, M::al_s / M::al_t — adding an exact 0.0 is the identity).
-template <class M>
-__device__ void gradients(PInst<M>& I, bool act, bool constrained) {
-    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
-    const Layout& L = I.L;
-    const int T = L.T, N = T - 1;
-    double* g = I.g;
-    if (act) {
-        for (int t = I.j; t < T; t += 16) {                              // Hessians accumulate: each timestep exactly once
-            double w[cdim<M::NW>::v];
-            load_w<M::NW>(g + L.w, t, w);
-            double xt[n];
-#pragma unroll
-            for (int i = 0; i < n; ++i) xt[i] = g[L.xb + t * n + i];
-            double* gxx = g + L.gxx + t * n * n;
-            if (t < N) {
-                double ut[m];
-#pragma unroll
-                for (int i = 0; i < m; ++i) ut[i] = g[L.ub + t * m + i];
-                M::dyn_jac_mem(xt, ut, w, g + L.fx + t * n * n, g + L.fu + t * n * m);     // `.=`  (src/dynamics.jl:45-46)
-                double gx[n], gu[m];
-                M::cost_s_grad(xt, ut, w, gx, gu);                                          // `.=`  (src/costs.jl:61,65)
-                double* guu = g + L.guu + t * m * m;
-                double* gux = g + L.gux + t * m * n;
-                M::cost_s_hess_acc(xt, ut, w, gxx, guu, gux);                               // `.+=` (src/costs.jl:74-80)
-                if constexpr (ncs > 0) {
-                    if (constrained) {                                                      // src/gradients.jl:54-80
-                        double ct[ncs], ir[ncs];
-                        const int off = t * ncs;
-#pragma unroll
-                        for (int i = 0; i < ncs; ++i) {
-                            ir[i] = g[L.rho + off + i] * g[L.act + off + i];
-                            ct[i] = g[L.lam + off + i] + ir[i] * g[L.c + off + i];
-                        }
-                        M::al_s(xt, ut, w, ct, ir, gx, gu, gxx, guu, gux);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < n; ++i) g[L.gx + t * n + i] = gx[i];
-#pragma unroll
-                for (int i = 0; i < m; ++i) g[L.gu + t * m + i] = gu[i];
-            } else {
-                double gx[n];
-                M::cost_t_grad(xt, w, gx);
-                M::cost_t_hess_acc(xt, w, gxx);
-                if constexpr (nct > 0) {
-                    if (constrained) {
-                        double ct[nct], ir[nct];
-                        const int off = N * ncs;
-#pragma unroll
-                        for (int i = 0; i < nct; ++i) {
-                            ir[i] = g[L.rho + off + i] * g[L.act + off + i];
-                            ct[i] = g[L.lam + off + i] + ir[i] * g[L.c + off + i];
-                        }
-                        M::al_t(xt, w, ct, ir, gx, gxx);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < n; ++i) g[L.gx + t * n + i] = gx[i];
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// ------------------------------------------------- backward_pass! + lagrangian_gradient! on all four MFMA blocks
-// Block beta runs the recursion of instance beta (the one-wave recursion of ilqr_device.hpp, ROLE 0). The right-hand side
-// of k shares K's triangular solve through the spare rows m..2m-1 of the block (K occupies rows 0..m-1).
-// act_blk: per-lane predicate (instance beta takes part). Returns the per-instance ‖∇L‖∞ and potrf info in the ROW mapping.
-template <class M>
-__device__ void backward_pass(PInst<M>& I, unsigned mask, double& gnorm_row, int& info_row) {
-    constexpr int n = M::NX, m = M::NU;
-    static_assert(n <= 4 && m <= 2, "packed Riccati step: nx <= 4, nu <= 2");
-    const Layout& L = I.L;
-    const int lane = I.lane, r = I.r, c = I.c, N = L.T - 1;
-    const bool on = I.valid_blk && ((mask >> I.beta) & 1u);
-    double* g = I.gb;
-    const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n, vmm = on && r < m && c < m;
-    const bool vn1 = on && c == 0 && r < n, vm1 = on && c == 0 && r < m;
-    const double* zero = g + L.gzero;
-    double* trash = g + L.gzero + 1;
-    // operand pointers: base + t * stride (non-negative offsets), padding lanes read the block's 0.0 with stride 0
-    const double* bfx = vnn ? g + L.fx + c * n + r : zero;    const int sfx = vnn ? n * n : 0;
-    const double* bfu = vnm ? g + L.fu + c * n + r : zero;    const int sfu = vnm ? n * m : 0;
-    const double* bgx = vn1 ? g + L.gx + r : zero;            const int sgx = vn1 ? n : 0;
-    const double* bgu = vm1 ? g + L.gu + r : zero;            const int sgu = vm1 ? m : 0;
-    const double* bxx = vnn ? g + L.gxx + c * n + r : zero;   const int sxx = vnn ? n * n : 0;
-    const double* buu = vmm ? g + L.guu + c * m + r : zero;   const int suu = vmm ? m * m : 0;
-    const double* bux = vmn ? g + L.gux + c * m + r : zero;   const int sux = vmn ? m * n : 0;
-    double* qK = vmn ? g + L.K + c * m + r : trash;           const int sK = vmn ? m * n : 0;
-    double* qk = vm1 ? g + L.k + r : trash;                   const int sk = vm1 ? m : 0;
-    double* qLu = vm1 ? g + L.Lu + r : trash;
-    double* qLx = vn1 ? g + L.Lx + r : trash;                 const int sLx = vn1 ? n : 0;
-
-    double P = vnn ? g[L.gxx + N * n * n + c * n + r] : 0.0;            // P[H] .= gxx[H]  (:39)
-    double p = vn1 ? g[L.gx + N * n + r] : 0.0;                         // p[H] .= gx[H]   (:40)
-    double gmax = 0.0;
-    int pinfo = 0;
-    struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
-    auto fetch = [&](Opnd& o, int tp) {
-        o.gxx = bxx[tp * sxx]; o.guu = buu[tp * suu]; o.gux = bux[tp * sux];
-        o.fx = bfx[tp * sfx]; o.fu = bfu[tp * sfu]; o.gx = bgx[tp * sgx]; o.gu = bgu[tp * sgu];
-    };
-    const int rr = (m == 2) ? (r & 1) : 0;                              // row inside a right-hand-side set
-    // potrs('U') of the right-hand sides held as Y(r, c): K in rows 0..m-1, k (column 0) in rows m..2m-1   (:70-75)
-    auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
-        if (m == 1 && info == 0) {
-            Y = Y * recip_fast(Uc[0]);                                              // see ilqr_device.hpp: 1x1 shortcut
-        } else {
-#pragma unroll
-            for (int i = 0; i < m; ++i) {                               // U^T y = b
-#pragma unroll
-                for (int l = 0; l < i; ++l) {
-                    const double yl = from_lane_minus16_odd_rows(Y);    // m == 2: row 1 <- row 0, row 3 <- row 2
-                    const double v = Y - Uc[i * m + l] * yl;
-                    Y = (rr == i) ? v : Y;
-                }
-                const double qv = Y * Ur[i];
-                Y = (rr == i) ? qv : Y;
-            }
-#pragma unroll
-            for (int i = m - 1; i >= 0; --i) {                          // U x = y
-#pragma unroll
-                for (int l = i + 1; l < m; ++l) {
-                    const double xl = from_lane_plus16_even_rows(Y);    // m == 2: row 0 <- row 1, row 2 <- row 3
-                    const double v = Y - Uc[l * m + i] * xl;
-                    Y = (rr == i) ? v : Y;
-                }
-                const double qv = Y * Ur[i];
-                Y = (rr == i) ? qv : Y;
-            }
-        }
-        return Y * -1.0;                                                // K .*= -1, k .*= -1
-    };
-    const int blk0 = (lane & 12);                                       // lane of element (0, 0) of this block
-    auto riccati_step = [&](const Opnd& o, int t) {
-        ILQR_ISA_MARK("riccati_step", 3);
-        const double fx = o.fx, fu = o.fu;
-        // (:52-64)
-        const double W = mfma444(P, fx, 0.0);
-        const double Wu = mfma444(P, fu, 0.0);
-        const double Qxx = mfma444(W, fx, o.gxx);
-        const double Qux = mfma444(Wu, fx, o.gux);
-        const double Quu = mfma444(Wu, fu, o.guu);
-        const double Qx = mfma444(fx, p, o.gx);                         // (:44-49)
-        const double Qu = mfma444(fu, p, o.gu);
-        // potrf('U') of the block's Quu: element (i, j) lives on lane j + 4*beta + 16*i   (:68-69)
-        double Uc[m * m];
-#pragma unroll
-        for (int jj = 0; jj < m; ++jj)
-#pragma unroll
-            for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;
-        int info = 0;
-        double Ur[m];
-        if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
-        else info = potrf_U<m>(Uc, Ur);
-        if (m == 1 && info != 0) potrf_U<m>(Uc, Ur);
-        if (info != 0 && pinfo == 0) pinfo = info;
-        // right-hand sides: Qux in rows 0..m-1, Qu (column 0) moved down into rows m..2m-1
-        const double Qu_dn = (m == 1) ? from_lane_minus16_odd_rows(Qu) : from_lane_minus32(Qu);
-        const bool krow = (r >= m && r < 2 * m && c == 0);
-        const double Y = solve(krow ? Qu_dn : Qux, Uc, Ur, info);
-        const double K = (r < m) ? Y : 0.0;                             // rows >= m of K must read as zero in the products
-        const double kY = krow ? Y : 0.0;
-        const double k_up = (m == 1) ? from_lane_plus16_even_rows(kY) : from_lane_plus32(kY);   // back to rows 0..m-1, column 0
-        const double k = (r < m && c == 0) ? k_up : 0.0;
-        const double uxt = mfma444(Quu, K, 0.0);                        // ux_tmp = Quu K   (:79)
-        double Pn = mfma444(K, uxt, 0.0);                               // (:81-84)
-        Pn = mfma444(K, Qux, Pn);
-        Pn = mfma444(Qux, K, Pn);
-        Pn += Qxx;
-        double pn = mfma444(uxt, k, 0.0);                               // (:86-89)
-        pn = mfma444(K, Qu, pn);
-        pn = mfma444(Qux, k, pn);
-        pn += Qx;
-        const double Lx = Qx - pn;                                      // src/solve.jl:73-81
-        gmax = nanmax(gmax, fabs(Lx));
-        gmax = nanmax(gmax, fabs(Qu));
-        qK[t * sK] = K; qk[t * sk] = k; qLu[t * sk] = Qu; qLx[t * sLx] = Lx;
-        P = Pn; p = pn;
-    };
-    Opnd A, B;
-    if (N > 0) fetch(A, N - 1);
-    int t = N - 1;
-    for (; t >= 1; t -= 2) {                                            // (:42)
-        fetch(B, t - 1);
-        riccati_step(A, t);
-        if (t >= 2) fetch(A, t - 2);
-        riccati_step(B, t - 1);
-    }
-    if (t == 0) riccati_step(A, 0);
-    // ‖∇L‖∞ over the block (padding lanes carry exact zeros), then block -> row mapping (instance q = block q)
-    double gm = (on && c == 0) ? gmax : 0.0;
-    { double w_; w_ = __shfl_xor(gm, 16); gm = nanmax(gm, w_); w_ = __shfl_xor(gm, 32); gm = nanmax(gm, w_); }
-    gnorm_row = shfl_d(gm, 4 * I.q);
-    info_row = __shfl(pinfo, 4 * I.q);
-    __syncthreads();
-}
-
 // ------------------------------------------------- gradients! FUSED into backward_pass! (the B phase of the state machine)
 // The Riccati recursion walks time backwards in chunks of 16 steps. Each chunk is first linearised time-parallel in the ROW
 // mapping (lane j of row q: timestep 16*chunk + j of instance q) — dynamics Jacobians and cost gradients go to a 13 KB LDS
@@ -468,7 +262,8 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
                                   double& gnorm_row, int& info_row, double& delta_row) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     typedef PkLds<M> LD;
-    static_assert(n <= 4 && m <= 2, "packed Riccati step: nx <= 4, nu <= 2");
+    static_assert(n <= 4 && m <= 4, "packed Riccati step: nx, nu <= 4");
+    constexpr bool SHARE = 2 * m <= 4;      // k's right-hand side fits into the spare rows m..2m-1 of the block and shares K's solve
     extern __shared__ __attribute__((aligned(16))) double pk_lds[];
     const Layout& L = I.L;
     const int lane = I.lane, r = I.r, c = I.c, N = L.T - 1;
@@ -528,16 +323,17 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     double nu = 0.0, dacc = 0.0;                                        // adjoint of the sensitivity recursion, Δ accumulator
     double gmax = 0.0;
     int pinfo = 0;
-    const int rr = (m == 2) ? (r & 1) : 0;
+    const int rr = (m == 2) ? (r & 1) : r;                              // row inside a right-hand-side set
+    // potrs('U') of right-hand sides held as Y(r, c), rows on lanes 16 apart (m == 2: two sets, rows {0,1} and {2,3})   (:70-75)
     auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
         if (m == 1 && info == 0) {
-            Y = Y * recip_fast(Uc[0]);
+            Y = Y * recip_fast(Uc[0]);                                  // see ilqr_device.hpp: 1x1 shortcut
         } else {
 #pragma unroll
-            for (int i = 0; i < m; ++i) {
+            for (int i = 0; i < m; ++i) {                               // U^T y = b
 #pragma unroll
                 for (int l = 0; l < i; ++l) {
-                    const double yl = from_lane_minus16_odd_rows(Y);
+                    const double yl = (m == 2) ? from_lane_minus16_odd_rows(Y) : __shfl(Y, lane - 16 * (i - l));
                     const double v = Y - Uc[i * m + l] * yl;
                     Y = (rr == i) ? v : Y;
                 }
@@ -545,10 +341,10 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
                 Y = (rr == i) ? qv : Y;
             }
 #pragma unroll
-            for (int i = m - 1; i >= 0; --i) {
+            for (int i = m - 1; i >= 0; --i) {                          // U x = y
 #pragma unroll
                 for (int l = i + 1; l < m; ++l) {
-                    const double xl = from_lane_plus16_even_rows(Y);
+                    const double xl = (m == 2) ? from_lane_plus16_even_rows(Y) : __shfl(Y, lane + 16 * (l - i));
                     const double v = Y - Uc[l * m + i] * xl;
                     Y = (rr == i) ? v : Y;
                 }
@@ -593,13 +389,22 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         else info = potrf_U<m>(Uc, Ur);
         if (m == 1 && info != 0) potrf_U<m>(Uc, Ur);
         if (info != 0 && pinfo == 0) pinfo = info;
-        const double Qu_dn = (m == 1) ? from_lane_minus16_odd_rows(Qu) : from_lane_minus32(Qu);
-        const bool krow = (r >= m && r < 2 * m && c == 0);
-        const double Y = solve(krow ? Qu_dn : Qux, Uc, Ur, info);       // (:70-75)
-        const double K = (r < m) ? Y : 0.0;
-        const double kY = krow ? Y : 0.0;
-        const double k_up = (m == 1) ? from_lane_plus16_even_rows(kY) : from_lane_plus32(kY);
-        const double k = (r < m && c == 0) ? k_up : 0.0;
+        double K, k;
+        if constexpr (SHARE) {
+            // right-hand sides: Qux in rows 0..m-1, Qu (column 0) moved down into rows m..2m-1: ONE solve for K and k
+            const double Qu_dn = (m == 1) ? from_lane_minus16_odd_rows(Qu) : from_lane_minus32(Qu);
+            const bool krow = (r >= m && r < 2 * m && c == 0);
+            const double Y = solve(krow ? Qu_dn : Qux, Uc, Ur, info);   // (:70-75)
+            K = (r < m) ? Y : 0.0;
+            const double kY = krow ? Y : 0.0;
+            const double k_up = (m == 1) ? from_lane_plus16_even_rows(kY) : from_lane_plus32(kY);
+            k = (r < m && c == 0) ? k_up : 0.0;
+        } else {                                                        // nu = 3, 4: no spare rows, two solves
+            const double YK = solve(Qux, Uc, Ur, info);
+            const double Yk = solve(Qu, Uc, Ur, info);
+            K = (r < m) ? YK : 0.0;
+            k = (r < m && c == 0) ? Yk : 0.0;
+        }
         const double uxt = mfma444(Quu, K, 0.0);                        // (:79)
         double Pn = mfma444(K, uxt, 0.0);                               // (:81-84)
         Pn = mfma444(K, Qux, Pn);
@@ -648,50 +453,6 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     info_row = __shfl(pinfo, 4 * I.q);
     delta_row = shfl_d(dacc, 4 * I.q);
     __syncthreads();
-}
-
-// ------------------------------------------ trajectory_sensitivities + gradient' * dz (block mapping, MFMA forward sweep)
-template <class M>
-__device__ double delta_sweep(PInst<M>& I, unsigned mask) {
-    constexpr int n = M::NX, m = M::NU;
-    const Layout& L = I.L;
-    const int r = I.r, c = I.c, N = L.T - 1;
-    const bool on = I.valid_blk && ((mask >> I.beta) & 1u);
-    const double* g = I.gb;
-    const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n;
-    const bool vn1 = on && c == 0 && r < n, vm1 = on && c == 0 && r < m;
-    const double* zero = g + L.gzero;
-    // transposed operands straight from memory: mfma(A <- X^T, B <- v, C) = X v + C
-    const double* pKT = vnm ? g + L.K + r * m + c : zero;     const int sKT = vnm ? m * n : 0;    // K^T(r,c) = K(c,r)
-    const double* pfxT = vnn ? g + L.fx + r * n + c : zero;   const int sfxT = vnn ? n * n : 0;
-    const double* pfuT = vmn ? g + L.fu + r * n + c : zero;   const int sfuT = vmn ? n * m : 0;
-    const double* pkc = vm1 ? g + L.k + r : zero;             const int skc = vm1 ? m : 0;
-    const double* pLx = vn1 ? g + L.Lx + r : zero;            const int sLx = vn1 ? n : 0;
-    const double* pLu = vm1 ? g + L.Lu + r : zero;
-    struct Ops { double KT, fxT, fuT, kc, Lx, Lu; };
-    auto fetch = [&](Ops& o, int t) {
-        o.KT = pKT[t * sKT]; o.fxT = pfxT[t * sfxT]; o.fuT = pfuT[t * sfuT]; o.kc = pkc[t * skc]; o.Lx = pLx[t * sLx]; o.Lu = pLu[t * skc];
-    };
-    double zx = 0.0, dacc = 0.0;
-    auto step = [&](const Ops& o) {
-        ILQR_ISA_MARK("delta_step", 3);
-        const double zu = mfma444(o.KT, zx, o.kc);                      // Δu = k + K Δx
-        const double fz = mfma444(o.fxT, zx, 0.0);                      // fx Δx
-        dacc = mfma444(o.Lx, zx, dacc);                                 // += ∇L_x · Δx
-        dacc = mfma444(o.Lu, zu, dacc);                                 // += ∇L_u · Δu
-        zx = mfma444(o.fuT, zu, fz);                                    // Δx⁺ = fu Δu + fx Δx
-    };
-    Ops A, B;
-    if (N > 0) fetch(A, 0);
-    int t = 0;
-    for (; t + 1 < N; t += 2) {
-        fetch(B, t + 1);
-        step(A);
-        if (t + 2 < N) fetch(A, t + 2);
-        step(B);
-    }
-    if (t < N) step(A);
-    return shfl_d(dacc, 4 * I.q);                                       // element (0,0) of block q -> row q
 }
 
 // ------------------------------------------------------------- rollout! (row mapping, cooperative inside a row)
@@ -918,16 +679,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                 const bool first = fw && I.trial == 1;
                 if (first) { I.status = 0; I.J_prev = I.objective; I.delta = 0.0; I.step_size = 1.0; }   // (:10, :13, :26)
                 const bool want_delta = first && opt.line_search == 1;
-                const unsigned dmask = row_mask(want_delta);
-#if ILQR_PK_FUSED
-                (void)dmask;
                 if (want_delta) I.delta = I.delta_next;                                   // (:16-20) came out of the backward pass (adjoint form)
-#else
-                if (dmask && !(dbg & 2)) {                                                // (:16-20)
-                    const double d = delta_sweep<M>(I, dmask);
-                    if (want_delta) I.delta = d;
-                }
-#endif
                 // while step_size >= min_step_size && iteration <= 25   (:28-29)
                 const bool go = fw && (I.step_size >= opt.min_step_size) && (I.trial <= 25);
                 if (__any(go)) {
@@ -953,15 +705,9 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
             const bool lin = nb && (I.it == 0 || opt.line_search != 0);                   // (:16-18), (:27-33)
             const unsigned bmask = row_mask(lin);
             if (bmask) {
-                double gn = 0.0; int info = 0;
-#if ILQR_PK_FUSED
-                double dn = 0.0;
+                double gn = 0.0, dn = 0.0; int info = 0;
                 if (!(dbg & 8)) linearise_riccati<M>(I, lin, bmask, constrained, gn, info, dn);
                 if (lin) I.delta_next = dn;
-#else
-                if (!(dbg & 4)) gradients<M>(I, lin, constrained);
-                if (!(dbg & 8)) backward_pass<M>(I, bmask, gn, info);
-#endif
                 if (lin) {
                     I.gradient_norm = gn;
                     if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
@@ -991,11 +737,8 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                 }
                 if (end_inner) I.state = al_outer ? ST_OUTER : ST_DONE;
                 else { I.it += 1; I.trial = 1; I.state = ST_FORWARD; }
-#if ILQR_PK_FUSED
                 I.leaving = end_inner ? 1 : 0;
-#endif
             }
-#if ILQR_PK_FUSED
             if (__any(I.leaving != 0)) {       // write the last linearisation of the inner solve out (terminal gx[N] is already there)
                 if (I.leaving) {
                     for (int t = I.j; t < N; t += 16) {
@@ -1006,7 +749,6 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                 I.leaving = 0;
                 __syncthreads();
             }
-#endif
         }
     }
     __syncthreads();

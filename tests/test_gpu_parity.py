@@ -793,3 +793,37 @@ def test_c_host_defines_a_model_and_runs_two_handles_concurrently(pkg, tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "user-defined model matches the built-in one" in out.stdout
+
+
+@pytest.mark.parametrize("nm", [(3, 3), (4, 4), (2, 3)])
+def test_packed_kernel_with_three_and_four_actions(pkg, nm):
+    """nu = 3, 4 on the packed kernel (K and k take separate triangular solves, no spare rows in the 4x4 block), and
+    nu > nx; user-defined models through the symbolic generator, compared with the latency kernel."""
+    import sympy as sp
+    n, m = nm
+    h = 0.1
+    A = [[(-0.5 if i == j else 0.0) + 0.2 * np.cos(1.0 + i + 2 * j) for j in range(n)] for i in range(n)]
+    Bm = [[np.sin(1.0 + 3 * i + j) for j in range(m)] for i in range(n)]
+    f = lambda x, u: [x[i] + h * (sum(A[i][j] * x[j] for j in range(n)) + sum(Bm[i][j] * u[j] for j in range(m)) + 0.3 * sp.sin(x[i]))
+                      for i in range(n)]
+    dyn = pkg.Dynamics(f, n, m)
+    stage = pkg.Cost(lambda x, u: 0.5 * sum(xi * xi for xi in x) + 0.05 * sum((1 + j) * u[j] * u[j] for j in range(m)) + 0.01 * u[0] * u[m - 1], n, m)
+    term = pkg.Cost(lambda x, u: 5.0 * sum(xi * xi for xi in x), n, 0)
+    box = pkg.Constraint(lambda x, u: [u[0] - 0.8, -0.8 - u[0]], n, m, indices_inequality=[1, 2])
+    goal = pkg.Constraint(lambda x, u: [x[0] - 0.3], n, 0)
+    T, B = 31, 10
+    rng = np.random.default_rng(23)
+    x1 = rng.standard_normal((B, n)); ub = 0.3 * rng.standard_normal((B, T - 1, m))
+    res = {}
+    for v in ("latency", "packed"):
+        sol = pkg.Solver([dyn] * (T - 1), [stage] * (T - 1) + [term], [box] * (T - 1) + [goal], batch=B,
+                         options=pkg.Options(verbose=0), name="pk%d%d" % (n, m))
+        sol.set_kernel_variant_(v)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        res[v] = (sol.get_trajectory(), sol.get_policy(), sol.stats())
+        sol.close()
+    a, b = res["latency"], res["packed"]
+    assert (a[2]["iterations"] == b[2]["iterations"]).all() and (a[2]["rollouts"] == b[2]["rollouts"]).all()
+    assert a[2]["iterations"].min() >= 2 and (b[2]["max_violation"] <= 5e-3).all()
+    assert np.abs(a[0][0] - b[0][0]).max() < 1e-9 and np.abs(a[0][1] - b[0][1]).max() < 1e-9
+    assert np.abs(a[1][0] - b[1][0]).max() <= 1e-8 * max(1.0, np.abs(a[1][0]).max())
