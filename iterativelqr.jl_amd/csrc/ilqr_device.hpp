@@ -423,7 +423,7 @@ __device__ void gradients_small(Inst<M>& I, bool constrained) {
 // failed factorisation (info > 0, ignored by the reference) R holds the reciprocals of whatever is on the diagonal.
 template <int m>
 __device__ __forceinline__ int potrf_U(double (&A)[m * m], double (&R)[m]) {
-    // branch-free (selects only), so that the scheduler can interleave it with independent MFMA work
+    // selects only on the common path, so that the scheduler can interleave it with independent MFMA work
     int info = 0;
 #pragma unroll
     for (int j = 0; j < m; ++j) {
@@ -433,9 +433,13 @@ __device__ __forceinline__ int potrf_U(double (&A)[m * m], double (&R)[m]) {
         const bool ok = (info == 0) && (ajj > 0.0);
         const bool fail_now = (info == 0) && !(ajj > 0.0);
         info = fail_now ? j + 1 : info;
-        const double d = ok ? sqrt(ajj) : (fail_now ? ajj : A[j * m + j]);
+        double dq, rq;
+        sqrt_rsqrt_fast(ok ? ajj : 1.0, dq, rq);                       // pivot and its reciprocal in one sequence (ilqr_math.hpp)
+        const double dbad = fail_now ? ajj : A[j * m + j];             // after a failed factorisation: whatever is on the diagonal
+        const double d = ok ? dq : dbad;
         A[j * m + j] = d;
-        const double r = 1.0 / d;
+        double r = rq;
+        if (__builtin_expect(!ok, 0)) r = 1.0 / dbad;                  // rare (diverged instances): a real branch keeps the division off the common path
         R[j] = r;
 #pragma unroll
         for (int c = j + 1; c < m; ++c) {
