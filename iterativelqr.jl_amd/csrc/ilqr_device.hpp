@@ -614,6 +614,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         if (VEC && vn1) I.p[N * n + r] = p;
     }
     double gmax = 0.0;
+    bool gnan = false;      // ‖·‖∞ must propagate NaN like Julia's norm: v_max_f64 drops NaNs, so they are tracked beside it (3 instead of 6 slots per value)
     // operands of step t are fetched one step ahead (accumulated Hessians from HBM/L2, the rest from
     // LDS); the time loop is unrolled by two with ping-pong operand sets so no register copies are needed
     struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
@@ -749,8 +750,9 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81). The padding of Lx and
             // Qu is exactly zero, so the running ∞-norm needs no lane predicate (block 0 is picked at the end).
             const double Lx = Qx - pn;
-            gmax = nanmax(gmax, fabs(Lx));
-            gmax = nanmax(gmax, fabs(Qu));
+            gmax = fmax(gmax, fabs(Lx));
+            gmax = fmax(gmax, fabs(Qu));
+            gnan |= (Lx != Lx) | (Qu != Qu);
             if (b0) {
 #if ILQR_BW_PTR_STORES
                 *qk = k; *qLu = Qu; *qLx = Lx;
@@ -795,7 +797,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             if constexpr (ROLE == 1) __syncthreads();                   // hand the chunk over (the other half-ring is free again)
         }
     }
-    if constexpr (VEC) I.gradient_norm = wave_max((b0 && c == 0) ? gmax : 0.0);
+    if constexpr (VEC) I.gradient_norm = wave_max((b0 && c == 0) ? (gnan ? __builtin_nan("") : gmax) : 0.0);
 }
 
 template <class M, bool STORE_VALUE>

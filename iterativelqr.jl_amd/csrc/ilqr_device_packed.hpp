@@ -322,6 +322,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     double p = vn1 ? pk_lds[LD::TERM + I.beta * n + r] : 0.0;           // p[H] .= gx[H]   (:40)
     double nu = 0.0, dacc = 0.0;                                        // adjoint of the sensitivity recursion, Δ accumulator
     double gmax = 0.0;
+    bool gnan = false;
     int pinfo = 0;
     const int rr = (m == 2) ? (r & 1) : r;                              // row inside a right-hand-side set
     // potrs('U') of right-hand sides held as Y(r, c), rows on lanes 16 apart (m == 2: two sets, rows {0,1} and {2,3})   (:70-75)
@@ -415,8 +416,9 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         pn = mfma444(Qux, k, pn);
         pn += Qx;
         const double Lx = Qx - pn;                                      // src/solve.jl:73-81
-        gmax = nanmax(gmax, fabs(Lx));
-        gmax = nanmax(gmax, fabs(Qu));
+        gmax = fmax(gmax, fabs(Lx));
+        gmax = fmax(gmax, fabs(Qu));
+        gnan |= (Lx != Lx) | (Qu != Qu);
         // adjoint sensitivity step: w = ∇L_u + fuᵀν', Δ += wᵀk, ν = ∇L_x + fxᵀν' + Kᵀw
         const double wv = mfma444(fu, nu, Qu);
         dacc = mfma444(wv, k, dacc);
@@ -447,7 +449,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         if (sl == 0) riccati_step(A, t0);
         __syncthreads();                      // the chunk buffer is free again
     }
-    double gm = (on && c == 0) ? gmax : 0.0;
+    double gm = (on && c == 0) ? (gnan ? __builtin_nan("") : gmax) : 0.0;
     { double w_; w_ = __shfl_xor(gm, 16); gm = nanmax(gm, w_); w_ = __shfl_xor(gm, 32); gm = nanmax(gm, w_); }
     gnorm_row = shfl_d(gm, 4 * I.q);
     info_row = __shfl(pinfo, 4 * I.q);
