@@ -75,6 +75,10 @@ def parse_args(argv=None):
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
     ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed"])
+    ap.add_argument("--shared-step", action="store_true",
+                    help="optional mode, NOT the reference's behaviour and not the headline: one Armijo step size per inner iteration "
+                         "for the whole (multi-GPU) batch, decided on the summed merit — one all-reduce (RCCL over xGMI) of three "
+                         "doubles per line-search trial, line search stepped from the host (Solver.solve_shared_step_)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -231,7 +235,10 @@ def worker(args):
         counter[0] += 1
         s.reset_()
         s.initialize_rollout_device_(d_x1.data_ptr() if d_x1 is not None else 0, d_u.data_ptr() if d_u is not None else 0)
-        s.solve_(sync=False)
+        if args.shared_step and not stub:
+            s.solve_shared_step_(pkg.distributed.torch_allreduce_sum(dist, cdev))
+        else:
+            s.solve_(sync=False)
 
     def barrier():
         for s in sols:
@@ -282,7 +289,10 @@ def worker(args):
                                % (args.config, sol.nx, sol.nu, T, B),
                    "global_batch": world * B, "horizon": T,
                    "parallelism": "batch-shard x%d (no collective), %s" % (world, "distinct shards" if args.distinct_shards else "same %d instances per GPU" % B),
-                   "batches_in_flight": len(sols), "kernel_variant": args.variant},
+                   "batches_in_flight": len(sols), "kernel_variant": args.variant,
+                   "mode": ("shared_step: one step size per iteration for the global batch, all-reduce(sum) of 3 doubles per trial over %s, "
+                            "host-stepped line search — changes the iterates, not comparable with the reference" % (backend or "one rank"))
+                           if args.shared_step else "independent line search per instance (the reference's semantics)"},
         "ranks": {"world_size": world, "collective_backend": backend, "group_world_size": (dist.get_world_size() if dist is not None else 1),
                   "ms_per_step_per_rank": rank_ms, "slowest_rank": int(np.argmax(rank_ms)),
                   "solve_kernel_ms_per_rank": [r[1] for r in per_rank],
@@ -313,7 +323,7 @@ def worker(args):
                 # stage-materialised model a resident solve sits
                 "io_lower_bound_bytes_per_launch": io_bytes,
                 "io_lower_bound_GBs": io_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0}
-        if world == 1 and not args.no_pmc:
+        if world == 1 and not args.no_pmc and not args.shared_step:
             for s_ in sols:
                 s_.synchronize()
             tr, why = measure_traffic(args)

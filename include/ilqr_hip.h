@@ -135,9 +135,25 @@ enum {
      * AL_BEGIN once (:93-103), then AL_OUTER per outer iteration (:105-122, skipping instances that already
      * met the constraint tolerance); the caller runs its callback between AL_OUTER launches. */
     ILQR_STAGE_AL_BEGIN = 7,
-    ILQR_STAGE_AL_OUTER = 8
+    ILQR_STAGE_AL_OUTER = 8,
+    /* SHARED STEP SIZE over a whole (multi-GPU) batch — not in the reference (every Solver there line-searches alone); the
+     * optional mode of the north star: all instances take the SAME Armijo step, decided on the summed merit. The line search
+     * of forward_pass! (src/forward_pass.jl:26-52) is stepped from the host, everything else stays per instance:
+     *   SS_INNER_BEGIN            src/solve.jl:9-21 for every instance whose outer loop is still running
+     *   SS_TRIAL(alpha, first)    rollout!(alpha) + cost!(mode = :current) (src/forward_pass.jl:34-36); with first != 0 also
+     *                             J_prev and delta_grad_product (:13-20). The caller sums objective, "j_prev" and
+     *                             "delta_grad_product" over the instances with "inner_done" == 0 (and over ranks: ONE all-reduce
+     *                             of three doubles) and tests  sum J <= sum J_prev + 1e-4 alpha sum delta  (:44)
+     *   SS_FINISH(alpha, accept)  update_nominal_trajectory! or line-search failure, then src/solve.jl:27-51 per instance
+     *   SS_OUTER                  src/solve.jl:113-122 per instance
+     * (ilqr_run_stage_param; Python: Solver.solve_shared_step_). With a batch of one it reproduces solve! exactly. */
+    ILQR_STAGE_SS_INNER_BEGIN = 9,
+    ILQR_STAGE_SS_TRIAL = 10,
+    ILQR_STAGE_SS_FINISH = 11,
+    ILQR_STAGE_SS_OUTER = 12
 };
 int ilqr_run_stage(ilqr_handle* h, int32_t stage);
+int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t flag);
 
 /* get_trajectory(solver) — src/solver.jl:48-50: nominal states [B][T][nx] and
  * actions [B][T-1][nu]. */
@@ -164,7 +180,8 @@ int ilqr_enable_action_value_buffers(ilqr_handle* h);
 /* Index of a named SolverData scalar inside the "_scalars" buffer: "objective","max_violation","step_size","status",
  * "iterations","gradient_norm","outer_iterations","potrf_info","rollouts","done" (host-stepped AL loop: instance met
  * the constraint tolerance), "delta_grad_product" (∇Lᵀ·Δz of the last forward_pass!, src/forward_pass.jl:20),
- * "trace_len" (rows the last solve wrote to the trace), "count" (length of "_scalars"). -1 if unknown. */
+ * "trace_len" (rows the last solve wrote to the trace), "count" (length of "_scalars"); shared-step mode: "obj_prev",
+ * "inner_done", "j_prev", "inner_it". -1 if unknown. */
 int ilqr_scalar_slot(const char* name);
 
 /* Kernel variant of ilqr_solve: 0 = auto (default: the latency kernel — two waves per instance, all iteration

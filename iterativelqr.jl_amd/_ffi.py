@@ -54,6 +54,7 @@ SYMBOLS = {
     "ilqr_solve": (C.c_int, [C.c_void_p]),
     "ilqr_synchronize": (C.c_int, [C.c_void_p]),
     "ilqr_run_stage": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ilqr_run_stage_param": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32]),
     "ilqr_get_trajectory": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "ilqr_get_policy": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "ilqr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
@@ -75,7 +76,7 @@ SYMBOLS = {
 }
 
 STAGES = dict(cost_nominal=0, gradients=1, backward_pass=2, forward_pass=3, reset_model_objective=4,
-              ilqr_solve=5, al_update=6, al_begin=7, al_outer=8)
+              ilqr_solve=5, al_update=6, al_begin=7, al_outer=8, ss_inner_begin=9, ss_trial=10, ss_finish=11, ss_outer=12)
 
 _lib = None
 

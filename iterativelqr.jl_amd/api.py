@@ -173,6 +173,51 @@ class Solver:
                 break
             augmented_lagrangian_callback_(self)
 
+    def run_stage_param_(self, stage, param, flag):
+        _ffi.check(_ffi.lib().ilqr_set_options(self._h, C.byref(self.options)))
+        _ffi.check(_ffi.lib().ilqr_run_stage_param(self._h, _ffi.STAGES[stage], float(param), int(flag)))
+
+    def solve_shared_step_(self, allreduce_sum=None):
+        """solve! with ONE step size per inner iteration for the whole batch (all ranks): the optional mode of the north
+        star, not a reference behaviour — the reference line-searches every Solver on its own. forward_pass!'s Armijo loop
+        (src/forward_pass.jl:26-52) runs on the host over the SUMMED merit: per trial one all-reduce of three doubles
+        (Σ J(α), Σ J_prev, Σ ∇Lᵀ·Δz over the instances still in their inner loop) — `allreduce_sum(np.ndarray) -> np.ndarray`,
+        e.g. distributed.torch_allreduce_sum(dist, device) for RCCL; identity on one rank. Everything else (linearisation,
+        Riccati pass, convergence tests, dual updates) stays per instance on the device. With a batch of one instance it
+        reproduces solve_ exactly. Constrained solvers only. Returns the list of accepted step sizes."""
+        L = _ffi.lib()
+        ar = allreduce_sum if allreduce_sum is not None else (lambda v: v)
+        slot = {k: L.ilqr_scalar_slot(k.encode()) for k in ("objective", "j_prev", "delta_grad_product", "inner_done", "done")}
+        opt = self.options
+        steps = []
+        self.run_stage_("al_begin")
+        for _ in range(int(opt.max_dual_updates)):
+            self.run_stage_("ss_inner_begin")
+            for _it in range(int(opt.max_iterations)):
+                sc = self.buffer("_scalars")
+                active = (sc[:, slot["done"]] == 0.0) & (sc[:, slot["inner_done"]] == 0.0)
+                if ar(np.array([float(active.sum())]))[0] == 0.0:
+                    break
+                alpha, first, accepted, trials = 1.0, 1, 0, 1
+                while alpha >= opt.min_step_size and trials <= 25:                       # src/forward_pass.jl:28-29
+                    self.run_stage_param_("ss_trial", alpha, first)
+                    sc = self.buffer("_scalars")
+                    sums = ar(np.array([sc[active, slot["objective"]].sum(), sc[active, slot["j_prev"]].sum(),
+                                        sc[active, slot["delta_grad_product"]].sum()]))    # the data-path collective
+                    if sums[0] <= sums[1] + 1.0e-4 * alpha * sums[2]:                       # (:44) NaN ⇒ reject
+                        accepted = 1
+                        break
+                    alpha *= 0.5                                                          # (:51)
+                    first = 0
+                    trials += 1
+                self.run_stage_param_("ss_finish", alpha, accepted)
+                steps.append(alpha if accepted else 0.0)
+            self.run_stage_("ss_outer")
+            sc = self.buffer("_scalars")
+            if ar(np.array([float((sc[:, slot["done"]] == 0.0).sum())]))[0] == 0.0:
+                break
+        return steps
+
     def synchronize(self):
         _ffi.check(_ffi.lib().ilqr_synchronize(self._h))
 

@@ -101,6 +101,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.x1 = nullptr; a.u_in = nullptr;
     a.trace = h->trace; a.trace_cap = h->trace_cap;
     a.qv = h->qv; a.QL = h->QL;
+    a.stage_param = 0.0; a.stage_flag = 0;
     return a;
 }
 
@@ -500,13 +501,15 @@ int ilqr_solve(ilqr_handle* h) {
     return ILQR_OK;
 }
 
-int ilqr_run_stage(ilqr_handle* h, int32_t stage) {
+int ilqr_run_stage(ilqr_handle* h, int32_t stage) { return ilqr_run_stage_param(h, stage, 0.0, 0); }
+
+int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t flag) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
     if (!h->lds_fits) return fail(ILQR_ERR_LDS, "stage kernels are LDS-resident: this horizon only runs through ilqr_solve (packed kernel)");
     ilqr::KArgs a = make_args(h);
-    a.stage = stage;
+    a.stage = stage; a.stage_param = param; a.stage_flag = flag;
     if (stage != ILQR_STAGE_BACKWARD_PASS && stage != ILQR_STAGE_ILQR_SOLVE) a.qv = nullptr;
     // the stage runs in the mapping selected by ilqr_set_kernel_variant (2 = throughput: one wave per instance)
     if (h->variant == 2 && h->vt->launch_stage_slim != nullptr) {
@@ -581,6 +584,7 @@ int ilqr_scalar_slot(const char* name) {
         {"outer_iterations", ilqr::S_OUTER_ITERATIONS}, {"potrf_info", ilqr::S_POTRF_INFO}, {"rollouts", ilqr::S_ROLLOUTS},
         {"states_eq_nominal", ilqr::S_STATES_EQ_NOMINAL}, {"profile", ilqr::S_PROF}, {"done", ilqr::S_DONE},
         {"delta_grad_product", ilqr::S_DELTA}, {"trace_len", ilqr::S_TRACE_LEN}, {"count", ilqr::S_COUNT},
+        {"obj_prev", ilqr::S_OBJ_PREV}, {"inner_done", ilqr::S_INNER_DONE}, {"j_prev", ilqr::S_J_PREV}, {"inner_it", ilqr::S_INNER_IT},
     };
     if (!name) return -1;
     for (auto& s_ : slots)

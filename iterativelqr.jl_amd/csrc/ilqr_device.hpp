@@ -48,6 +48,8 @@ struct KArgs {
     int trace_cap;
     double* qv;          // optional action-value buffers [B][QL.stride] (backward-pass stage kernel only; null = off)
     QLayout QL;
+    double stage_param;  // stage kernel only: step size of ILQR_STAGE_SS_TRIAL / SS_FINISH
+    int stage_flag;      //                    first trial / accepted
 };
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
@@ -1262,7 +1264,7 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2
     const bool con = a.constrained != 0;
     // host-stepped AL loop (solve! with augmented_lagrangian_callback!, src/solve.jl:88,125): instances that
     // already met the constraint tolerance sit out the remaining outer iterations
-    const bool done = I.scal[S_DONE] != 0.0 && a.stage >= ILQR_STAGE_AL_BEGIN;
+    const bool done = I.scal[S_DONE] != 0.0 && a.stage > ILQR_STAGE_AL_BEGIN;      // AL_BEGIN itself re-arms a finished instance
     if (!done) switch (a.stage) {
         case ILQR_STAGE_COST_NOMINAL: cost_bang<M>(I, false, con); break;
         case ILQR_STAGE_GRADIENTS: gradients<M>(I, con); break;
@@ -1288,6 +1290,67 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2
                 if (I.lane == 0 && I.wave == 0) I.scal[S_DONE] = 1.0;
             } else {
                 al_update<M>(I, a.opt);                               // (:120-122)
+            }
+        } break;
+        // ---- shared step size over the whole batch: the line search is stepped from the host (include/ilqr_hip.h)
+        case ILQR_STAGE_SS_INNER_BEGIN: {                             // src/solve.jl:9-21
+            I.outer_iterations += 1;
+            reset_model_objective<M>(I, false);
+            if (a.opt.reset_cache) { I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; }
+            cost_bang<M>(I, false, con);                              // (:14)
+            gradients<M>(I, con);                                     // (:16)
+            backward_pass<M, false>(I);                               // (:18)
+            if (I.lane == 0 && I.wave == 0) { I.scal[S_OBJ_PREV] = I.objective; I.scal[S_INNER_DONE] = 0.0; I.scal[S_INNER_IT] = 0.0; }
+        } break;
+        case ILQR_STAGE_SS_TRIAL: {                                   // src/forward_pass.jl:10-20 (first trial), :34-36
+            if (I.scal[S_INNER_DONE] == 0.0) {
+                const bool first = a.stage_flag != 0;
+                if (first) {
+                    I.status = 0;
+                    if (I.lane == 0 && I.wave == 0) I.scal[S_J_PREV] = I.objective;
+                    I.delta = 0.0;
+                }
+                double d = 0.0;
+                const bool want_delta = first && a.opt.line_search == 1;
+                rollout_bang<M>(I, a.stage_param, want_delta, d);
+                if (want_delta) I.delta = d;
+                cost_bang<M>(I, true, con);
+            }
+        } break;
+        case ILQR_STAGE_SS_FINISH: {                                  // src/forward_pass.jl:44-52, then src/solve.jl:27-51
+            if (I.scal[S_INNER_DONE] == 0.0) {
+                constexpr int n = M::NX, m = M::NU;
+                I.step_size = a.stage_param;
+                if (a.stage_flag != 0) {                              // update_nominal_trajectory!
+                    for (int i = I.lane; i < I.T * n; i += 64) I.xb[i] = I.x[i];
+                    for (int i = I.lane; i < I.N * m; i += 64) I.ub[i] = I.u[i];
+                    I.states_eq_nominal = 1; I.status = 1;
+                    __syncthreads();
+                } else {
+                    I.status = 0;
+                }
+                if (a.opt.line_search != 0) { gradients<M>(I, con); backward_pass<M, false>(I); }
+                I.iterations += 1;
+                const int it = (int)I.scal[S_INNER_IT] + 1;
+                const double obj_prev = I.scal[S_OBJ_PREV];
+                bool stop = false;
+                if (I.gradient_norm < a.opt.lagrangian_gradient_tolerance) stop = true;
+                else if (fabs(I.objective - obj_prev) < a.opt.objective_tolerance) stop = true;
+                else if (!I.status) stop = true;
+                else if (it >= a.opt.max_iterations) stop = true;
+                __syncthreads();
+                if (I.lane == 0 && I.wave == 0) {
+                    I.scal[S_INNER_IT] = (double)it;
+                    if (stop) I.scal[S_INNER_DONE] = 1.0; else I.scal[S_OBJ_PREV] = I.objective;
+                }
+            }
+        } break;
+        case ILQR_STAGE_SS_OUTER: {                                   // src/solve.jl:113-122
+            cost_bang<M>(I, false, true);
+            if (I.max_violation <= a.opt.constraint_tolerance) {
+                if (I.lane == 0 && I.wave == 0) I.scal[S_DONE] = 1.0;
+            } else {
+                al_update<M>(I, a.opt);
             }
         } break;
         default: break;
@@ -1379,7 +1442,7 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 3   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+#define ILQR_MODEL_ABI_VERSION 4   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against

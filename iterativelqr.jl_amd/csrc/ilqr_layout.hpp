@@ -18,6 +18,8 @@ enum {
     S_DONE = 17,        // host-stepped AL loop only: instance finished
     S_DELTA = 18,       // delta_grad_product = ∇Lᵀ·Δz of the last forward_pass! (src/forward_pass.jl:20)
     S_TRACE_LEN = 19,   // rows of the per-iteration trace written by the last solve
+    // host-stepped shared-step mode only (ILQR_STAGE_SS_*): loop state of ilqr_solve! that otherwise lives in registers
+    S_OBJ_PREV = 20, S_INNER_DONE = 21, S_J_PREV = 22, S_INNER_IT = 23,
     S_COUNT = 24
 };
 

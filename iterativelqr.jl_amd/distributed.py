@@ -92,6 +92,21 @@ def sum_over_ranks(value, dist=None, device=None):
     return float(t.item())
 
 
+def torch_allreduce_sum(dist, device=None):
+    """allreduce_sum callable for Solver.solve_shared_step_: SUM over the process group of a short float64 vector
+    (RCCL when the group's backend is nccl and `device` is the rank's GPU, gloo on CPU tensors otherwise)."""
+    import numpy as np
+    import torch
+
+    def ar(v):
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return v
+        t = torch.tensor(np.asarray(v, dtype=np.float64), dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+    return ar
+
+
 def gather_over_ranks(values, dist=None, device=None):
     """All-gather a short list of floats: returns [world][len(values)] (one row without a process group)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -827,3 +827,50 @@ def test_packed_kernel_with_three_and_four_actions(pkg, nm):
     assert a[2]["iterations"].min() >= 2 and (b[2]["max_violation"] <= 5e-3).all()
     assert np.abs(a[0][0] - b[0][0]).max() < 1e-9 and np.abs(a[0][1] - b[0][1]).max() < 1e-9
     assert np.abs(a[1][0] - b[1][0]).max() <= 1e-8 * max(1.0, np.abs(a[1][0]).max())
+
+
+# ------------------------------------------------------------------ shared step size (optional mode, not a reference behaviour)
+@pytest.mark.parametrize("config", ["particle", "car", "acrobot51"])
+def test_shared_step_with_a_batch_of_one_is_the_reference_solve(pkg, config):
+    """solve_shared_step_ decides the Armijo test on the summed merit; with one instance the sum is that instance's merit,
+    so the host-stepped loop must reproduce the fused single-launch solve! (iterations, step sizes, trajectories)."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, 3)
+    for b in range(3):
+        fused = pkg.Solver(model=model, horizon=T, batch=1, options=pkg.Options(verbose=0))
+        fused.set_kernel_variant_("latency"); fused.enable_trace_(600)
+        fused.initialize_rollout_(x1[b:b + 1], ub[b:b + 1]); fused.solve_()
+        ss = pkg.Solver(model=model, horizon=T, batch=1, options=pkg.Options(verbose=0))
+        ss.initialize_rollout_(x1[b:b + 1], ub[b:b + 1])
+        steps = ss.solve_shared_step_()
+        tr = fused.trace()[0][:int(fused.scalar("trace_len")[0])]
+        assert len(steps) == tr.shape[0] and np.array_equal(np.array(steps), np.where(tr[:, 6] != 0, tr[:, 5], 0.0)), (config, b)
+        sf, s1 = fused.stats(), ss.stats()
+        for f in ("iterations", "outer_iterations", "rollouts", "status"):
+            assert sf[f][0] == s1[f][0], (config, b, f)
+        assert np.abs(fused.get_trajectory()[0] - ss.get_trajectory()[0]).max() < 1e-11
+        assert np.abs(fused.get_policy()[0] - ss.get_policy()[0]).max() <= 1e-10 * max(1.0, np.abs(fused.get_policy()[0]).max())
+        fused.close(); ss.close()
+
+
+def test_shared_step_over_two_ranks_matches_one_rank(pkg, tmp_path):
+    """The data-path collective: two ranks (gloo, both on device 0 — one GPU in the test box; RCCL takes the same call with
+    one GPU per rank) solve halves of a car batch with ONE step size per iteration for all 8 instances. The accepted steps
+    must be those of a single process solving the 8 instances, on both ranks, and every instance must end feasible."""
+    B = 8
+    model, T, x1, ub = pkg.workloads.make_inputs("car", B)
+    one = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    one.initialize_rollout_(x1, ub)
+    steps = np.array(one.solve_shared_step_())
+    x_one = one.get_trajectory()[0]; st = one.stats()
+    assert (st["max_violation"] <= 5e-3).all() and np.isfinite(x_one).all() and steps.size > 20
+    one.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "ss")
+    rc, _ = pkg.distributed.launch_ranks(os.path.join(root, "tests", "ss_worker.py"), [out, str(B)], 2, share_device=True, timeout=600)
+    assert rc == 0
+    parts = [np.load(out + ".%d.npz" % r) for r in range(2)]
+    assert np.array_equal(parts[0]["steps"], parts[1]["steps"])                      # one step size for everybody
+    assert np.array_equal(parts[0]["steps"], steps)                                  # ... the same as on one rank
+    x_two = np.concatenate([parts[0]["x"], parts[1]["x"]])
+    assert np.abs(x_two - x_one).max() < 1e-9
+    assert (np.concatenate([p["max_violation"] for p in parts]) <= 5e-3).all()
