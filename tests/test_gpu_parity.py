@@ -874,3 +874,32 @@ def test_shared_step_over_two_ranks_matches_one_rank(pkg, tmp_path):
     x_two = np.concatenate([parts[0]["x"], parts[1]["x"]])
     assert np.abs(x_two - x_one).max() < 1e-9
     assert (np.concatenate([p["max_violation"] for p in parts]) <= 5e-3).all()
+
+
+def test_lazy_reset_of_large_models_is_unobservable(pkg):
+    """ilqr_reset of an HBM-resident model defers zeroing the megabyte-sized Jacobian / Hessian / value arrays to the solve
+    kernel; a getter, setter or stage call that could see stale values first must trigger it."""
+    B, T = 3, 11
+    model, _, x1, ub = pkg.workloads.make_inputs("synth32", B)
+    ub = ub[:, :T - 1] + 0.3
+    sol = pkg.Solver(model="synth32", horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    first = sol.get_trajectory()[0].copy()
+    assert np.abs(sol.buffer("jacobian_state")).max() > 0 and np.abs(sol.buffer("hessian_state_state")).max() > 0
+    sol.run_stage_("backward_pass")                                   # writes P, p
+    assert np.abs(sol.buffer("P")).max() > 0
+    sol.reset_()
+    for name in ("jacobian_state", "jacobian_action", "hessian_state_state", "hessian_action_action", "hessian_action_state", "P", "p",
+                 "K", "nominal_states", "constraint_dual"):
+        assert not sol.buffer(name).any(), name                       # a fresh solver: all zero (src/data/*.jl)
+    assert (sol.stats()["objective"] == np.inf).all()
+    sol.reset_(); sol.initialize_rollout_(x1, ub)
+    sol.run_stage_("cost_nominal"); sol.run_stage_("gradients")        # the accumulating stage on a fresh solver must start from zero Hessians
+    h1 = sol.buffer("hessian_state_state").copy()
+    sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()        # and the solve after a reset reproduces the first one
+    assert np.array_equal(sol.get_trajectory()[0], first)
+    assert not sol.buffer("P").any()                                  # the fused solve does not store P: still the fresh zeros
+    sol.reset_(); sol.initialize_rollout_(x1, ub)
+    sol.run_stage_("cost_nominal"); sol.run_stage_("gradients")
+    assert np.array_equal(sol.buffer("hessian_state_state"), h1)
+    sol.close()
