@@ -45,3 +45,19 @@ def test_gpus_n_refuses_when_fewer_devices_are_visible():
 def test_world_size_mismatch_is_an_error():
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], ILQR_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr.decode()
+
+
+def test_driver_style_torchrun_launch():
+    """The driver's own launch line for N > 1: python -m torch.distributed.run ... bench.py --gpus N (stub solve, gloo)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e["ILQR_BENCH_STUB"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"],
+                       env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"]["group_world_size"] == 2 and "torchrun" in out["ranks"]["launcher"]
