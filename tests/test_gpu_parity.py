@@ -903,3 +903,22 @@ def test_lazy_reset_of_large_models_is_unobservable(pkg):
     sol.run_stage_("cost_nominal"); sol.run_stage_("gradients")
     assert np.array_equal(sol.buffer("hessian_state_state"), h1)
     sol.close()
+
+
+def test_packed_kernel_edge_shapes(pkg):
+    """Minimal horizons (one and two dynamics steps), horizons around the 16-step chunk of the fused linearise + Riccati
+    sweep, batches that leave one to three rows of a wave empty: packed against latency kernel."""
+    rng = np.random.default_rng(3)
+    for model, n, m in (("particle", 2, 1), ("car", 3, 2)):
+        for T in (2, 3, 16, 17, 18, 33, 34):
+            for B in (1, 3, 5):
+                x1 = 0.1 * rng.standard_normal((B, n)); ub = 0.05 * rng.standard_normal((B, T - 1, m))
+                res = []
+                for v in ("latency", "packed"):
+                    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+                    sol.set_kernel_variant_(v); sol.initialize_rollout_(x1, ub); sol.solve_()
+                    res.append((sol.get_trajectory()[0], sol.get_policy()[0], sol.stats())); sol.close()
+                a, b = res
+                assert (a[2]["iterations"] == b[2]["iterations"]).all() and (a[2]["rollouts"] == b[2]["rollouts"]).all(), (model, T, B)
+                assert np.isfinite(b[0]).all() and np.abs(a[0] - b[0]).max() < 1e-9, (model, T, B)
+                assert np.abs(a[1] - b[1]).max() <= 1e-8 * max(1.0, np.abs(a[1]).max()), (model, T, B)
