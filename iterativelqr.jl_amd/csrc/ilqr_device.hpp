@@ -720,11 +720,13 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         }
         if constexpr (MAT) {
             uxt = mfma444(Quu, K, 0.0);                                 // ux_tmp = Quu K   (:79)   (Quu^T K; Quu is symmetric up to rounding)
-            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84)
-            double Pn = mfma444(K, uxt, 0.0);
-            Pn = mfma444(K, Qux, Pn);
+            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84). The four terms are summed as ((Qxx + K^T Qux) + Qux^T K) + K^T ux_tmp:
+            // the first two products need only K, so they issue while ux_tmp = Quu K is still in the matrix pipe, and the chain
+            // behind ux_tmp is ONE dependent MFMA instead of three plus an addition (fewer hazard wait states on wave 0's stream).
+            // Same terms, other association than the reference's mul!(P, ..., 1.0, 1.0) sequence: rounding-level.
+            double Pn = mfma444(K, Qux, Qxx);
             Pn = mfma444(Qux, K, Pn);
-            Pn += Qxx;
+            Pn = mfma444(K, uxt, Pn);
             if (b0) {
 #if ILQR_BW_PTR_STORES
                 *qK = K; qK -= sK;
@@ -745,10 +747,10 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         }
         if constexpr (VEC) {
             // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89)
-            double pn = mfma444(uxt, k, 0.0);
-            pn = mfma444(K, Qu, pn);
+            // (same association as P: Qx seeds the accumulator, the ux_tmp term goes last)
+            double pn = mfma444(K, Qu, Qx);
             pn = mfma444(Qux, k, pn);
-            pn += Qx;
+            pn = mfma444(uxt, k, pn);
             // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81). The padding of Lx and
             // Qu is exactly zero, so the running ∞-norm needs no lane predicate (block 0 is picked at the end).
             const double Lx = Qx - pn;

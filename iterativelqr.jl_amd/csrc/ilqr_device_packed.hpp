@@ -407,14 +407,14 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
             k = (r < m && c == 0) ? Yk : 0.0;
         }
         const double uxt = mfma444(Quu, K, 0.0);                        // (:79)
-        double Pn = mfma444(K, uxt, 0.0);                               // (:81-84)
-        Pn = mfma444(K, Qux, Pn);
+        // (:81-84), (:86-89): summed as ((Qxx + K^T Qux) + Qux^T K) + K^T ux_tmp, the association of backward_pass_mfma
+        // (ilqr_device.hpp) — results must not depend on which kernel variant a batch size selects
+        double Pn = mfma444(K, Qux, Qxx);
         Pn = mfma444(Qux, K, Pn);
-        Pn += Qxx;
-        double pn = mfma444(uxt, k, 0.0);                               // (:86-89)
-        pn = mfma444(K, Qu, pn);
+        Pn = mfma444(K, uxt, Pn);
+        double pn = mfma444(K, Qu, Qx);
         pn = mfma444(Qux, k, pn);
-        pn += Qx;
+        pn = mfma444(uxt, k, pn);
         const double Lx = Qx - pn;                                      // src/solve.jl:73-81
         gmax = fmax(gmax, fabs(Lx));
         gmax = fmax(gmax, fabs(Qu));
