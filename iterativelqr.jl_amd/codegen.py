@@ -188,6 +188,52 @@ def _group_reciprocals(repl):
     return groups
 
 
+# Per-lane constants of the cooperative rollout code of the model being generated (small models): name -> one value per
+# cooperating slot. They become members of the model's WaveCtx, built once per kernel by wave_ctx(lane).
+_CTX = []
+
+
+def _ctx_coef(values, nslots=8):
+    vals = tuple(float(v) for v in values) + (0.0,) * (nslots - len(values))
+    for i, v in enumerate(_CTX):
+        if v == vals:
+            return i
+    _CTX.append(vals)
+    return len(_CTX) - 1
+
+
+def _affine_args(chunk_exprs, repl):
+    """Trig arguments of one cooperative batch as affine forms of values every lane already holds: returns
+    (symbols, rows) with rows[q] = ([coefficient per symbol], constant) or None if some argument is not affine.
+    Symbols are whatever the CSE'd expressions bottom out in (x*, u*, w*, earlier sn*/cs* results)."""
+    defs = dict(repl)
+
+    def expand(e):
+        while True:
+            fs = [f for f in e.free_symbols if f in defs]
+            if not fs:
+                return e
+            e = e.xreplace({f: defs[f] for f in fs})
+    full = [sp.expand(expand(e)) for e in chunk_exprs]
+    syms = sorted(set().union(*[f.free_symbols for f in full]), key=str)
+    rows = []
+    for f in full:
+        try:
+            poly = sp.Poly(f, *syms) if syms else None
+        except sp.PolynomialError:
+            return None
+        if poly is not None and poly.total_degree() > 1:
+            return None
+        coefs = [sp.sympify(f.coeff(sy, 1)) for sy in syms]
+        const = sp.sympify(f.xreplace({sy: 0 for sy in syms}))
+        if any(c.free_symbols for c in coefs) or const.free_symbols:
+            return None
+        if sp.simplify(f - (sum(c * sy for c, sy in zip(coefs, syms)) + const)) != 0:
+            return None
+        rows.append(([float(c) for c in coefs], float(const)))
+    return syms, rows
+
+
 def _select(var, sel, qi, expr):
     """var = (sel == qi) ? expr : var. For small models the (cheap) expression is evaluated on every lane first and made
     opaque, so that hipcc emits two v_cndmask instead of an exec-masked branch around one addition."""
@@ -235,7 +281,7 @@ def _emit_block(outputs, prefix, coop=False):
     for gi, g in enumerate(recip_groups):
         txt = ["double rb%d = %s;" % (gi, _P.doprint(g[0][1]))]
         for qi, (_, base) in enumerate(g[1:], start=1):
-            txt.append(_select("rb%d" % gi, "lane", qi, _P.doprint(base)))
+            txt.append(_select("rb%d" % gi, "l16" if COOP_GROUP == 16 else "lane", qi, _P.doprint(base)))
         # small models (serial rollout chain of the LDS / packed kernels): v_rcp + two Newton steps instead of the IEEE
         # division sequence (5 instead of 11 issue slots per group, <= 1 ulp)
         txt.append(("const double rr%d = ilqr::recip_fast(rb%d);" if COOP_GROUP == 16 else "const double rr%d = 1.0 / rb%d;") % (gi, gi))
@@ -248,7 +294,46 @@ def _emit_block(outputs, prefix, coop=False):
         for d, e in trig_red:
             rounds.setdefault(d[5], []).append((d, e))
         batch_id = 0
-        for r in sorted(rounds):
+        for r in sorted(rounds) if COOP_GROUP == 16 else []:
+            # small models: every angle of a dependency level on a PAIR of lanes of the 16-lane row (even lane: sine, odd lane:
+            # cosine; ilqr::sincos_pair), up to eight angles per batch; results handed to the whole row by DPP row broadcasts.
+            # Affine arguments (the usual case: integrator stages of angles) are formed as one FMA chain with per-lane constant
+            # coefficients from the WaveCtx instead of one select per angle.
+            items = rounds[r]
+            for chunk in [items[i:i + 8] for i in range(0, len(items), 8)]:
+                j = batch_id
+                batch_id += 1
+                aff = _affine_args([e for _, e in chunk], repl)
+                txt = []
+                if aff is not None:
+                    syms_, rows = aff
+                    consts = [row[1] for row in rows]
+                    acc = None
+                    if any(c != 0.0 for c in consts):
+                        acc = "cx.a[%d]" % _ctx_coef(consts)
+                    for si, sy in enumerate(syms_):
+                        col = [row[0][si] for row in rows]
+                        if all(c == 0.0 for c in col):
+                            continue
+                        k_ = "cx.a[%d]" % _ctx_coef(col)
+                        acc = ("%s * %s" % (k_, sy)) if acc is None else ("fma(%s, %s, %s)" % (k_, sy, acc))
+                    txt.append("const double ta%d = %s;" % (j, acc if acc is not None else "0.0"))
+                else:
+                    txt.append("double ta%d = %s;" % (j, _P.doprint(chunk[0][1])))
+                    for qi, (_, e) in enumerate(chunk[1:], start=1):
+                        txt.append(_select("ta%d" % j, "pq", qi, _P.doprint(e)))
+                txt.append("const double tr%d = ilqr::sincos_pair(ta%d, cx.tp);" % (j, j))
+                defined, dep = set(), sp.Tuple(*[e for _, e in chunk])
+                for qi, (d, _) in enumerate(chunk):
+                    _, s_sym, c_sym, need_s, need_c, _ = d
+                    if need_s:
+                        txt.append("const double %s = ilqr::wave_bcast<%d>(tr%d);" % (s_sym, 2 * qi, j))
+                    if need_c:
+                        txt.append("const double %s = ilqr::wave_bcast<%d>(tr%d);" % (c_sym, 2 * qi + 1, j))
+                    defined |= {s_sym, c_sym}
+                    d.append("done")
+                nodes.append((defined, dep, "\n".join(txt)))
+        for r in sorted(rounds) if COOP_GROUP != 16 else []:
             items = rounds[r]
             # up to 4 arguments: one per lane of every quad, results handed back by DPP quad broadcasts
             # (stay in VGPRs); 5..64 arguments: one per lane of the wave, results by v_readlane (SGPRs).
@@ -459,7 +544,8 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
             body.append("return ret_;")
         un = _prune_unpack(unpack_xu(obj, with_u), body)
         if coop:
-            un = ["const int ql = lane & 3; (void)ql;"] + un
+            un = [("const int l16 = lane & 15, pq = l16 >> 1; (void)l16; (void)pq;" if COOP_GROUP == 16
+                   else "const int ql = lane & 3; (void)ql;")] + un
         L.extend(_fn(ret, fname, sig, un + body))
 
     # dynamics
@@ -467,8 +553,27 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)])
     # wave-cooperative variant for the serial closed-loop rollout (all lanes hold the same x, u)
     L.append("#if defined(__HIPCC__)")
-    add("void", "dyn_wave", ["const int lane"] + sig_xu + [_arr("y", n, False)], dynamics,
+    del _CTX[:]
+    mark = len(L)
+    add("void", "dyn_wave", (["const WaveCtx& cx"] if COOP_GROUP == 16 else []) + ["const int lane"] + sig_xu + [_arr("y", n, False)], dynamics,
         [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)], coop=True)
+    if COOP_GROUP == 16:
+        # per-lane constants of the cooperative code, built ONCE per kernel (not per timestep): the trig pair coefficients and
+        # the coefficient columns of the affine trig arguments, indexed by the angle slot pq = (lane & 15) >> 1
+        ctx = ["    struct WaveCtx { ilqr::TrigPair tp; double a[%d]; };" % max(1, len(_CTX)),
+               "    __device__ __forceinline__ static WaveCtx wave_ctx(const int lane) {",
+               "        const int pq = (lane & 15) >> 1; (void)pq;",
+               "        WaveCtx cx;",
+               "        cx.tp = ilqr::make_trig_pair(lane);"]
+        if not _CTX:
+            ctx.append("        cx.a[0] = 0.0;")
+        for i, vals in enumerate(_CTX):
+            expr = repr(vals[-1])
+            for q in range(len(vals) - 2, -1, -1):
+                expr = "(pq == %d) ? %r : (%s)" % (q, vals[q], expr)
+            ctx.append("        cx.a[%d] = %s; ILQR_OPAQUE(cx.a[%d]);" % (i, expr, i))
+        ctx += ["        return cx;", "    }"]
+        L[mark:mark] = ctx
     L.append("#endif")
     outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
     outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
@@ -567,7 +672,7 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     src = src.replace("ilqr::wave_bcast<", "BC::template bcast<")
     for fn in ("dyn_wave", "dyn_rem_wave"):
         src = src.replace("__device__ __forceinline__ static void %s(" % fn,
-                          "template <class BC = ilqr::WaveBC> __device__ __forceinline__ static void %s(" % fn)
+                          "template <class BC = ilqr::%s> __device__ __forceinline__ static void %s(" % ("RowBC" if COOP_GROUP == 16 else "WaveBC", fn))
     return sname, src
 
 

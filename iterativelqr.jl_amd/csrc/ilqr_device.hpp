@@ -856,6 +856,7 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     // policy operands of step t are fetched from LDS one step ahead so that their latency
     // hides under the previous step's dynamics chain; the loop is unrolled by two with
     // ping-pong operand sets so that no register copies are needed
+    const typename M::WaveCtx wcx = M::wave_ctx(I.lane);            // per-lane constants of the cooperative dynamics, built once
     struct Ops { double K[m * n], k[m], ub[m], xb[n]; };
     auto fetch = [&](Ops& o, int t) {
 #pragma unroll
@@ -911,7 +912,7 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
         }
         double w[cdim<M::NW>::v];
         load_w<M::NW>(I.w, t, w);
-        M::dyn_wave(I.lane, xin, ut, w, xout);                        // (:29)
+        M::dyn_wave(wcx, I.lane, xin, ut, w, xout);                   // (:29)
         if (I.lane == 0) {
 #pragma unroll
             for (int i = 0; i < m; ++i) I.u[t * m + i] = ut[i];

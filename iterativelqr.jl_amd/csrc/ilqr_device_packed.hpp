@@ -475,6 +475,7 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) g[L.x + i] = xt[i];
     }
+    const typename M::WaveCtx wcx = M::wave_ctx(I.j);                  // per-lane constants of the cooperative dynamics (I.j: lane of the row)
     struct Ops { double K[m * n], k[m], ub[m], xb[n]; };
     auto fetch = [&](Ops& o, int t) {
 #pragma unroll
@@ -503,7 +504,7 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
         }
         double w[cdim<M::NW>::v];
         load_w<M::NW>(g + L.w, t, w);
-        M::template dyn_wave<Row16BC>(I.j, xin, ut, w, xout);           // (:29)
+        M::template dyn_wave<Row16BC>(wcx, I.j, xin, ut, w, xout);      // (:29)
 #pragma unroll
         for (int i = 0; i < m; ++i) pu[t * su + (wr ? i : 0)] = ut[i];
 #pragma unroll

@@ -110,6 +110,61 @@ ILQR_HD void sincos_fast(double x, double& s, double& c) {
     c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// ---- sine and cosine of one angle on a PAIR of lanes (even lane: sine, odd lane: cosine).
+// The critical wave of the solve kernels is bound by its instruction COUNT (one wave issues one instruction per ~5-6 clk
+// whatever its class, tools/probes/probe_issue.hip), and sincos_fast spends 16 fp64 instructions on two Horner chains that a
+// pair of lanes can run as ONE: per-lane constant coefficients (c[0..6]: {0, S6..S1} on sine lanes, {C6..C1, -1/2} on cosine
+// lanes; g = r on sine lanes, 1 on cosine lanes), own = g + (g z) q(z) — operation for operation the value sincos_reduced
+// produces, so the results are bitwise those of sincos_fast (tests/test_device_math.py) — then the quadrant fix-up takes
+// the partner lane's kernel value where sincos_fast swaps, and flips the sign bit.
+struct TrigPair {
+    double c[7], m, o;      // Horner coefficients, g = fma(r, m, o)
+    int odd;                // 1 on cosine lanes
+};
+ILQR_HD TrigPair trig_pair_constants(bool odd) {
+    TrigPair t;
+    t.c[0] = odd ? -1.13596475577881948265e-11 : 0.0;
+    t.c[1] = odd ? 2.08757232129817482790e-09 : 1.58969099521155010221e-10;
+    t.c[2] = odd ? -2.75573143513906633035e-07 : -2.50507602534068634195e-08;
+    t.c[3] = odd ? 2.48015872894767294178e-05 : 2.75573137070700676789e-06;
+    t.c[4] = odd ? -1.38888888888741095749e-03 : -1.98412698298579493134e-04;
+    t.c[5] = odd ? 4.16666666666666019037e-02 : 8.33333333332248946124e-03;
+    t.c[6] = odd ? -0.5 : -1.66666666666666324348e-01;
+    t.m = odd ? 0.0 : 1.0;
+    t.o = odd ? 1.0 : 0.0;
+    t.odd = odd ? 1 : 0;
+    return t;
+}
+// kernel value of this lane (sine kernel on even, cosine kernel on odd lanes) and the quadrant of the argument
+ILQR_HD double trig_pair_own(double x, const TrigPair& t, int& quadrant) {
+    if (!(fabs(x) < 1073741824.0)) {
+#pragma clang loop unroll(disable)
+        for (int it = 0; it < 24 && !(fabs(x) < 1073741824.0) && x == x; ++it) {
+            const double k = rint(x * 1.5915494309189535e-01);
+            x = fma(-k, 6.283185307179586, x);
+        }
+    }
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-fn, 1.5707963267948966e+00, x);
+    r = fma(-fn, 6.123233995736766e-17, r);
+    r = fma(-fn, -1.4973849048591698e-33, r);
+    const double z = r * r;
+    double q = fma3(z, t.c[0], t.c[1]);
+    q = fma3(z, q, t.c[2]);
+    q = fma3(z, q, t.c[3]);
+    q = fma3(z, q, t.c[4]);
+    q = fma3(z, q, t.c[5]);
+    q = fma3(z, q, t.c[6]);
+    const double g = fma(r, t.m, t.o);
+    quadrant = (int)fn;
+    return fma(g * z, q, g);
+}
+// own / partner: kernel values of this lane and of the other lane of the pair
+ILQR_HD double trig_pair_fix(double own, double partner, int quadrant, const TrigPair& t) {
+    const double v = (quadrant & 1) ? partner : own;
+    return ((quadrant + t.odd) & 2) ? -v : v;
+}
+
 ILQR_HD double sin_fast(double x) { double s, c; sincos_fast(x, s, c); return s; }
 ILQR_HD double cos_fast(double x) { double s, c; sincos_fast(x, s, c); return c; }
 
@@ -130,19 +185,44 @@ __device__ __forceinline__ double wave_bcast(double v) {
     hi = __builtin_amdgcn_readlane(hi, I);
     return __hiloint2double(hi, lo);
 }
+// value of the other lane of an (even, odd) lane pair: DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ double pair_swap(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ TrigPair make_trig_pair(int lane) {
+    TrigPair t = trig_pair_constants(lane & 1);
+    // pinned in registers: the time loops must not rebuild per-lane constants with selects every step
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ILQR_OPAQUE(t.c[i]);
+    ILQR_OPAQUE(t.m); ILQR_OPAQUE(t.o);
+    return t;
+}
+// sin(x) on even lanes, cos(x) on odd lanes; both lanes of a pair must hold the same x
+__device__ __forceinline__ double sincos_pair(double x, const TrigPair& t) {
+    int quadrant;
+    const double own = trig_pair_own(x, t, quadrant);
+    return trig_pair_fix(own, pair_swap(own), quadrant, t);
+}
+// lane I of every 16-lane row to all lanes of the row: ONE v_mov_b64_dpp row_newbcast (gfx90a+ DPP on 64-bit operands)
+template <int I>
+__device__ __forceinline__ double row_bcast(double v) {
+    static_assert(I >= 0 && I < 16, "row_newbcast takes a lane of the 16-lane row");
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + I, 0xF, 0xF, true);
+}
 // How the wave-cooperative model code (M::dyn_wave) hands a value from lane I of the cooperating group to every lane of it.
 struct WaveBC {      // group = the whole wave (one instance per wave); result is wave-uniform (SGPRs)
     template <int I> static __device__ __forceinline__ double bcast(double v) { return wave_bcast<I>(v); }
 };
-struct Row16BC {     // group = a row of 16 lanes (four instances per wave): ds_swizzle bit mode, lane' = (lane & 0x10) | I
-    template <int I> static __device__ __forceinline__ double bcast(double v) {
-        static_assert(I < 16, "a 16-lane row cooperates on at most 16 values");
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __builtin_amdgcn_ds_swizzle(lo, 0x10 | (I << 5));
-        hi = __builtin_amdgcn_ds_swizzle(hi, 0x10 | (I << 5));
-        return __hiloint2double(hi, lo);
-    }
+// group = a row of 16 lanes. Small models cooperate within rows in EVERY kernel: four instances per wave in the packed kernel,
+// four identical copies of the one instance in the latency / throughput kernels (so the result stays in VGPRs, one instruction
+// per value, instead of two v_readlane into SGPRs that the register allocator then spills).
+struct RowBC {
+    template <int I> static __device__ __forceinline__ double bcast(double v) { return row_bcast<I>(v); }
 };
+using Row16BC = RowBC;
 #endif
 
 }  // namespace ilqr

@@ -39,8 +39,10 @@ struct AdaptedModel {
         zero(y);
         F::dynamics(y, x, u, w);
     }
-    template <class BC = WaveBC>
-    __device__ __forceinline__ static void dyn_wave(const int, const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&y)[NX]) {
+    struct WaveCtx {};
+    __device__ __forceinline__ static WaveCtx wave_ctx(const int) { return WaveCtx{}; }
+    template <class BC = RowBC>
+    __device__ __forceinline__ static void dyn_wave(const WaveCtx&, const int, const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&y)[NX]) {
         dyn(x, u, w, y);
     }
     __device__ __forceinline__ static void dyn_jac(const double (&x)[NX], const double (&u)[NU], const double (&w)[W],
