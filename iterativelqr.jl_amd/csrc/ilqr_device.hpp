@@ -840,31 +840,65 @@ template <class M>
 __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
     constexpr int n = M::NX, m = M::NU;
     constexpr bool MF = (n <= 4 && m <= 4) && waves_of<M>::value == 1;   // with two waves Δ is wave 1's job (delta_small)
+    // The rollout is ONE instruction stream per instance and a wave issues one instruction per ~5-6 clk whatever it is
+    // (tools/probes/probe_issue.hip): every instruction taken out of the step is time. So everything of (:24-28) that does not
+    // depend on the running state is formed beforehand, one timestep per lane: a_t = k_t α + ū_t and b_t = K_t x̄_t, parked in
+    // the trial buffers where step t will put u_t and x_{t+1} (a_t in u[t], b_t in the first nu entries of x[t+1]); the step then
+    // reads K_t, a_t, b_t through three walking LDS addresses with immediate offsets and forms u = (a_t + K_t x) − b_t — the
+    // operations of the reference's order, each rounded as before.
+    constexpr bool PRE = (m <= n);
+    typedef __attribute__((address_space(3))) double ldsd;
+    const int lane = I.lane;
+    if constexpr (PRE) {
+        for (int t = lane; t < I.N; t += 64) {
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+                const double a = fma(I.k[t * m + i], alpha, I.ub[t * m + i]);     // (:24-26)
+                double b = 0.0;
+#pragma unroll
+                for (int j = 0; j < n; ++j) b = fma(I.K[t * m * n + j * m + i], I.xb[t * n + j], b);
+                I.u[t * m + i] = a;
+                I.x[(t + 1) * n + i] = b;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // same wave reads them back: LDS operations of a wave complete in order
+        __builtin_amdgcn_wave_barrier();
+    }
     double xt[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) xt[i] = I.xb[i];                      // (:19)
-    if (I.lane == 0) {
 #pragma unroll
-        for (int i = 0; i < n; ++i) I.x[i] = xt[i];
-    }
+    for (int i = 0; i < n; ++i) I.x[i] = xt[i];                       // every lane the same value to the same address
     // sensitivity state (MFMA layout: element (r, c) on lane c + 4*blk + 16*r, vectors in column 0)
-    const int lane = I.lane, r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
+    const int r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
     const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n;
     const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m;
     double zx = 0.0, dacc = 0.0;
     (void)blk;
-    // policy operands of step t are fetched from LDS one step ahead so that their latency
-    // hides under the previous step's dynamics chain; the loop is unrolled by two with
-    // ping-pong operand sets so that no register copies are needed
-    const typename M::WaveCtx wcx = M::wave_ctx(I.lane);            // per-lane constants of the cooperative dynamics, built once
-    struct Ops { double K[m * n], k[m], ub[m], xb[n]; };
-    auto fetch = [&](Ops& o, int t) {
+    const typename M::WaveCtx wcx = M::wave_ctx(lane);               // per-lane constants of the cooperative dynamics, built once
+    // LDS byte addresses of K_t, u[t], x[t] held in VGPRs (opaque to the compiler, which would otherwise rebuild every address
+    // from scalar registers with shift / add / move triples); they advance by two steps per loop trip, all other offsets are
+    // immediates. Operands of step t are fetched one step ahead; the loop is unrolled by two with ping-pong operand sets.
+    unsigned aK = (unsigned)(size_t)(ldsd*)I.K, aU = (unsigned)(size_t)(ldsd*)I.u, aX = (unsigned)(size_t)(ldsd*)I.x;
+    unsigned aKb = (unsigned)(size_t)(ldsd*)I.k, aUb = (unsigned)(size_t)(ldsd*)I.ub, aXb = (unsigned)(size_t)(ldsd*)I.xb;
+    asm volatile("" : "+v"(aK), "+v"(aU), "+v"(aX));
+    if constexpr (!PRE) asm volatile("" : "+v"(aKb), "+v"(aUb), "+v"(aXb));
+    auto L = [](unsigned a, int off) -> double { return *(const ldsd*)(size_t)(a + 8u * off); };
+    auto S = [](unsigned a, int off, double v) { *(ldsd*)(size_t)(a + 8u * off) = v; };
+    struct Ops { double K[m * n], a[m], b[m], xb[PRE ? 1 : n]; };
+    // d: step offset (0, 1, 2) from the step the walking addresses stand at
+    auto fetch = [&](Ops& o, int d) {
 #pragma unroll
-        for (int i = 0; i < m * n; ++i) o.K[i] = I.K[t * m * n + i];
+        for (int i = 0; i < m * n; ++i) o.K[i] = L(aK, d * m * n + i);
+        if constexpr (PRE) {
 #pragma unroll
-        for (int i = 0; i < m; ++i) { o.k[i] = I.k[t * m + i]; o.ub[i] = I.ub[t * m + i]; }
+            for (int i = 0; i < m; ++i) { o.a[i] = L(aU, d * m + i); o.b[i] = L(aX, (d + 1) * n + i); }
+        } else {
 #pragma unroll
-        for (int i = 0; i < n; ++i) o.xb[i] = I.xb[t * n + i];
+            for (int i = 0; i < m; ++i) { o.a[i] = L(aKb, d * m + i); o.b[i] = L(aUb, d * m + i); }    // k_t, ū_t
+#pragma unroll
+            for (int i = 0; i < n; ++i) o.xb[i] = L(aXb, d * n + i);
+        }
     };
     // Sensitivity operands, transposed straight from LDS (mfma(A<-X^T, B<-v, C) = X v + C), through
     // per-lane pointers that walk forward in time; padding lanes aim at the zero slot with stride 0.
@@ -875,7 +909,7 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     const double* pkc = (MF && vm1) ? I.k + r : I.zs;             const int skc = (MF && vm1) ? m : 0;
     const double* pLx = (MF && vn1) ? I.Lx + r : I.zs;            const int sLx = (MF && vn1) ? n : 0;
     const double* pLu = (MF && vm1) ? I.Lu + r : I.zs;
-    auto step = [&](const Ops& o, int t, const double (&xin)[n], double (&xout)[n]) {
+    auto step = [&](const Ops& o, int t, int d, const double (&xin)[n], double (&xout)[n]) {
         ILQR_ISA_MARK("rollout_step", MF ? 1 : 0);
         // sensitivity recursion: operand loads first (their latency hides under the policy evaluation)
         double KT = 0.0, fxT = 0.0, fuT = 0.0, kc = 0.0, Lxc = 0.0, Luc = 0.0;
@@ -888,17 +922,17 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
         double ut[m];
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-            double v = o.k[i] * alpha;                                // (:24-25)
-            v += o.ub[i];                                             // (:26)
-            double a1 = 0.0, a2 = 0.0;
+            double a1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < n; ++j) {
-                a1 += o.K[j * m + i] * xin[j];
-                a2 += o.K[j * m + i] * o.xb[j];
+            for (int j = 0; j < n; ++j) a1 = fma(o.K[j * m + i], xin[j], a1);
+            if constexpr (PRE) {
+                ut[i] = (o.a[i] + a1) - o.b[i];                          // (:27), (:28)
+            } else {
+                double a2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < n; ++j) a2 = fma(o.K[j * m + i], o.xb[j], a2);
+                ut[i] = (fma(o.a[i], alpha, o.b[i]) + a1) - a2;          // (:24-28)
             }
-            v += a1;                                                  // (:27)
-            v += -1.0 * a2;                                           // (:28)
-            ut[i] = v;
         }
         // first half of the recursion goes to the matrix pipe before the long VALU dynamics chain,
         // the dependent second half is issued after it: Δ costs issue slots only
@@ -912,13 +946,12 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
         }
         double w[cdim<M::NW>::v];
         load_w<M::NW>(I.w, t, w);
-        M::dyn_wave(wcx, I.lane, xin, ut, w, xout);                   // (:29)
-        if (I.lane == 0) {
+        M::dyn_wave(wcx, lane, xin, ut, w, xout);                     // (:29)
+        // the trial trajectory: every lane stores the same values to the same addresses (no exec mask to set up and restore)
 #pragma unroll
-            for (int i = 0; i < m; ++i) I.u[t * m + i] = ut[i];
+        for (int i = 0; i < m; ++i) S(aU, d * m + i, ut[i]);
 #pragma unroll
-            for (int i = 0; i < n; ++i) I.x[(t + 1) * n + i] = xout[i];
-        }
+        for (int i = 0; i < n; ++i) S(aX, (d + 1) * n + i, xout[i]);
         if constexpr (MF) {
             if (with_delta) {
                 dacc = mfma444(Luc, zu, dacc);                         // += ∇L_u · Δu
@@ -926,18 +959,23 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
             }
         }
     };
+    auto advance2 = [&]() {
+        aK += 16u * m * n; aU += 16u * m; aX += 16u * n;
+        if constexpr (!PRE) { aKb += 16u * m; aUb += 16u * m; aXb += 16u * n; }
+    };
     Ops A, B;
     double xo[n];
     if (I.N > 0) fetch(A, 0);
     int t = 0;
     for (; t + 1 < I.N; t += 2) {
-        fetch(B, t + 1);
-        step(A, t, xt, xo);
-        if (t + 2 < I.N) fetch(A, t + 2);
-        step(B, t + 1, xo, xt);
+        fetch(B, 1);
+        step(A, t, 0, xt, xo);
+        if (t + 2 < I.N) fetch(A, 2);
+        step(B, t + 1, 1, xo, xt);
+        advance2();
     }
     if (t < I.N) {
-        step(A, t, xt, xo);
+        step(A, t, 0, xt, xo);
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = xo[i];
     }
