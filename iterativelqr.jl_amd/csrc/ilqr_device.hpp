@@ -559,6 +559,16 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// A step of the recursion ends with the MFMA that produces P (or p) and the next one starts with MFMAs that read it as an A / B
+// operand. Inside one basic block hipcc inserts the wait states a dependent f64 MFMA needs; on a path that ENTERS the next step
+// through a taken branch (the skipped operand prefetch of the last pair, the odd tail) it did not (ROCm 7.2, observed: the first
+// MFMA of step t = 0 read a stale P whenever nothing but the branch lay between). Those rare paths carry their own wait states.
+__device__ __forceinline__ void mfma_block_boundary_guard() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7\n\ts_nop 7");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 #ifndef ILQR_BW_PTR_LOADS
 #define ILQR_BW_PTR_LOADS 1
 #endif
@@ -782,9 +792,10 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             fetch_prev(B, t - 1);
             riccati_step(A, t, 0);
             if (t >= 2) fetch_prev(A, t - 2);
+            else mfma_block_boundary_guard();
             riccati_step(B, t - 1, 0);
         }
-        if (t == 0) riccati_step(A, 0, 0);
+        if (t == 0) { mfma_block_boundary_guard(); riccati_step(A, 0, 0); }
     } else {
         // chunks of RING_STEPS timesteps; the vector chain works one chunk behind the matrix chain
         for (int chunk = 0; t >= 0; ++chunk) {                          // (:42)
@@ -795,13 +806,234 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
                 fetch_prev(B, t - 1);
                 riccati_step(A, t, base + i);
                 if (t >= 2) fetch_prev(A, t - 2);
+                else mfma_block_boundary_guard();
                 riccati_step(B, t - 1, base + i + 1);
             }
-            if (i < cnt) { riccati_step(A, t, base + i); t -= 1; }      // odd tail: only ever the very last step
+            if (i < cnt) { mfma_block_boundary_guard(); riccati_step(A, t, base + i); t -= 1; }      // odd tail: only ever the very last step
             if constexpr (ROLE == 1) __syncthreads();                   // hand the chunk over (the other half-ring is free again)
         }
     }
     if constexpr (VEC) I.gradient_norm = wave_max((b0 && c == 0) ? (gnan ? __builtin_nan("") : gmax) : 0.0);
+}
+
+// ---- the two-wave form of the recursion (latency kernel), written for INSTRUCTION COUNT: a wave issues one instruction per
+// ~5-6 clk whatever its class (tools/probes/probe_issue.hip), so the step is as long as its instruction list.
+//   ROLE 1 (wave 0): matrix chain W, Wu, Qxx, Qux, Quu, potrf, K, ux_tmp, P.   ROLE 2 (wave 1): vector chain Qx, Qu, k, p, ∇L,
+//   one ring chunk behind. All four MFMA blocks of a wave hold the SAME operands (the lane's address depends on (r, c) only),
+//   so every result store is unconditional: the lanes of the four blocks write the same value to the same address, padding
+//   lanes write to a trash slot with stride 0 — no exec mask is set up or restored anywhere in the step.
+//   * LDS operands and results go through per-lane BYTE ADDRESSES held in VGPRs that walk backwards in time (one v_add each);
+//     the accumulated Hessians come from the instance's HBM block through 32-bit per-lane offsets from its (scalar) base.
+//   * Hand-over ring slot (48 doubles): tiles Qux and ux_tmp, then the SOLVE SCALARS wave 0 has already paid for — for nu = 1
+//     the pair (a, b) with k = -((Qu a) b): (1 / Quu, 1) normally, (1 / d, 1 / d) in LAPACK's arithmetic after a failed potrf;
+//     for nu >= 2 the factor's off-diagonal entries and inverted diagonal. Wave 1 reads them back as wave-uniform LDS loads
+//     instead of re-factorising Quu (which it did before, from a Quu tile): same operands, same arithmetic for k.
+template <class M, bool STORE_VALUE, int ROLE>
+__device__ void backward_pass_split(Inst<M>& I) {
+    constexpr int n = M::NX, m = M::NU;
+    constexpr bool MAT = ROLE == 1, VEC = ROLE == 2;
+    static_assert(ROLE == 1 || ROLE == 2, "two-wave recursion");
+    static_assert(n <= 4 && m <= 4 && !slim_of<M>::value, "LDS-resident small models");
+    static_assert(m * (m + 1) / 2 + 2 <= 16, "solve scalars fit their ring tile");
+    typedef __attribute__((address_space(3))) double ldsd;
+    const int lane = I.lane, r = lane >> 4, c = lane & 3;
+    const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n, vmm = r < m && c < m;
+    const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m, b0 = ((lane >> 2) & 3) == 0;
+    const int N = I.N;
+    auto lds = [](const double* q) -> unsigned { return (unsigned)(size_t)(const ldsd*)q; };
+    auto LD = [](unsigned a, int off) -> double { return *(const ldsd*)(size_t)(a + 8u * off); };
+    auto ST = [](unsigned a, int off, double v) { *(ldsd*)(size_t)(a + 8u * off) = v; };
+    const unsigned zero = lds(I.zs), trash = lds(I.zs + 1);
+    // operand addresses of step N-1 (stride 0 at the zero slot for padding lanes)
+    unsigned afx = vnn ? lds(I.fx + (N - 1) * n * n + c * n + r) : zero;   const unsigned sfx = vnn ? 8u * n * n : 0u;
+    unsigned afu = vnm ? lds(I.fu + (N - 1) * n * m + c * n + r) : zero;   const unsigned sfu = vnm ? 8u * n * m : 0u;
+    unsigned agx = vn1 ? lds(I.gx + (N - 1) * n + r) : zero;               const unsigned sgx = vn1 ? 8u * n : 0u;
+    unsigned agu = vm1 ? lds(I.gu + (N - 1) * m + r) : zero;               const unsigned sgu = vm1 ? 8u * m : 0u;
+    unsigned aK = vmn ? lds(I.K + (N - 1) * m * n + c * m + r) : (MAT ? trash : zero);   const unsigned sK = vmn ? 8u * m * n : 0u;
+    unsigned ak = vm1 ? lds(I.k + (N - 1) * m + r) : trash;                const unsigned sk = vm1 ? 8u * m : 0u;
+    unsigned aLu = vm1 ? lds(I.Lu + (N - 1) * m + r) : trash;
+    unsigned aLx = vn1 ? lds(I.Lx + (N - 1) * n + r) : trash;              const unsigned sLx = vn1 ? 8u * n : 0u;
+    // accumulated Hessians: byte offsets into the instance's HBM block
+    const char* gb = (const char*)I.gbase;
+    auto goff = [&](const double* q) -> unsigned { return (unsigned)((const char*)q - gb); };
+    unsigned oxx = vnn ? goff(I.gxx + (N - 1) * n * n + c * n + r) : goff(I.gzero);   const unsigned sxx = vnn ? 8u * n * n : 0u;
+    unsigned ouu = vmm ? goff(I.guu + (N - 1) * m * m + c * m + r) : goff(I.gzero);   const unsigned suu = vmm ? 8u * m * m : 0u;
+    unsigned oux = vmn ? goff(I.gux + (N - 1) * m * n + c * m + r) : goff(I.gzero);   const unsigned sux = vmn ? 8u * m * n : 0u;
+    const unsigned aring0 = lds(I.ring + r * 4 + c);        // tile element (r, c) of slot 0
+    const unsigned asc0 = lds(I.ring + 32);                 // solve scalars of slot 0 (wave-uniform address)
+
+    double P = (MAT && vnn) ? I.gxx[N * n * n + c * n + r] : 0.0;      // P[H] .= gxx[H]  (:39)
+    double p = (VEC && vn1) ? I.gx[N * n + r] : 0.0;                   // p[H] .= gx[H]   (:40)
+    if (STORE_VALUE && b0) {
+        if (MAT && vnn) I.P[N * n * n + c * n + r] = P;
+        if (VEC && vn1) I.p[N * n + r] = p;
+    }
+    double gmax = 0.0;
+    unsigned long long nanmask = 0;     // ‖·‖∞ must propagate NaN like Julia's norm; v_max_f64 drops NaNs, so they are tracked beside it
+    struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
+    auto fetch = [&](Opnd& o) {          // operands at the walking addresses, then one step back in time
+        if constexpr (MAT) {
+            o.gxx = *(const double*)(gb + oxx); o.guu = *(const double*)(gb + ouu); o.gux = *(const double*)(gb + oux);
+            oxx -= sxx; ouu -= suu; oux -= sux;
+        } else { o.gxx = 0.0; o.guu = 0.0; o.gux = 0.0; }
+        o.fx = LD(afx, 0); o.fu = LD(afu, 0);
+        afx -= sfx; afu -= sfu;
+        if constexpr (VEC) { o.gx = LD(agx, 0); o.gu = LD(agu, 0); agx -= sgx; agu -= sgu; }
+        else { o.gx = 0.0; o.gu = 0.0; }
+    };
+    // potrs('U') of a right-hand-side set held as Y(r, c), given the factor's off-diagonal entries and inverted diagonal   (:70-75)
+    auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m]) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) {                                   // U^T y = b
+#pragma unroll
+            for (int l = 0; l < i; ++l) {
+                const double yl = (m == 2) ? from_lane_minus16_odd_rows(Y) : __shfl(Y, lane - 16 * (i - l));
+                const double v = Y - Uc[i * m + l] * yl;
+                Y = (r == i) ? v : Y;
+            }
+            const double q = Y * Ur[i];
+            Y = (r == i) ? q : Y;
+        }
+#pragma unroll
+        for (int i = m - 1; i >= 0; --i) {                              // U x = y
+#pragma unroll
+            for (int l = i + 1; l < m; ++l) {
+                const double xl = (m == 2) ? from_lane_plus16_even_rows(Y) : __shfl(Y, lane + 16 * (l - i));
+                const double v = Y - Uc[l * m + i] * xl;
+                Y = (r == i) ? v : Y;
+            }
+            const double q = Y * Ur[i];
+            Y = (r == i) ? q : Y;
+        }
+        return Y * -1.0;                                                // K .*= -1, k .*= -1
+    };
+    auto riccati_step = [&](const Opnd& o, int t, unsigned aslot, unsigned asc) {
+        ILQR_ISA_MARK("riccati_step", ROLE);
+        if constexpr (MAT) {
+            // W = P'^T fx, Wu = P'^T fu; Qxx = W^T fx + gxx, Qux = Wu^T fx + gux, Quu = Wu^T fu + guu   (:52-64)
+            const double W = mfma444(P, o.fx, 0.0);
+            const double Wu = mfma444(P, o.fu, 0.0);
+            const double Qxx = mfma444(W, o.fx, o.gxx);
+            const double Qux = mfma444(Wu, o.fx, o.gux);
+            const double Quu = mfma444(Wu, o.fu, o.guu);
+            double K;
+            if constexpr (m == 1) {
+                // 1x1: LAPACK (OpenBLAS trsm) computes (b (1/sqrt q)) (1/sqrt q); here b (1/q) with the reciprocal from v_rcp_f64 + two
+                // Newton steps: within 1.5 ulp of either. A failed potrf (q <= 0 or NaN; info ignored by the reference, :69) leaves q
+                // on the diagonal and potrs divides by it twice: the literal arithmetic, on a branch of its own.
+                const double q = lane_bcast(Quu, 0);
+                double sa, sb = 1.0;
+                if (__builtin_expect(q > 0.0, 1)) sa = recip_fast(q);
+                else {
+                    double Uc[1] = {q}, Ur[1];
+                    const int info = potrf_U<1>(Uc, Ur);
+                    if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
+                    sa = Ur[0]; sb = Ur[0];
+                }
+                K = ((Qux * sa) * sb) * -1.0;
+                ST(asc, 0, sa); ST(asc, 1, sb);
+            } else {
+                double Uc[m * m], Ur[m];
+#pragma unroll
+                for (int j = 0; j < m; ++j)
+#pragma unroll
+                    for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
+                const int info = potrf_U<m>(Uc, Ur);                    // (:68-69) upper triangle only, info ignored
+                if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
+                K = solve(Qux, Uc, Ur);
+                int q_ = 0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) {
+#pragma unroll
+                    for (int i = 0; i < j; ++i) ST(asc, q_++, Uc[j * m + i]);
+                }
+#pragma unroll
+                for (int i = 0; i < m; ++i) ST(asc, q_++, Ur[i]);
+            }
+            const double uxt = mfma444(Quu, K, 0.0);                    // ux_tmp = Quu K   (:79)
+            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), summed as ((Qxx + K^T Qux) + Qux^T K) + K^T ux_tmp (see backward_pass_mfma)
+            double Pn = mfma444(K, Qux, Qxx);
+            Pn = mfma444(Qux, K, Pn);
+            Pn = mfma444(K, uxt, Pn);
+            ST(aK, 0, K); aK -= sK;
+            ST(aslot, 0, Qux); ST(aslot, 16, uxt);
+            if (STORE_VALUE && b0) {
+                if (vnn) I.P[t * n * n + c * n + r] = Pn;
+                if (I.Q != nullptr) {                                   // policy.action_value.* (src/data/policy.jl:58-64)
+                    if (vnn) I.Q[I.QL.Qxx + t * n * n + c * n + r] = Qxx;
+                    if (vmn) I.Q[I.QL.Qux + t * m * n + c * m + r] = Qux;
+                    if (vmm) I.Q[I.QL.Quu + t * m * m + c * m + r] = Quu;
+                }
+            }
+            P = Pn;
+        } else {
+            const double Qx = mfma444(o.fx, p, o.gx);                   // Qx = fx^T p' + gx, Qu = fu^T p' + gu   (:44-49)
+            const double Qu = mfma444(o.fu, p, o.gu);
+            const double Qux = LD(aslot, 0), uxt = LD(aslot, 16);
+            const double K = LD(aK, 0); aK -= sK;
+            double k;
+            if constexpr (m == 1) {
+                const double sa = LD(asc, 0), sb = LD(asc, 1);
+                k = ((Qu * sa) * sb) * -1.0;
+            } else {
+                double Uc[m * m], Ur[m];
+                int q_ = 0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) {
+#pragma unroll
+                    for (int i = 0; i < m; ++i) Uc[j * m + i] = 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < m; ++j) {
+#pragma unroll
+                    for (int i = 0; i < j; ++i) Uc[j * m + i] = LD(asc, q_++);
+                }
+#pragma unroll
+                for (int i = 0; i < m; ++i) Ur[i] = LD(asc, q_++);
+                k = solve(Qu, Uc, Ur);
+            }
+            // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89), same association as P
+            double pn = mfma444(K, Qu, Qx);
+            pn = mfma444(Qux, k, pn);
+            pn = mfma444(uxt, k, pn);
+            // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81); the padding of Lx and Qu is exactly zero
+            const double Lx = Qx - pn;
+            asm("v_max_f64 %0, %1, |%2|" : "=v"(gmax) : "v"(gmax), "v"(Lx));
+            asm("v_max_f64 %0, %1, |%2|" : "=v"(gmax) : "v"(gmax), "v"(Qu));
+            nanmask |= __builtin_amdgcn_ballot_w64((Lx != Lx) | (Qu != Qu));
+            ST(ak, 0, k); ST(aLu, 0, Qu); ST(aLx, 0, Lx);
+            ak -= sk; aLu -= sk; aLx -= sLx;
+            if (STORE_VALUE && b0) {
+                if (vn1) I.p[t * n + r] = pn;
+                if (I.Q != nullptr) {
+                    if (vn1) I.Q[I.QL.Qx + t * n + r] = Qx;
+                    if (vm1) I.Q[I.QL.Qu + t * m + r] = Qu;
+                }
+            }
+            p = pn;
+        }
+    };
+    // operands of step t are fetched one step ahead; chunks of RING_STEPS timesteps, the vector chain one chunk behind
+    Opnd A, B;
+    if (N > 0) fetch(A);
+    int t = N - 1;
+    for (int chunk = 0; t >= 0; ++chunk) {                              // (:42)
+        if constexpr (ROLE == 2) __syncthreads();                       // chunk `chunk` of the ring is complete
+        const int base = (chunk & 1) * RING_STEPS, cnt = t + 1 < RING_STEPS ? t + 1 : RING_STEPS;
+        unsigned aslot = aring0 + 8u * 48u * base, asc = asc0 + 8u * 48u * base;
+        int i = 0;
+        for (; i + 1 < cnt; i += 2, t -= 2) {
+            fetch(B);
+            riccati_step(A, t, aslot, asc);
+            if (t >= 2) fetch(A);
+            else mfma_block_boundary_guard();
+            riccati_step(B, t - 1, aslot + 8u * 48u, asc + 8u * 48u);
+            aslot += 16u * 48u; asc += 16u * 48u;
+        }
+        if (i < cnt) { mfma_block_boundary_guard(); riccati_step(A, t, aslot, asc); t -= 1; }        // odd tail: only ever the very last step
+        if constexpr (ROLE == 1) __syncthreads();                       // hand the chunk over (the other half-ring is free again)
+    }
+    if constexpr (VEC) I.gradient_norm = wave_max(nanmask != 0 ? __builtin_nan("") : gmax);
 }
 
 template <class M, bool STORE_VALUE>
@@ -815,10 +1047,10 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
         } else {
             // matrix chain on wave 0, vector chain on wave 1 (one ring chunk behind); scalars through LDS
             if (I.wave == 0) {
-                backward_pass_mfma<M, STORE_VALUE, 1>(I);
+                backward_pass_split<M, STORE_VALUE, 1>(I);
                 if (I.lane == 0) I.zs[3] = (double)I.potrf_info;
             } else {
-                backward_pass_mfma<M, STORE_VALUE, 2>(I);
+                backward_pass_split<M, STORE_VALUE, 2>(I);
                 if (I.lane == 0) I.zs[2] = I.gradient_norm;
             }
             __syncthreads();

@@ -444,9 +444,10 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
             fetch(B, t0 + sl - 1, sl - 1);
             riccati_step(A, t0 + sl);
             if (sl >= 2) fetch(A, t0 + sl - 2, sl - 2);
+            else mfma_block_boundary_guard();         // (see ilqr_device.hpp: a step entered through a taken branch)
             riccati_step(B, t0 + sl - 1);
         }
-        if (sl == 0) riccati_step(A, t0);
+        if (sl == 0) { mfma_block_boundary_guard(); riccati_step(A, t0); }
         __syncthreads();                      // the chunk buffer is free again
     }
     double gm = (on && c == 0) ? (gnan ? __builtin_nan("") : gmax) : 0.0;

@@ -922,3 +922,31 @@ def test_packed_kernel_edge_shapes(pkg):
                 assert (a[2]["iterations"] == b[2]["iterations"]).all() and (a[2]["rollouts"] == b[2]["rollouts"]).all(), (model, T, B)
                 assert np.isfinite(b[0]).all() and np.abs(a[0] - b[0]).max() < 1e-9, (model, T, B)
                 assert np.abs(a[1] - b[1]).max() <= 1e-8 * max(1.0, np.abs(a[1]).max()), (model, T, B)
+
+
+@pytest.mark.parametrize("model,variant", [("acrobot", "latency"), ("car", "latency"), ("car", "throughput"), ("acrobot", "packed"),
+                                           ("car", "packed"), ("particle", "latency")])
+def test_fused_backward_pass_equals_staged_for_even_and_odd_horizons(pkg, model, variant):
+    """The Riccati recursion of the FUSED solve kernel (its own template instantiation: no value-function stores) against the
+    stage kernels, for horizons whose last pair / odd tail / single step enter a step through every branch of the unrolled
+    loop. (An f64 MFMA that reads P one branch after the MFMA that wrote it got no wait states from hipcc: the first step of
+    even horizons was wrong for nu = 3 until the rare paths carried their own, ilqr_device.hpp mfma_block_boundary_guard.)"""
+    n, m = {"acrobot": (4, 1), "car": (3, 2), "particle": (2, 1)}[model]
+    B = 5
+    for T in (2, 3, 4, 5, 6, 7, 9, 10, 13, 14):
+        rng = np.random.default_rng(100 + T)
+        x1 = 0.1 * rng.standard_normal((B, n)); ub = 0.3 * rng.standard_normal((B, T - 1, m))
+        out = {}
+        for mode in ("fused", "staged"):
+            sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, max_iterations=0, max_dual_updates=1))
+            sol.set_kernel_variant_(variant)
+            sol.initialize_rollout_(x1, ub)
+            if mode == "fused":
+                sol.solve_()
+            else:
+                for st in ("al_begin", "cost_nominal", "gradients", "backward_pass"):
+                    sol.run_stage_(st)
+            out[mode] = [sol.buffer(nm) for nm in ("K", "k", "gradient_state_lagrangian", "gradient_action_lagrangian")] + [sol.stats()["gradient_norm"]]
+            sol.close()
+        for a, b in zip(out["fused"], out["staged"]):
+            assert np.array_equal(a, b), (model, variant, T, np.abs(a - b).max())
