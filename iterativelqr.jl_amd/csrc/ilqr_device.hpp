@@ -868,7 +868,8 @@ __device__ void backward_pass_split(Inst<M>& I) {
         if (MAT && vnn) I.P[N * n * n + c * n + r] = P;
         if (VEC && vn1) I.p[N * n + r] = p;
     }
-    double gmax = 0.0;
+    double gmax = 0.0, one = 1.0;
+    ILQR_OPAQUE(one);                   // stays in a register pair instead of being rebuilt where the rare path joins
     unsigned long long nanmask = 0;     // ‖·‖∞ must propagate NaN like Julia's norm; v_max_f64 drops NaNs, so they are tracked beside it
     struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
     auto fetch = [&](Opnd& o) {          // operands at the walking addresses, then one step back in time
@@ -922,15 +923,17 @@ __device__ void backward_pass_split(Inst<M>& I) {
                 // Newton steps: within 1.5 ulp of either. A failed potrf (q <= 0 or NaN; info ignored by the reference, :69) leaves q
                 // on the diagonal and potrs divides by it twice: the literal arithmetic, on a branch of its own.
                 const double q = lane_bcast(Quu, 0);
-                double sa, sb = 1.0;
-                if (__builtin_expect(q > 0.0, 1)) sa = recip_fast(q);
-                else {
+                double sa, sb = one;
+                if (__builtin_expect(q > 0.0, 1)) {
+                    sa = recip_fast(q);
+                    K = (Qux * sa) * -1.0;                              // (x 1.0 is exact: the vector chain's ((Qu a) b) agrees)
+                } else {
                     double Uc[1] = {q}, Ur[1];
                     const int info = potrf_U<1>(Uc, Ur);
                     if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
                     sa = Ur[0]; sb = Ur[0];
+                    K = ((Qux * sa) * sb) * -1.0;
                 }
-                K = ((Qux * sa) * sb) * -1.0;
                 ST(asc, 0, sa); ST(asc, 1, sb);
             } else {
                 double Uc[m * m], Ur[m];
@@ -1025,8 +1028,10 @@ __device__ void backward_pass_split(Inst<M>& I) {
         for (; i + 1 < cnt; i += 2, t -= 2) {
             fetch(B);
             riccati_step(A, t, aslot, asc);
-            if (t >= 2) fetch(A);
-            else mfma_block_boundary_guard();
+            // operands of step t - 2, unconditionally: for the last pair they are reads below the arrays (inside this instance's
+            // LDS set and HBM block: every array fetched here sits behind x̄, ū) whose values are never used — no branch, and no
+            // step entered through one (mfma_block_boundary_guard)
+            fetch(A);
             riccati_step(B, t - 1, aslot + 8u * 48u, asc + 8u * 48u);
             aslot += 16u * 48u; asc += 16u * 48u;
         }

@@ -134,12 +134,37 @@ def marked_loop(body, marker):
     return classify(lines, (0, len(lines) - 1)), k
 
 
+def functions(lines):
+    """[(name, first, last)] of every function in the assembly (LLVM prints 'name:   ; @name' at a function's entry)."""
+    starts = [(i, m.group(1)) for i, ln in enumerate(lines) for m in [re.match(r"^([.\w$]+):\s+; @", ln)] if m]
+    return [(nm, i, (starts[k + 1][0] if k + 1 < len(starts) else len(lines)) - 1) for k, (i, nm) in enumerate(starts)]
+
+
+def body_with_marker(lines, funcs, marker, config):
+    """The function of solve_kernel<Model_config>'s call tree that holds `marker`: the kernel itself, or a device function it
+    calls (forward_pass, backward_pass_split<.., false, ROLE> are real calls with their own register allocation)."""
+    model = "Model_%s" % config
+    best = None
+    for nm, a, b in funcs:
+        if ("%d%s" % (len(model), model)) not in nm or any(x in nm for x in ("Slim", "packed", "stage_kernel", "slim")):
+            continue
+        if "backward_pass_split" in nm and "Lb0E" not in nm:           # the fused solve's instantiation (STORE_VALUE = false)
+            continue
+        if any(marker in ln for ln in lines[a:b + 1]):
+            if best is None or nm == MANGLED[config]:
+                best = (nm, a, b)
+    if best is None:
+        raise RuntimeError("marker %r not found for %s" % (marker, config))
+    return lines[best[1]:best[2] + 1]
+
+
 def model_for(config, lines):
-    body = function_body(lines, MANGLED[config])
-    rol, krol = marked_loop(body, "ILQR_MARK rollout_step 0")          # wave 0's rollout (two-wave kernel: no MFMA ride-along)
-    ric, kric = marked_loop(body, "ILQR_MARK riccati_step 1")          # ROLE 1: matrix chain on wave 0
-    vec, kvec = marked_loop(body, "ILQR_MARK riccati_step 2")          # ROLE 2: vector chain on wave 1
-    dlt, kdlt = marked_loop(body, "ILQR_MARK delta_step 0")            # wave 1, beside the first rollout
+    funcs = functions(lines)
+    mk = lambda marker: marked_loop(body_with_marker(lines, funcs, marker, config), marker)
+    rol, krol = mk("ILQR_MARK rollout_step 0")          # wave 0's rollout (two-wave kernel: no MFMA ride-along)
+    ric, kric = mk("ILQR_MARK riccati_step 1")          # ROLE 1: matrix chain on wave 0
+    vec, kvec = mk("ILQR_MARK riccati_step 2")          # ROLE 2: vector chain on wave 1
+    dlt, kdlt = mk("ILQR_MARK delta_step 0")            # wave 1, beside the first rollout
     table = [dict(rol, kind="rollout (wave 0)", steps=krol), dict(ric, kind="riccati matrix chain (wave 0)", steps=kric),
              dict(vec, kind="riccati vector chain (wave 1)", steps=kvec), dict(dlt, kind="delta sweep (wave 1)", steps=kdlt)]
     slots = lambda c, k: (c["total"] + c["nop_states"]) / k
