@@ -152,6 +152,8 @@ struct Inst {
     double *Q;             // HBM: this instance's block of the optional Qx, Qu, Qxx, Quu, Qux buffers (null = not stored)
     QLayout QL;
     double delta;          // delta_grad_product of the last forward_pass! (src/forward_pass.jl:20)
+    double delta_next;     // the same product for the NEXT forward pass, when the backward pass produced it (adjoint form, two-wave kernel)
+    int delta_next_ok;
     const double* gzero;   // HBM: a 0.0
     int T, N, C, lane, wave;
     double objective, max_violation, step_size, gradient_norm;
@@ -870,6 +872,11 @@ __device__ void backward_pass_split(Inst<M>& I) {
     }
     double gmax = 0.0, one = 1.0;
     ILQR_OPAQUE(one);                   // stays in a register pair instead of being rebuilt where the rare path joins
+    // Δ = ∇Lᵀ·Δz (src/forward_pass.jl:16-20, src/data/methods.jl:42-54) as the ADJOINT of the sensitivity recursion, carried by the
+    // vector chain: w = ∇L_u + fuᵀν′, Δ += wᵀk, ν = ∇L_x + fxᵀν′ + Kᵀw — four MFMAs on operands this step holds anyway, instead of
+    // a forward sweep of 84 instructions per timestep on wave 1 beside the first rollout (which shared the SIMD's fp64 pipe with
+    // another instance's critical wave). Same number up to rounding; it only enters the Armijo test (c1 = 1e-4).
+    double nu = 0.0, dacc = 0.0;
     unsigned long long nanmask = 0;     // ‖·‖∞ must propagate NaN like Julia's norm; v_max_f64 drops NaNs, so they are tracked beside it
     struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
     auto fetch = [&](Opnd& o) {          // operands at the walking addresses, then one step back in time
@@ -1006,6 +1013,10 @@ __device__ void backward_pass_split(Inst<M>& I) {
             nanmask |= __builtin_amdgcn_ballot_w64((Lx != Lx) | (Qu != Qu));
             ST(ak, 0, k); ST(aLu, 0, Qu); ST(aLx, 0, Lx);
             ak -= sk; aLu -= sk; aLx -= sLx;
+            const double wv = mfma444(o.fu, nu, Qu);
+            dacc = mfma444(wv, k, dacc);
+            const double nun = mfma444(o.fx, nu, Lx);
+            nu = mfma444(K, wv, nun);
             if (STORE_VALUE && b0) {
                 if (vn1) I.p[t * n + r] = pn;
                 if (I.Q != nullptr) {
@@ -1038,7 +1049,10 @@ __device__ void backward_pass_split(Inst<M>& I) {
         if (i < cnt) { mfma_block_boundary_guard(); riccati_step(A, t, aslot, asc); t -= 1; }        // odd tail: only ever the very last step
         if constexpr (ROLE == 1) __syncthreads();                       // hand the chunk over (the other half-ring is free again)
     }
-    if constexpr (VEC) I.gradient_norm = wave_max(nanmask != 0 ? __builtin_nan("") : gmax);
+    if constexpr (VEC) {
+        I.gradient_norm = wave_max(nanmask != 0 ? __builtin_nan("") : gmax);
+        I.delta_next = lane_bcast(dacc, 0);                             // element (0, 0)
+    }
 }
 
 template <class M, bool STORE_VALUE>
@@ -1056,10 +1070,11 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
                 if (I.lane == 0) I.zs[3] = (double)I.potrf_info;
             } else {
                 backward_pass_split<M, STORE_VALUE, 2>(I);
-                if (I.lane == 0) I.zs[2] = I.gradient_norm;
+                if (I.lane == 0) { I.zs[2] = I.gradient_norm; I.zs[5] = I.delta_next; }
             }
             __syncthreads();
             I.gradient_norm = I.zs[2]; I.potrf_info = (int)I.zs[3];
+            I.delta_next = I.zs[5]; I.delta_next_ok = 1;
         }
     }
     ILQR_PROF_END(I, PROF_BACKWARD);
@@ -1282,12 +1297,12 @@ __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with
             if (I.wave == 0) {
                 double unused = 0.0;
                 rollout_small<M>(I, alpha, false, unused);
-            } else if (with_delta) {
+            } else if (with_delta && !I.delta_next_ok) {                // stage kernels: the backward pass was another launch
                 const double d = delta_small<M>(I);
                 if (I.lane == 0) I.zs[4] = d;
             }
             __syncthreads();
-            if (with_delta) delta_out = I.zs[4];
+            if (with_delta) delta_out = I.delta_next_ok ? I.delta_next : I.zs[4];
         }
         I.rollouts += 1;
         I.states_eq_nominal = 0;
@@ -1443,7 +1458,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;
     I.Q = a.qv ? a.qv + (size_t)b * (size_t)a.QL.stride : nullptr; I.QL = a.QL;
-    I.delta = I.scal[S_DELTA];
+    I.delta = I.scal[S_DELTA]; I.delta_next = 0.0; I.delta_next_ok = 0;
     if constexpr (is_large<M>::value) {
         // large path: every buffer stays in the HBM workspace, LDS is staging only
         I.xb = g + L.xb; I.ub = g + L.ub; I.x = g + L.x; I.u = g + L.u;
