@@ -94,9 +94,22 @@ class Constraint(_Traced):
 
 
 # --------------------------------------------------------------------------- printing
+# While the cooperative rollout code of a small model is being printed, its floating-point literals are collected here and
+# printed as members of the WaveCtx (cx.k[i], pinned in VGPRs by wave_ctx): hipcc otherwise keeps two dozen fp64 constants in
+# scalar register PAIRS, runs out of them, and rebuilds pairs from halves with s_mov every timestep (8 of 150 issue slots
+# of the acrobot step). Constants the ISA encodes inline stay literals.
+_CONST_CTX = None
+_INLINE_FP = {0.0, 0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 4.0, -4.0}
+
+
 class _Printer(C99CodePrinter):
     def _print_Float(self, expr):
-        return repr(float(expr))
+        v = float(expr)
+        if _CONST_CTX is not None and v not in _INLINE_FP:
+            if v not in _CONST_CTX:
+                _CONST_CTX.append(v)
+            return "cx.k[%d]" % _CONST_CTX.index(v)
+        return repr(v)
 
     def _print_Integer(self, expr):
         return "%d.0" % int(expr)
@@ -555,16 +568,20 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     L.append("#if defined(__HIPCC__)")
     del _CTX[:]
     mark = len(L)
+    global _CONST_CTX
+    _CONST_CTX = [] if COOP_GROUP == 16 else None
     add("void", "dyn_wave", (["const WaveCtx& cx"] if COOP_GROUP == 16 else []) + ["const int lane"] + sig_xu + [_arr("y", n, False)], dynamics,
         [("y[%d]" % i, e) for i, e in enumerate(dynamics.evaluate)], coop=True)
+    consts, _CONST_CTX = _CONST_CTX, None
     if COOP_GROUP == 16:
         # per-lane constants of the cooperative code, built ONCE per kernel (not per timestep): the trig pair coefficients and
         # the coefficient columns of the affine trig arguments, indexed by the angle slot pq = (lane & 15) >> 1
-        ctx = ["    struct WaveCtx { ilqr::TrigPair tp; double a[%d]; };" % max(1, len(_CTX)),
-               "    __device__ __forceinline__ static WaveCtx wave_ctx(const int lane) {",
+        ctx = ["    struct WaveCtx { ilqr::TrigPair tp; double a[%d], k[%d]; };" % (max(1, len(_CTX)), max(1, len(consts))),
+               "    // PIN_CONSTANTS = false (packed kernel, short of VGPRs): the model constants stay compile-time constants",
+               "    template <bool PIN_CONSTANTS = true> __device__ __forceinline__ static WaveCtx wave_ctx(const int lane) {",
                "        const int pq = (lane & 15) >> 1; (void)pq;",
                "        WaveCtx cx;",
-               "        cx.tp = ilqr::make_trig_pair(lane);"]
+               "        cx.tp = ilqr::make_trig_pair<PIN_CONSTANTS>(lane);"]
         if not _CTX:
             ctx.append("        cx.a[0] = 0.0;")
         for i, vals in enumerate(_CTX):
@@ -572,6 +589,10 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
             for q in range(len(vals) - 2, -1, -1):
                 expr = "(pq == %d) ? %r : (%s)" % (q, vals[q], expr)
             ctx.append("        cx.a[%d] = %s; ILQR_OPAQUE(cx.a[%d]);" % (i, expr, i))
+        if not consts:
+            ctx.append("        cx.k[0] = 0.0;")
+        for i, v in enumerate(consts):
+            ctx.append("        cx.k[%d] = %r; if (PIN_CONSTANTS) ILQR_OPAQUE(cx.k[%d]);" % (i, v, i))
         ctx += ["        return cx;", "    }"]
         L[mark:mark] = ctx
     L.append("#endif")

@@ -476,7 +476,7 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) g[L.x + i] = xt[i];
     }
-    const typename M::WaveCtx wcx = M::wave_ctx(I.j);                  // per-lane constants of the cooperative dynamics (I.j: lane of the row)
+    const typename M::WaveCtx wcx = M::template wave_ctx<false>(I.j);                  // per-lane constants of the cooperative dynamics (I.j: lane of the row)
     struct Ops { double K[m * n], k[m], ub[m], xb[n]; };
     auto fetch = [&](Ops& o, int t) {
 #pragma unroll

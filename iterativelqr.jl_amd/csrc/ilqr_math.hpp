@@ -119,6 +119,7 @@ ILQR_HD void sincos_fast(double x, double& s, double& c) {
 // the partner lane's kernel value where sincos_fast swaps, and flips the sign bit.
 struct TrigPair {
     double c[7], m, o;      // Horner coefficients, g = fma(r, m, o)
+    double red[4];          // 2/pi and the three parts of pi/2 of the argument reduction (wave-uniform, but kept in VGPRs like the rest)
     int odd;                // 1 on cosine lanes
 };
 ILQR_HD TrigPair trig_pair_constants(bool odd) {
@@ -132,6 +133,8 @@ ILQR_HD TrigPair trig_pair_constants(bool odd) {
     t.c[6] = odd ? -0.5 : -1.66666666666666324348e-01;
     t.m = odd ? 0.0 : 1.0;
     t.o = odd ? 1.0 : 0.0;
+    t.red[0] = 6.36619772367581382433e-01; t.red[1] = 1.5707963267948966e+00;
+    t.red[2] = 6.123233995736766e-17; t.red[3] = -1.4973849048591698e-33;
     t.odd = odd ? 1 : 0;
     return t;
 }
@@ -144,10 +147,10 @@ ILQR_HD double trig_pair_own(double x, const TrigPair& t, int& quadrant) {
             x = fma(-k, 6.283185307179586, x);
         }
     }
-    const double fn = rint(x * 6.36619772367581382433e-01);
-    double r = fma(-fn, 1.5707963267948966e+00, x);
-    r = fma(-fn, 6.123233995736766e-17, r);
-    r = fma(-fn, -1.4973849048591698e-33, r);
+    const double fn = rint(x * t.red[0]);
+    double r = fma(-fn, t.red[1], x);
+    r = fma(-fn, t.red[2], r);
+    r = fma(-fn, t.red[3], r);
     const double z = r * r;
     double q = fma3(z, t.c[0], t.c[1]);
     q = fma3(z, q, t.c[2]);
@@ -162,7 +165,13 @@ ILQR_HD double trig_pair_own(double x, const TrigPair& t, int& quadrant) {
 // own / partner: kernel values of this lane and of the other lane of the pair
 ILQR_HD double trig_pair_fix(double own, double partner, int quadrant, const TrigPair& t) {
     const double v = (quadrant & 1) ? partner : own;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // sign flip as three integer instructions on the high word (shift-add, and, xor) instead of negate / compare / select
+    const unsigned flip = (((unsigned)quadrant << 30) + ((unsigned)t.odd << 30)) & 0x80000000u;
+    return __hiloint2double(__double2hiint(v) ^ (int)flip, __double2loint(v));
+#else
     return ((quadrant + t.odd) & 2) ? -v : v;
+#endif
 }
 
 ILQR_HD double sin_fast(double x) { double s, c; sincos_fast(x, s, c); return s; }
@@ -192,12 +201,17 @@ __device__ __forceinline__ double pair_swap(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+template <bool PIN_UNIFORM = true>
 __device__ __forceinline__ TrigPair make_trig_pair(int lane) {
     TrigPair t = trig_pair_constants(lane & 1);
     // pinned in registers: the time loops must not rebuild per-lane constants with selects every step
 #pragma unroll
     for (int i = 0; i < 7; ++i) ILQR_OPAQUE(t.c[i]);
     ILQR_OPAQUE(t.m); ILQR_OPAQUE(t.o);
+    if constexpr (PIN_UNIFORM) {        // wave-uniform constants: pinned too where VGPRs are plentiful (scalar-register pairs are not)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ILQR_OPAQUE(t.red[i]);
+    }
     return t;
 }
 // sin(x) on even lanes, cos(x) on odd lanes; both lanes of a pair must hold the same x
