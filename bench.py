@@ -343,7 +343,9 @@ def worker(args):
                     + im["per_iteration_other_clk"]
                 slots_iter = (T - 1) * (im["rollout_step_instr"] * rollouts_per_iter + im["riccati_step_instr"])
                 floor_ms = it_max * per_iter_clk / (im["clock_ghz"] * 1e6)
-                roof["actual_bound"] = "fp64 instruction issue + dependent latency of the serial chain of the SLOWEST instance"
+                roof["actual_bound"] = ("instruction issue of ONE wave: the slowest instance's critical wave issues one instruction per 5-6 clk "
+                                        "whatever its class (tools/probes/probe_issue.hip), so its serial loops last as long as their "
+                                        "instruction lists; predicted_floor_ms prices this build's lists at those rates")
                 roof["issue_model"] = dict(im, iterations_max=it_max, rollouts_per_iteration=rollouts_per_iter,
                                            issue_slots_per_iteration=slots_iter,
                                            measured_clk_per_issue_slot=kernel_ms * im["clock_ghz"] * 1e6 / (it_max * slots_iter),

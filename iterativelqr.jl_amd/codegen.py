@@ -405,6 +405,17 @@ def _emit_block(outputs, prefix, coop=False):
     sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
     for i in range(len(nodes)):
         visit(i)
+    # CSE temporaries that only fed a trig argument now formed from per-lane coefficients are dead: drop them
+    import re
+    changed = True
+    while changed:
+        changed = False
+        for i, l in enumerate(lines):
+            m_ = re.match(r"^const double (%s\d+) = [^;]*;$" % re.escape(prefix), l)
+            if m_ and not any(re.search(r"\b%s\b" % m_.group(1), o) for j, o in enumerate(lines) if j != i):
+                del lines[i]
+                changed = True
+                break
     return lines
 
 

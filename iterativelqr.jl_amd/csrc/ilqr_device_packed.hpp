@@ -69,6 +69,7 @@ struct PInst {
     double* g;
     // block mapping (instance beta = (lane >> 2) & 3, element (r, c) = (lane >> 4, lane & 3))
     double* gb;
+    const char* wb;    // wave-uniform: block of the wave's first instance (per-lane 32-bit byte offsets are taken from it)
     Layout L;
     int lane, q, j, beta, r, c;
     bool valid_row, valid_blk;
@@ -301,22 +302,31 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     __syncthreads();
     const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n, vmm = on && r < m && c < m;
     const bool vn1 = on && c == 0 && r < n, vm1 = on && c == 0 && r < m;
-    const double* zero = g + L.gzero;
-    double* trash = g + L.gzero + 1;
-    const double* lz = pk_lds + LD::ZERO;
-    // LDS operands of the chunk (per-lane base + step * stride; padding lanes read the LDS zero with stride 0)
-    const double* lfx = vnn ? lblk + LD::FX + c * n + r : lz;     const int sfx = vnn ? LD::SFX : 0;
-    const double* lfu = vnm ? lblk + LD::FU + c * n + r : lz;     const int sfu = vnm ? LD::SFU : 0;
-    const double* lgx = vn1 ? lblk + LD::GX + r : lz;             const int sgx = vn1 ? LD::SGX : 0;
-    const double* lgu = vm1 ? lblk + LD::GU + r : lz;             const int sgu = vm1 ? LD::SGU : 0;
-    // HBM operands: accumulated Hessians (just updated by this wave: L2 hits), results
-    const double* bxx = vnn ? g + L.gxx + c * n + r : zero;   const int sxx = vnn ? n * n : 0;
-    const double* buu = vmm ? g + L.guu + c * m + r : zero;   const int suu = vmm ? m * m : 0;
-    const double* bux = vmn ? g + L.gux + c * m + r : zero;   const int sux = vmn ? m * n : 0;
-    double* qK = vmn ? g + L.K + c * m + r : trash;           const int sK = vmn ? m * n : 0;
-    double* qk = vm1 ? g + L.k + r : trash;                   const int sk = vm1 ? m : 0;
-    double* qLu = vm1 ? g + L.Lu + r : trash;
-    double* qLx = vn1 ? g + L.Lx + r : trash;                 const int sLx = vn1 ? n : 0;
+    // Addresses for INSTRUCTION COUNT (a wave issues one instruction per 5-6 clk whatever it is, tools/probes/probe_issue.hip):
+    // HBM operands and results through 32-bit per-lane byte offsets from the wave's (scalar) base that walk backwards in time — one
+    // v_sub per access instead of a multiply and a 64-bit add; padding lanes aim at the block's zero / trash slot with stride 0.
+    // LDS chunk operands through per-lane byte addresses re-aimed at the top of every chunk.
+    typedef __attribute__((address_space(3))) double ldsd;
+    const char* wb = I.wb;
+    const unsigned ob = (unsigned)((const char*)g - wb);
+    auto GL = [&](unsigned off) -> double { return *(const double*)(wb + off); };
+    auto GS = [&](unsigned off, double v) { *(double*)(const_cast<char*>(wb) + off) = v; };
+    auto ldsa = [](const double* q) -> unsigned { return (unsigned)(size_t)(const ldsd*)q; };
+    auto LDr = [](unsigned a_) -> double { return *(const ldsd*)(size_t)a_; };
+    const unsigned ozero = ob + 8u * L.gzero, otrash = ob + 8u * (L.gzero + 1);
+    unsigned oxx = vnn ? ob + 8u * (L.gxx + (N - 1) * n * n + c * n + r) : ozero;   const unsigned sxx = vnn ? 8u * n * n : 0u;
+    unsigned ouu = vmm ? ob + 8u * (L.guu + (N - 1) * m * m + c * m + r) : ozero;   const unsigned suu = vmm ? 8u * m * m : 0u;
+    unsigned oux = vmn ? ob + 8u * (L.gux + (N - 1) * m * n + c * m + r) : ozero;   const unsigned sux = vmn ? 8u * m * n : 0u;
+    unsigned oK = vmn ? ob + 8u * (L.K + (N - 1) * m * n + c * m + r) : otrash;     const unsigned sK = vmn ? 8u * m * n : 0u;
+    unsigned ok_ = vm1 ? ob + 8u * (L.k + (N - 1) * m + r) : otrash;                const unsigned sk = vm1 ? 8u * m : 0u;
+    unsigned oLu = vm1 ? ob + 8u * (L.Lu + (N - 1) * m + r) : otrash;
+    unsigned oLx = vn1 ? ob + 8u * (L.Lx + (N - 1) * n + r) : otrash;               const unsigned sLx = vn1 ? 8u * n : 0u;
+    const unsigned lzero = ldsa(pk_lds + LD::ZERO);
+    const unsigned bfx = vnn ? ldsa(lblk + LD::FX + c * n + r) : lzero;   const unsigned sfx = vnn ? 8u * LD::SFX : 0u;
+    const unsigned bfu = vnm ? ldsa(lblk + LD::FU + c * n + r) : lzero;   const unsigned sfu = vnm ? 8u * LD::SFU : 0u;
+    const unsigned bgx = vn1 ? ldsa(lblk + LD::GX + r) : lzero;           const unsigned sgx = vn1 ? 8u * LD::SGX : 0u;
+    const unsigned bgu = vm1 ? ldsa(lblk + LD::GU + r) : lzero;           const unsigned sgu = vm1 ? 8u * LD::SGU : 0u;
+    unsigned afx = bfx, afu = bfu, agx = bgx, agu = bgu;
 
     double P = vnn ? g[L.gxx + N * n * n + c * n + r] : 0.0;            // P[H] .= gxx[H]  (:39)
     double p = vn1 ? pk_lds[LD::TERM + I.beta * n + r] : 0.0;           // p[H] .= gx[H]   (:40)
@@ -357,9 +367,11 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     };
     const int blk0 = (lane & 12);
     struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
-    auto fetch = [&](Opnd& o, int t, int sl) {
-        o.gxx = bxx[t * sxx]; o.guu = buu[t * suu]; o.gux = bux[t * sux];
-        o.fx = lfx[sl * sfx]; o.fu = lfu[sl * sfu]; o.gx = lgx[sl * sgx]; o.gu = lgu[sl * sgu];
+    auto fetch = [&](Opnd& o) {          // operands at the walking addresses (timesteps are fetched in descending order), then one step back
+        o.gxx = GL(oxx); o.guu = GL(ouu); o.gux = GL(oux);
+        oxx -= sxx; ouu -= suu; oux -= sux;
+        o.fx = LDr(afx); o.fu = LDr(afu); o.gx = LDr(agx); o.gu = LDr(agu);
+        afx -= sfx; afu -= sfu; agx -= sgx; agu -= sgu;
     };
     auto riccati_step = [&](const Opnd& o, int t) {
         ILQR_ISA_MARK("riccati_step", 4);
@@ -371,40 +383,52 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         const double Quu = mfma444(Wu, fu, o.guu);
         const double Qx = mfma444(fx, p, o.gx);                         // (:44-49)
         const double Qu = mfma444(fu, p, o.gu);
-        double Uc[m * m];
+        double K, k;
         if constexpr (m == 1) {
-            // Quu(0,0) of the block sits on lane 4*beta: DPP quad broadcast hands it to row 0 (K's row), one v_permlane16_swap
-            // to row 1 (k's row) — no LDS round trip (ds_bpermute) on the serial chain; rows 2, 3 are padding
+            // 1x1: Quu(0,0) of the block sits on lane 4*beta; a DPP quad broadcast hands it to the block's row 0, where K (a row) and
+            // k (its first entry) live. Rows 1..3 are padding: Qux and Qu are exactly zero there, a pivot of 1 keeps them zero.
+            // K = -(Qux (1/q)), k = -(Qu (1/q)) with the reciprocal of ilqr_device.hpp's 1x1 shortcut on EVERY lane; an instance
+            // whose potrf fails (q <= 0 or NaN; info ignored by the reference, :69) redoes its lanes in LAPACK's arithmetic behind
+            // one wave-uniform branch — no exec-masked region on the common path.
             const double q0 = quad_bcast<0>(Quu);
-            const double q1 = from_lane_minus16_odd_rows(q0);
-            Uc[0] = (r & 1) ? q1 : q0;                                                                        // (:68-69)
+            const double qs = (r == 0) ? q0 : 1.0;                      // (:68-69)
+            const bool bad = !(qs > 0.0);
+            const double rinv = recip_fast(qs);
+            K = (Qux * rinv) * -1.0;                                    // (:70-75)
+            k = (Qu * rinv) * -1.0;
+            if (__builtin_expect(__any(bad), 0)) {
+                if (bad) {
+                    double Uc[1] = {qs}, Ur[1];
+                    const int info = potrf_U<1>(Uc, Ur);
+                    if (info != 0 && pinfo == 0) pinfo = info;
+                    K = ((Qux * Ur[0]) * Ur[0]) * -1.0;
+                    k = ((Qu * Ur[0]) * Ur[0]) * -1.0;
+                }
+            }
         } else {
+            double Uc[m * m];
 #pragma unroll
             for (int jj = 0; jj < m; ++jj)
 #pragma unroll
                 for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;   // (:68-69)
-        }
-        int info = 0;
-        double Ur[m];
-        if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
-        else info = potrf_U<m>(Uc, Ur);
-        if (m == 1 && info != 0) potrf_U<m>(Uc, Ur);
-        if (info != 0 && pinfo == 0) pinfo = info;
-        double K, k;
-        if constexpr (SHARE) {
-            // right-hand sides: Qux in rows 0..m-1, Qu (column 0) moved down into rows m..2m-1: ONE solve for K and k
-            const double Qu_dn = (m == 1) ? from_lane_minus16_odd_rows(Qu) : from_lane_minus32(Qu);
-            const bool krow = (r >= m && r < 2 * m && c == 0);
-            const double Y = solve(krow ? Qu_dn : Qux, Uc, Ur, info);   // (:70-75)
-            K = (r < m) ? Y : 0.0;
-            const double kY = krow ? Y : 0.0;
-            const double k_up = (m == 1) ? from_lane_plus16_even_rows(kY) : from_lane_plus32(kY);
-            k = (r < m && c == 0) ? k_up : 0.0;
-        } else {                                                        // nu = 3, 4: no spare rows, two solves
-            const double YK = solve(Qux, Uc, Ur, info);
-            const double Yk = solve(Qu, Uc, Ur, info);
-            K = (r < m) ? YK : 0.0;
-            k = (r < m && c == 0) ? Yk : 0.0;
+            double Ur[m];
+            const int info = potrf_U<m>(Uc, Ur);
+            if (info != 0 && pinfo == 0) pinfo = info;
+            if constexpr (SHARE) {
+                // right-hand sides: Qux in rows 0..m-1, Qu (column 0) moved down into rows m..2m-1: ONE solve for K and k
+                const double Qu_dn = from_lane_minus32(Qu);
+                const bool krow = (r >= m && r < 2 * m && c == 0);
+                const double Y = solve(krow ? Qu_dn : Qux, Uc, Ur, info);   // (:70-75)
+                K = (r < m) ? Y : 0.0;
+                const double kY = krow ? Y : 0.0;
+                const double k_up = from_lane_plus32(kY);
+                k = (r < m && c == 0) ? k_up : 0.0;
+            } else {                                                        // nu = 3, 4: no spare rows, two solves
+                const double YK = solve(Qux, Uc, Ur, info);
+                const double Yk = solve(Qu, Uc, Ur, info);
+                K = (r < m) ? YK : 0.0;
+                k = (r < m && c == 0) ? Yk : 0.0;
+            }
         }
         const double uxt = mfma444(Quu, K, 0.0);                        // (:79)
         // (:81-84), (:86-89): summed as ((Qxx + K^T Qux) + Qux^T K) + K^T ux_tmp, the association of backward_pass_mfma
@@ -416,8 +440,8 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         pn = mfma444(Qux, k, pn);
         pn = mfma444(uxt, k, pn);
         const double Lx = Qx - pn;                                      // src/solve.jl:73-81
-        gmax = fmax(gmax, fabs(Lx));
-        gmax = fmax(gmax, fabs(Qu));
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(gmax) : "v"(gmax), "v"(Lx));    // v_max_f64 drops NaNs: they are tracked beside it
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(gmax) : "v"(gmax), "v"(Qu));
         gnan |= (Lx != Lx) | (Qu != Qu);
         // adjoint sensitivity step: w = ∇L_u + fuᵀν', Δ += wᵀk, ν = ∇L_x + fxᵀν' + Kᵀw
         const double wv = mfma444(fu, nu, Qu);
@@ -425,7 +449,8 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         double nun = mfma444(fx, nu, Lx);
         nun = mfma444(K, wv, nun);
         nu = nun;
-        qK[t * sK] = K; qk[t * sk] = k; qLu[t * sk] = Qu; qLx[t * sLx] = Lx;
+        GS(oK, K); GS(ok_, k); GS(oLu, Qu); GS(oLx, Lx);
+        oK -= sK; ok_ -= sk; oLu -= sk; oLx -= sLx;
         P = Pn; p = pn;
     };
     for (int ch = (N + 15) / 16 - 1; ch >= 0; --ch) {
@@ -439,11 +464,12 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         // ---- Riccati steps of the chunk, last timestep first   (:42)
         Opnd A, B;
         int sl = cnt - 1;
-        fetch(A, t0 + sl, sl);
+        afx = bfx + sl * sfx; afu = bfu + sl * sfu; agx = bgx + sl * sgx; agu = bgu + sl * sgu;   // LDS operands of the chunk's last step
+        fetch(A);
         for (; sl >= 1; sl -= 2) {
-            fetch(B, t0 + sl - 1, sl - 1);
+            fetch(B);
             riccati_step(A, t0 + sl);
-            if (sl >= 2) fetch(A, t0 + sl - 2, sl - 2);
+            if (sl >= 2) fetch(A);
             else mfma_block_boundary_guard();         // (see ilqr_device.hpp: a step entered through a taken branch)
             riccati_step(B, t0 + sl - 1);
         }
@@ -599,6 +625,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
     I.valid_row = b_row < a.B; I.valid_blk = b_blk < a.B;
     I.g = a.ws + (size_t)(I.valid_row ? b_row : a.B - 1) * (size_t)L.stride;
     I.gb = a.ws + (size_t)(I.valid_blk ? b_blk : a.B - 1) * (size_t)L.stride;
+    I.wb = (const char*)(a.ws + (size_t)(blockIdx.x * 4) * (size_t)L.stride);
     I.trace = a.trace ? a.trace + (size_t)(I.valid_row ? b_row : 0) * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;
     const ilqr_options& opt = a.opt;

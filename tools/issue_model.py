@@ -2,15 +2,15 @@
 
     python tools/issue_model.py [config ...]      # writes profiles/issue_model.json, prints the loop table
 
-What bounds solve_kernel<Model_acrobot> at batch 1024 is not HBM (counter traffic = 0.6 % of peak) but the serial
-instruction stream of each instance's slowest wave: a lone wave issues one fp64 VALU instruction every ~12 shader
-clocks whether or not it depends on the previous one (tools/probes/probe_mfma.hip, profiles/r01_probes_fp64_latency_dvfs.txt:
-dependent 14.0, independent 13.0 clk/op one wave per SIMD; 12.3 clk at two waves per SIMD, the headline residency),
-so the kernel is bound by the instruction stream of the critical wave, not by bytes.  This script compiles csrc/builtin_models.hip to assembly,
-finds the serial time loops of solve_kernel<Model_X> through comment markers (-DILQR_ISA_MARKERS) and LLVM's loop
-annotations, and counts the instructions ISSUED per timestep on wave 0 by class (s_nop N counts N+1 idle states).
-bench.py turns them into the SIMD-occupancy floor of the slowest instance's critical wave
-(roofline.issue_model.predicted_floor_ms, achieved_over_floor)."""
+What bounds solve_kernel<Model_acrobot> at batch 1024 is not HBM (counter traffic well under 1 % of peak) but the serial
+instruction stream of each instance's slowest wave. tools/probes/probe_issue.hip (profiles/r02_probe_issue.txt) measures what
+ONE wave can issue on gfx950: one instruction every ~5.1-6 shader clocks whatever its class (fp64 / integer VALU, DPP,
+v_readlane, scalar ALU, s_nop) and whether or not it depends on the previous one; a 4x4x4 f64 MFMA every ~17 clk; an LDS write
+every ~13 clk; LDS reads ~7-10 clk. So the step of a serial loop lasts as long as its instruction list, and instruction-level
+parallelism inside the wave buys nothing. This script compiles csrc/builtin_models.hip to assembly, finds the serial time
+loops of solve_kernel<Model_X> through comment markers (-DILQR_ISA_MARKERS) and LLVM's loop annotations, and counts the
+instructions ISSUED per timestep on each wave by class (s_nop N counts N+1 idle states). bench.py turns them into the issue
+time of the slowest instance's critical wave (roofline.issue_model.predicted_floor_ms, achieved_over_floor)."""
 import json
 import os
 import re
@@ -22,10 +22,11 @@ CSRC = os.path.join(ROOT, "iterativelqr.jl_amd", "csrc")
 MANGLED = {"acrobot": "_ZN4ilqr12solve_kernelI13Model_acrobotEEvNS_5KArgsE",
            "car": "_ZN4ilqr12solve_kernelI9Model_carEEvNS_5KArgsE"}
 HORIZON_UNROLL = 2          # both time loops are unrolled by two (ping-pong operand sets)
-# SIMD occupancy of one wave64 instruction, in shader clocks (MI355X_MICROARCH.md: SIMD-32, fp32 VALU 2 clk; fp64 vector
-# peak 78.6 TFLOP/s = 16 DP lanes per clk per SIMD -> 4 clk; v_mfma_f64_4x4x4 = 4 blocks x 64 FMA at the same DP rate -> 16 clk;
-# scalar / branch / wait instructions 1 clk; s_nop N = N + 1 idle states)
-OCC = {"valu_f64": 4.0, "mfma": 16.0, "valu_other": 2.0, "dpp_perm": 2.0, "lds": 2.0, "vmem": 2.0, "salu": 1.0, "waitcnt": 1.0, "nop_states": 1.0}
+# Issue time of one instruction of a LONE wave, in shader clocks (tools/probes/probe_issue.hip, profiles/r02_probe_issue.txt;
+# the critical wave shares its SIMD with one other wave, which the probe shows to cost nothing until both are fp64-dense):
+# VALU of any kind 5.1-6.0, scalar ALU / s_nop 5.1-5.3 (+1 per extra idle state), v_mfma_f64_4x4x4 17, ds_write_b64 13,
+# ds_read_b64 7-10, global load ~6 (issue only)
+OCC = {"valu_f64": 5.5, "mfma": 17.0, "valu_other": 5.1, "dpp_perm": 5.5, "lds": 10.0, "vmem": 6.0, "salu": 5.2, "waitcnt": 5.0, "nop_states": 1.0}
 CLOCK_GHZ = 2.38            # sustained shader clock with 1024 such workgroups resident (probe_clock.hip)
 
 
@@ -168,7 +169,9 @@ def model_for(config, lines):
     table = [dict(rol, kind="rollout (wave 0)", steps=krol), dict(ric, kind="riccati matrix chain (wave 0)", steps=kric),
              dict(vec, kind="riccati vector chain (wave 1)", steps=kvec), dict(dlt, kind="delta sweep (wave 1)", steps=kdlt)]
     slots = lambda c, k: (c["total"] + c["nop_states"]) / k
-    occ = lambda c, k: sum(OCC[key] * c[key] for key in OCC) / k
+    # every s_nop is an instruction of its own (5 clk at the scalar rate) plus one clock per idle state
+    nops = lambda c: c["total"] - sum(c[key] for key in ("valu_f64", "valu_other", "mfma", "salu", "lds", "vmem", "waitcnt", "dpp_perm"))
+    occ = lambda c, k: (sum(OCC[key] * c[key] for key in OCC) + 4.2 * nops(c)) / k
     return {
         "kernel": "solve_kernel<Model_%s>, wave 0 (the instance's critical wave)" % config,
         "rollout_step_instr": slots(rol, krol), "riccati_step_instr": slots(ric, kric),
@@ -178,12 +181,13 @@ def model_for(config, lines):
         "occupancy_clk_per_instruction": OCC, "clock_ghz": CLOCK_GHZ,
         "per_iteration_other_clk": 14000.0,
         "note": "issue slots per timestep = (instructions + s_nop idle states of the loop holding the step marker, cold child loops "
-                "excluded) / step copies in that loop body (-DILQR_ISA_MARKERS analysis build of the same sources). The floor is the "
-                "SIMD OCCUPANCY of the critical wave's stream (perfect instruction-level overlap, no dependency stalls): what is left "
-                "between it and the measured time are the dependent latencies of the serial chain (fp64 FMA 14 clk, MFMA 24-32 clk, "
-                "division 82 clk, LDS 65 clk dependent — profiles/r01_probes_fp64_latency_dvfs.txt). "
-                "per_iteration_other_clk = cost pass + wave 0's share of the linearisation + copies "
-                "(profiles/r01_final_phase_cycles.txt: 0.8 % + 3.4 % + 1.5 % of an iteration)",
+                "excluded) / step copies in that loop body (-DILQR_ISA_MARKERS analysis build of the same sources). *_occupancy_clk = "
+                "the issue time of that instruction list at the single-wave rates of tools/probes/probe_issue.hip "
+                "(occupancy_clk_per_instruction; s_nop N = 5 + N). A lone wave issues one instruction per 5-6 clk whether or not it "
+                "depends on the previous one, so this IS the speed limit of the serial loops; what the measured time adds on top "
+                "is fp64-pipe sharing with the other wave of the SIMD, LDS / HBM waits and barriers. "
+                "per_iteration_other_clk = cost pass + wave 0's share of the linearisation + copies + barriers "
+                "(tools/phase_cycles.py on a -DILQR_PROFILE build of this round: 2.0 k + 7.9 k + 4 k ticks per iteration)",
     }, table
 
 

@@ -17,6 +17,8 @@
                      "v_mov_b32 v6, %4\n v_mov_b32 v7, %5\n"                                                       \
                      :: "v"(__double2loint(a)), "v"(__double2hiint(a)), "v"(__double2loint(b)), "v"(__double2hiint(b)),      \
                         "v"(__double2loint(c)), "v"(__double2hiint(c)) : "v2", "v3", "v4", "v5", "v6", "v7");      \
+        __shared__ double lds_[64]; lds_[threadIdx.x & 63] = 0.0;                                                  \
+        asm volatile("v_mov_b32 v8, 0" ::: "v8");                                                                  \
         long long t0 = clock64();                                                                                  \
         for (int i = 0; i < n; ++i) {                                                                              \
             asm volatile(asm32 ::: "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", \
@@ -56,6 +58,19 @@
 // fp64 result consumed by a 32-bit op and back (the select / sign fix-up pattern)
 #define FMA_THEN_CND_4 "v_fma_f64 v[10:11], v[10:11], v[4:5], v[6:7]\n v_cndmask_b32 v10, v10, v4, vcc\n v_fma_f64 v[10:11], v[10:11], v[4:5], v[6:7]\n v_cndmask_b32 v11, v11, v5, vcc\n"
 
+// more mixes: scalar work hidden behind vector work?  (4 instructions each)
+#define FMA3_SMOV_4 "v_fma_f64 v[10:11], v[2:3], v[4:5], v[6:7]\n v_fma_f64 v[12:13], v[2:3], v[4:5], v[6:7]\n v_fma_f64 v[14:15], v[2:3], v[4:5], v[6:7]\n s_mov_b32 s20, s21\n"
+#define FMADEP_SMOV_4 "v_fma_f64 v[10:11], v[10:11], v[4:5], v[6:7]\n s_mov_b32 s20, s21\n v_fma_f64 v[10:11], v[10:11], v[4:5], v[6:7]\n s_mov_b32 s22, s23\n"
+#define FMADEP_SNOP_4 "v_fma_f64 v[10:11], v[10:11], v[4:5], v[6:7]\n s_nop 0\n v_fma_f64 v[10:11], v[10:11], v[4:5], v[6:7]\n s_nop 0\n"
+#define MFMA_4 "v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[6:7]\n v_mfma_f64_4x4x4_4b_f64 v[12:13], v[2:3], v[4:5], v[6:7]\n v_mfma_f64_4x4x4_4b_f64 v[14:15], v[2:3], v[4:5], v[6:7]\n v_mfma_f64_4x4x4_4b_f64 v[16:17], v[2:3], v[4:5], v[6:7]\n"
+#define MFMA_DEPC_4 "v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]\n v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]\n v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]\n v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]\n"
+#define MFMA_DEPB_4 "v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[10:11], 0\n s_nop 7\n v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[10:11], 0\n s_nop 7\n"
+#define MFMA_FMA_4 "v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[6:7]\n v_fma_f64 v[12:13], v[2:3], v[4:5], v[6:7]\n v_mfma_f64_4x4x4_4b_f64 v[14:15], v[2:3], v[4:5], v[6:7]\n v_fma_f64 v[16:17], v[2:3], v[4:5], v[6:7]\n"
+#define DSW_4 "ds_write_b64 v8, v[2:3]\n ds_write_b64 v8, v[4:5] offset:8\n ds_write_b64 v8, v[6:7] offset:16\n ds_write_b64 v8, v[2:3] offset:24\n"
+#define DSR_4 "ds_read_b64 v[10:11], v8\n ds_read_b64 v[12:13], v8 offset:8\n ds_read_b64 v[14:15], v8 offset:16\n ds_read_b64 v[16:17], v8 offset:24\n"
+#define DSR_FMA_4 "ds_read_b64 v[10:11], v8\n v_fma_f64 v[12:13], v[2:3], v[4:5], v[6:7]\n v_fma_f64 v[14:15], v[2:3], v[4:5], v[6:7]\n v_fma_f64 v[16:17], v[2:3], v[4:5], v[6:7]\n"
+#define BCAST64_4 "v_mov_b64_dpp v[10:11], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp v[12:13], v[4:5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp v[14:15], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp v[16:17], v[2:3] row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+
 #define X8(s) s s s s s s s s
 KERNEL(k_fma64, X8(FMA64_4))
 KERNEL(k_mul64, X8(MUL64_4))
@@ -83,6 +98,18 @@ KERNEL(k_cnd_dep, X8(CND_DEP_4))
 KERNEL(k_fma32_dep, X8(FMA32_DEP_4))
 KERNEL(k_fma_then_cnd, X8(FMA_THEN_CND_4))
 
+KERNEL(k_fma3_smov, X8(FMA3_SMOV_4))
+KERNEL(k_fmadep_smov, X8(FMADEP_SMOV_4))
+KERNEL(k_fmadep_snop, X8(FMADEP_SNOP_4))
+KERNEL(k_mfma, X8(MFMA_4))
+KERNEL(k_mfma_depc, X8(MFMA_DEPC_4))
+KERNEL(k_mfma_depb, X8(MFMA_DEPB_4))
+KERNEL(k_mfma_fma, X8(MFMA_FMA_4))
+KERNEL(k_dsw, X8(DSW_4))
+KERNEL(k_dsr, X8(DSR_4) "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_dsr_fma, X8(DSR_FMA_4) "s_waitcnt lgkmcnt(0)\n")
+KERNEL(k_bcast64, X8(BCAST64_4))
+
 typedef void (*kfn)(double*, int);
 int main() {
     double* d; hipMalloc(&d, 1024);
@@ -95,12 +122,17 @@ int main() {
         {"mix fma64 / s_mov", k_fma_smov}, {"mix fma64 / v_mov_b32", k_fma_mov}, {"mix fma64 / v_cndmask", k_fma_cnd}, {"mix fma64 / v_readlane", k_fma_rdl},
         {"v_fma_f64 dependent", k_fma64_dep}, {"v_mul_f64 dependent", k_mul64_dep}, {"v_add_f64 dependent", k_add64_dep},
         {"v_fma_f32 dependent", k_fma32_dep}, {"v_mov_b32 dependent", k_mov32_dep}, {"v_cndmask_b32 dependent", k_cnd_dep},
-        {"fma64 -> cndmask -> fma64 dependent", k_fma_then_cnd}};
+        {"fma64 -> cndmask -> fma64 dependent", k_fma_then_cnd},
+        {"mix 3 fma64 / 1 s_mov", k_fma3_smov}, {"mix dependent fma64 / salu", k_fmadep_smov}, {"mix dependent fma64 / s_nop 0", k_fmadep_snop},
+        {"v_mfma_f64_4x4x4 independent", k_mfma}, {"v_mfma_f64_4x4x4 dependent (C)", k_mfma_depc},
+        {"v_mfma_f64_4x4x4 dependent (B) + s_nop 7", k_mfma_depb}, {"mix mfma / fma64", k_mfma_fma},
+        {"ds_write_b64", k_dsw}, {"ds_read_b64 (32 then wait)", k_dsr}, {"mix ds_read / 3 fma64", k_dsr_fma},
+        {"v_mov_b64_dpp row_newbcast", k_bcast64}};
     const int n = 40000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("clk per instruction seen by ONE wave (s_memtime); and wall time of the launch per instruction of a wave; columns: 1 wave on the chip | 1 | 2 | 4 waves per SIMD\n");
     for (auto& k : ks) {
-        printf("%-40s", k.name);
+        printf("%-40s", k.name); fflush(stdout);
         for (int blocks : {1, 1024, 2048, 4096}) {
             k.f<<<blocks, 64>>>(d, n);                                    // warm
             hipEventRecord(e0);
@@ -110,7 +142,7 @@ int main() {
             double h; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
             printf(" %6.2f (%6.2f ns)", h, ms * 1e6 / (32.0 * n));
         }
-        printf("\n");
+        printf("\n"); fflush(stdout);
     }
     return 0;
 }
