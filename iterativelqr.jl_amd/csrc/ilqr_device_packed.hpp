@@ -485,16 +485,25 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
 }
 
 // ------------------------------------------------------------- rollout! (row mapping, cooperative inside a row)
-// alpha is per instance. Lane j == 0 of an active row stores the trial trajectory.
+// alpha is per instance. Lane j == 0 of an active row stores the trial trajectory. Every operand and result goes through 32-bit
+// byte offsets from the wave's scalar base that advance once per three steps (immediate offsets in between), instead of a
+// multiply and a 64-bit add per access. (Forming a_t = k_t α + ū_t and b_t = K_t x̄_t beforehand, as the LDS kernels do, does
+// not pay here: the pass that forms them waits on HBM seven times per rollout with nothing to hide behind — measured
+// 113 -> 119 ms on acrobot:8192.)
 template <class M>
 __device__ void rollout(PInst<M>& I, bool act, double alpha) {
     constexpr int n = M::NX, m = M::NU;
     const Layout& L = I.L;
     const int N = L.T - 1;
     double* g = I.g;
+    const char* wb = I.wb;
+    const unsigned og = (unsigned)((const char*)g - wb);
+    // (offset zero-extended FIRST, constant index added in 64 bits: the constant then folds into the instruction's immediate
+    // offset and neighbouring doubles merge into one wide load; a 32-bit add could wrap, so hipcc would keep it)
+    auto GL = [&](unsigned off, int idx) -> double { return ((const double*)(wb + off))[idx]; };
+    auto GS = [&](unsigned off, int idx, double v) { ((double*)(const_cast<char*>(wb) + off))[idx] = v; };
+    const unsigned otrash = og + 8u * (L.gzero + 1);
     const bool wr = act && I.j == 0;
-    double* px = wr ? g + L.x : g + L.gzero + 1;   const int sx = wr ? n : 0;
-    double* pu = wr ? g + L.u : g + L.gzero + 1;   const int su = wr ? m : 0;
     double xt[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) xt[i] = g[L.xb + i];                    // (:19)
@@ -502,59 +511,61 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) g[L.x + i] = xt[i];
     }
-    const typename M::WaveCtx wcx = M::template wave_ctx<false>(I.j);                  // per-lane constants of the cooperative dynamics (I.j: lane of the row)
+    const typename M::WaveCtx wcx = M::template wave_ctx<false>(I.j);   // per-lane constants of the cooperative dynamics (I.j: lane of the row)
+    // loads on every lane of the row (all lanes evaluate the policy), stores on the row's lane 0 only (trash slot, stride 0 elsewhere)
+    unsigned oK = og + 8u * L.K, ok_ = og + 8u * L.k, oub = og + 8u * L.ub, oxb = og + 8u * L.xb;
+    unsigned wU = wr ? og + 8u * L.u : otrash, wX = wr ? og + 8u * L.x : otrash;
+    const unsigned sU = wr ? 8u * m : 0u, sX = wr ? 8u * n : 0u;
     struct Ops { double K[m * n], k[m], ub[m], xb[n]; };
-    auto fetch = [&](Ops& o, int t) {
+    // d: step offset (0..4) from the step the walking offsets stand at
+    auto fetch = [&](Ops& o, int d) {
 #pragma unroll
-        for (int i = 0; i < m * n; ++i) o.K[i] = g[L.K + t * m * n + i];
+        for (int i = 0; i < m * n; ++i) o.K[i] = GL(oK, d * m * n + i);
 #pragma unroll
-        for (int i = 0; i < m; ++i) { o.k[i] = g[L.k + t * m + i]; o.ub[i] = g[L.ub + t * m + i]; }
+        for (int i = 0; i < m; ++i) { o.k[i] = GL(ok_, d * m + i); o.ub[i] = GL(oub, d * m + i); }
 #pragma unroll
-        for (int i = 0; i < n; ++i) o.xb[i] = g[L.xb + t * n + i];
+        for (int i = 0; i < n; ++i) o.xb[i] = GL(oxb, d * n + i);
     };
-    auto step = [&](const Ops& o, int t, const double (&xin)[n], double (&xout)[n]) {
+    auto step = [&](const Ops& o, int t, int d, const double (&xin)[n], double (&xout)[n]) {
         ILQR_ISA_MARK("rollout_step", 3);
         double ut[m];
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-            double v = o.k[i] * alpha;                                  // (:24-25)
-            v += o.ub[i];                                               // (:26)
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int jj = 0; jj < n; ++jj) {
-                a1 += o.K[jj * m + i] * xin[jj];
-                a2 += o.K[jj * m + i] * o.xb[jj];
+                a1 = fma(o.K[jj * m + i], xin[jj], a1);
+                a2 = fma(o.K[jj * m + i], o.xb[jj], a2);
             }
-            v += a1;                                                    // (:27)
-            v += -1.0 * a2;                                             // (:28)
-            ut[i] = v;
+            ut[i] = (fma(o.k[i], alpha, o.ub[i]) + a1) - a2;            // (:24-28)
         }
         double w[cdim<M::NW>::v];
         load_w<M::NW>(g + L.w, t, w);
         M::template dyn_wave<Row16BC>(wcx, I.j, xin, ut, w, xout);      // (:29)
 #pragma unroll
-        for (int i = 0; i < m; ++i) pu[t * su + (wr ? i : 0)] = ut[i];
+        for (int i = 0; i < m; ++i) GS(wU + d * sU, wr ? i : 0, ut[i]);
 #pragma unroll
-        for (int i = 0; i < n; ++i) px[(t + 1) * sx + (wr ? i : 0)] = xout[i];
+        for (int i = 0; i < n; ++i) GS(wX + (d + 1) * sX, wr ? i : 0, xout[i]);
     };
-    // operands are fetched TWO steps ahead (three rotating register sets): K, k, ū, x̄ come from HBM / L2 here, and at one
-    // wave per SIMD nothing else hides their latency
+    // operands are fetched TWO steps ahead (three rotating register sets): they come from HBM / L2 here, and at one wave per
+    // SIMD nothing else hides their latency
     Ops A, B, C;
     double xo[n];
     if (N > 0) fetch(A, 0);
     if (N > 1) fetch(B, 1);
     int t = 0;
     for (; t + 2 < N; t += 3) {
-        fetch(C, t + 2);
-        step(A, t, xt, xo);
-        if (t + 3 < N) fetch(A, t + 3);
-        step(B, t + 1, xo, xt);
-        if (t + 4 < N) fetch(B, t + 4);
-        step(C, t + 2, xt, xo);
+        fetch(C, 2);
+        step(A, t, 0, xt, xo);
+        if (t + 3 < N) fetch(A, 3);
+        step(B, t + 1, 1, xo, xt);
+        if (t + 4 < N) fetch(B, 4);
+        step(C, t + 2, 2, xt, xo);
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = xo[i];
+        oK += 24u * m * n; ok_ += 24u * m; oub += 24u * m; oxb += 24u * n; wU += 3u * sU; wX += 3u * sX;
     }
-    if (t < N) { step(A, t, xt, xo); ++t; if (t < N) step(B, t, xo, xt); }
+    if (t < N) { step(A, t, 0, xt, xo); ++t; if (t < N) step(B, t, 1, xo, xt); }
     __syncthreads();
 }
 
@@ -714,7 +725,9 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                 // while step_size >= min_step_size && iteration <= 25   (:28-29)
                 const bool go = fw && (I.step_size >= opt.min_step_size) && (I.trial <= 25);
                 if (__any(go)) {
-                    if (!(dbg & 16)) rollout<M>(I, go, I.step_size);                      // (:34)
+                    if (!(dbg & 16)) {                                                      // (:34)
+                        rollout<M>(I, go, I.step_size);
+                    }
                     if (go) { I.rollouts += 1; I.states_eq_nominal = 0; }
                     if (!(dbg & 32)) cost_bang<M>(I, go, true, constrained);              // (:36)
                     const bool acc = go && !(dbg & 1) && (I.objective <= I.J_prev + 1.0e-4 * I.step_size * I.delta);   // (:44) NaN ⇒ reject
