@@ -588,8 +588,9 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         # per-lane constants of the cooperative code, built ONCE per kernel (not per timestep): the trig pair coefficients and
         # the coefficient columns of the affine trig arguments, indexed by the angle slot pq = (lane & 15) >> 1
         ctx = ["    struct WaveCtx { ilqr::TrigPair tp; double a[%d], k[%d]; };" % (max(1, len(_CTX)), max(1, len(consts))),
-               "    // PIN_CONSTANTS = false (packed kernel, short of VGPRs): the model constants stay compile-time constants",
-               "    template <bool PIN_CONSTANTS = true> __device__ __forceinline__ static WaveCtx wave_ctx(const int lane) {",
+               "    // PIN_CONSTANTS = true keeps the model's fp64 constants in VGPRs too (8 fewer scalar-pair moves per acrobot step, but the",
+               "    // forward pass then needs 248 VGPRs and its caller spills around the call: not used by the shipped kernels)",
+               "    template <bool PIN_CONSTANTS = false> __device__ __forceinline__ static WaveCtx wave_ctx(const int lane) {",
                "        const int pq = (lane & 15) >> 1; (void)pq;",
                "        WaveCtx cx;",
                "        cx.tp = ilqr::make_trig_pair<PIN_CONSTANTS>(lane);"]

@@ -1127,7 +1127,7 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m;
     double zx = 0.0, dacc = 0.0;
     (void)blk;
-    const typename M::WaveCtx wcx = M::wave_ctx(lane);               // per-lane constants of the cooperative dynamics, built once
+    const typename M::WaveCtx wcx = M::template wave_ctx<false>(lane);               // per-lane constants of the cooperative dynamics, built once
     // LDS byte addresses of K_t, u[t], x[t] held in VGPRs (opaque to the compiler, which would otherwise rebuild every address
     // from scalar registers with shift / add / move triples); they advance by two steps per loop trip, all other offsets are
     // immediates. Operands of step t are fetched one step ahead; the loop is unrolled by two with ping-pong operand sets.

@@ -201,7 +201,7 @@ __device__ __forceinline__ double pair_swap(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-template <bool PIN_UNIFORM = true>
+template <bool PIN_UNIFORM = false>
 __device__ __forceinline__ TrigPair make_trig_pair(int lane) {
     TrigPair t = trig_pair_constants(lane & 1);
     // pinned in registers: the time loops must not rebuild per-lane constants with selects every step

@@ -40,7 +40,7 @@ struct AdaptedModel {
         F::dynamics(y, x, u, w);
     }
     struct WaveCtx {};
-    template <bool PIN_CONSTANTS = true> __device__ __forceinline__ static WaveCtx wave_ctx(const int) { return WaveCtx{}; }
+    template <bool PIN_CONSTANTS = false> __device__ __forceinline__ static WaveCtx wave_ctx(const int) { return WaveCtx{}; }
     template <class BC = RowBC>
     __device__ __forceinline__ static void dyn_wave(const WaveCtx&, const int, const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&y)[NX]) {
         dyn(x, u, w, y);
