@@ -504,9 +504,9 @@ __device__ __forceinline__ void potrs_U(const double (&U)[m * m], double (&B)[m 
 
 // ------------------------------------------------- backward_pass! on the matrix cores
 // For nx <= 4, nu <= 4 the whole Riccati step runs on v_mfma_f64_4x4x4 (4 blocks).
-// Measured on gfx950 (tools/probes/probe_mfma.hip): with one wave per SIMD a fp64
-// VALU instruction issues only every ~14 clk, a dependent 4x4x4 f64 MFMA every
-// 24-32 clk — one MFMA replaces ~16 DP FMAs plus the cross-lane traffic they need.
+// Measured on gfx950 (tools/probes/probe_issue.hip): one wave issues an fp64 VALU
+// instruction every 5-6 clk and a 4x4x4 f64 MFMA every ~17 clk, dependent or not —
+// one MFMA replaces ~16 DP FMAs plus the cross-lane traffic they would need.
 // Lane layout of the instruction (decoded by the probe), block beta = (lane>>2)&3:
 //     A[i][k] at lane i + 4*beta + 16*k,  B[k][j] at lane j + 4*beta + 16*k,
 //     C/D[i][j] at lane j + 4*beta + 16*i.
