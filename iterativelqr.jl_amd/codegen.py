@@ -533,7 +533,8 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     assert cost_stage.num_state == n and cost_stage.num_action == m
     assert cost_term.num_state == n and cost_term.num_action == 0
     ncs, nct = con_stage.num_constraint, con_term.num_constraint
-    assert ncs <= 64 and nct <= 64
+    assert ncs <= 64 and nct <= 64, "at most 64 constraint rows per stage (64-bit inequality masks)"
+    assert n <= 64 and m <= 16, "device kernels: nx <= 64 (one state component per lane on the large path), nu <= 16"
     ineq_s = sum(1 << (i - 1) for i in con_stage.indices_inequality)
     ineq_t = sum(1 << (i - 1) for i in con_term.indices_inequality)
     sname = "Model_" + name

@@ -1,4 +1,4 @@
-// Large-model path (nx > 4 or nu > 4, up to nx = 32, nu = 16), e.g. BASELINE config "synth32".
+// Large-model path (nx > 4 or nu > 4, up to nx = 64 — one state component per lane — and nu = 16), e.g. BASELINE config "synth32".
 //
 // Differences from the LDS-resident small-model path of ilqr_device.hpp:
 //   * the per-instance workspace (2.4 MB for nx=32, nu=8, T=101) stays in HBM; the wave streams the
@@ -262,7 +262,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, ldm = LD::ldm;
     constexpr int n4 = r4(n), m4 = r4(m), TN = NP / 16, TM = MP / 16, NT = 128;
     constexpr int EFX = (n * n + NT - 1) / NT, EFU = (n * m + NT - 1) / NT;
-    static_assert(n <= 32 && m <= 16, "large path: nx <= 32, nu <= 16");
+    static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
     static_assert(LD::total == large_lds_doubles(n, m), "LDS carve and host-side size disagree");
     static_assert(waves_of<M>::value == 2, "the Riccati step is written for two waves per instance");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
@@ -440,17 +440,22 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             fetch_late(t > 0 ? t - 1 : 0);
             ILQR_SUB_MARK(I, 3);
             // potrs('U'): column j of Qux per lane, Qu on lane n   (:70-75)
-            if (lane <= n) {
-                const int j = lane;
-                double b[m];
+            // (nx = 64 leaves no lane for k: a second pass on lane 0)
 #pragma unroll
-                for (int i = 0; i < m; ++i) b[i] = j < n ? sQux[j * ldm + i] : sQu[i];
-                potrs_U_rdiag<m, 1>(Uc, Ur, b);       // inverted diagonal from the factorisation: no divisions here
+            for (int pass = 0; pass < (n < 64 ? 1 : 2); ++pass) {
+                const bool mine = n < 64 ? lane <= n : (pass == 0 || lane == 0);
+                if (mine) {
+                    const int j = (n < 64 || pass == 0) ? lane : n;
+                    double b[m];
 #pragma unroll
-                for (int i = 0; i < m; ++i) {
-                    const double v = b[i] * -1.0;
-                    if (j < n) { sK[j * ldm + i] = v; I.K[(size_t)t * m * n + j * m + i] = v; }
-                    else { sk[i] = v; I.k[t * m + i] = v; }
+                    for (int i = 0; i < m; ++i) b[i] = j < n ? sQux[j * ldm + i] : sQu[i];
+                    potrs_U_rdiag<m, 1>(Uc, Ur, b);       // inverted diagonal from the factorisation: no divisions here
+#pragma unroll
+                    for (int i = 0; i < m; ++i) {
+                        const double v = b[i] * -1.0;
+                        if (j < n) { sK[j * ldm + i] = v; I.K[(size_t)t * m * n + j * m + i] = v; }
+                        else { sk[i] = v; I.k[t * m + i] = v; }
+                    }
                 }
             }
         } else {
@@ -581,7 +586,7 @@ template <class M>
 __device__ __forceinline__ void rollout_large_body(const LargeArgs& A, double alpha, int lane) {
     typedef LargeDims<M> LD;
     constexpr int n = M::NX, m = M::NU, EK = (m * n + 63) / 64;
-    static_assert(n <= 32 && m <= 16, "large path: nx <= 32, nu <= 16");
+    static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const int N = A.N;
     double* sK = lds_dyn + LD::oK;                     // packed m x n

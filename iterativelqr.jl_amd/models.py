@@ -210,6 +210,36 @@ def synth32():
     )
 
 
+def synth_nm(n, m):
+    """The synth32 family at other sizes (x⁺ = x + h(Ax + Bu + 0.1 sin x), action box as 2 nu stage inequalities): the large
+    path takes nx <= 48, nu <= 16."""
+    h = 0.05
+    A = [[(-1.0 if i == j else 0.0) + 0.3 * math.cos(float((i + 1) + 2 * (j + 1))) / float(n) for j in range(n)] for i in range(n)]
+    Bm = [[math.sin(float(3 * (i + 1) + (j + 1))) / math.sqrt(float(n)) for j in range(m)] for i in range(n)]
+
+    def f(x, u):
+        out = []
+        for i in range(n):
+            acc = 0.0
+            for j in range(n):
+                acc = acc + A[i][j] * x[j]
+            for j in range(m):
+                acc = acc + Bm[i][j] * u[j]
+            acc = acc + 0.1 * sp.sin(x[i])
+            out.append(x[i] + h * acc)
+        return out
+
+    xg = 0.5
+    return dict(
+        dynamics=Dynamics(f, n, m),
+        cost_stage=Cost(lambda x, u: 0.1 * sum((xi - xg) * (xi - xg) for xi in x) + 0.01 * _dot(u, u), n, m),
+        cost_term=Cost(lambda x, u: 10.0 * sum((xi - xg) * (xi - xg) for xi in x), n, 0),
+        con_stage=Constraint(lambda x, u: [-1.0 - u[j] for j in range(m)] + [u[j] - 1.0 for j in range(m)], n, m,
+                             indices_inequality=list(range(1, 2 * m + 1))),
+        con_term=Constraint(),
+    )
+
+
 def synth12():
     """A second large-path model whose dimensions are NOT multiples of the MFMA tile (nx = 12, nu = 5), with a
     bilinear term (state-dependent fu entries) and a terminal equality; twin of oracle/models.cpp "synth12"."""

@@ -6,6 +6,7 @@ device libm, reduction order); whole solve |Î”x|,|Î”u| â‰¤ 1e-7, |Î”K| â‰¤ 5e-7Â
 for instances whose control flow (iteration counts) matches the oracle's.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -950,3 +951,33 @@ def test_fused_backward_pass_equals_staged_for_even_and_odd_horizons(pkg, model,
             sol.close()
         for a, b in zip(out["fused"], out["staged"]):
             assert np.array_equal(a, b), (model, variant, T, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("nm", [(40, 6), (48, 16), (64, 8)])
+def test_large_path_beyond_32_states_against_the_independent_restatement(pkg, nm):
+    """nx = 40, nu = 6 and nx = 48, nu = 16 (the limits; three 16x16 MFMA tiles per side, the generic tile loops of ilqr_device_large.hpp; the reference sizes
+    everything dynamically, src/data/policy.jl:44-78). No oracle twin exists for this size: the check is the second,
+    independent restatement (numpy + sympy + scipy LAPACK, tests/golden/reference_restatement.py) run live."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    (n, m), T, B = nm, 21, 3
+    rng = np.random.default_rng(40)
+    x1 = 0.5 * rng.standard_normal((B, n)); ub = 0.4 * rng.standard_normal((B, T - 1, m))
+    mdl = pkg.models.synth_nm(n, m)
+    sol = pkg.Solver([mdl["dynamics"]] * (T - 1), [mdl["cost_stage"]] * (T - 1) + [mdl["cost_term"]],
+                     [mdl["con_stage"]] * (T - 1) + [mdl["con_term"]], batch=B, options=pkg.Options(verbose=0), name="synth%d" % n)
+    assert (sol.nx, sol.nu, sol.nc_stage) == (n, m, 2 * m)
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    dyn, costs, cons = R.synth32_problem(T, n, m)
+    for b in range(B):
+        s = R.Solver(dyn, costs, cons)
+        s.initialize_controls(ub[b]); s.initialize_states(R.rollout(dyn, x1[b], ub[b]))
+        s.solve()
+        assert st["iterations"][b] == s.iterations and st["outer_iterations"][b] == s.outer_iterations, (b, st["iterations"][b], s.iterations)
+        assert st["iterations"][b] >= 2
+        assert np.abs(x[b] - np.stack(s.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s.nominal_actions[:-1])).max() < 1e-8
+        Kr = np.stack([Kt.T for Kt in s.K])                    # [t][n][m]: column-major m x n blocks
+        assert np.abs(K[b] - Kr).max() <= 1e-7 * max(1.0, np.abs(Kr).max())
+        assert abs(st["objective"][b] - s.objective) <= 1e-9 * max(1.0, abs(s.objective))
+    sol.close()
