@@ -701,8 +701,9 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     L.append("};")
     src = "\n".join(L) + "\n"
     # the cooperative rollout code is generic over HOW a value travels from one lane of the cooperating group to all of
-    # them: ilqr::WaveBC (whole wave, v_readlane) in the latency / throughput kernels, ilqr::Row16BC (16-lane rows,
-    # ds_swizzle) in the packed kernel that runs four instances per wave
+    # them: ilqr::RowBC (16-lane rows, one v_mov_b64_dpp row_newbcast per value) for small models in every kernel — four
+    # instances per wave in the packed kernel, four identical copies of one instance in the LDS kernels — and ilqr::WaveBC
+    # (whole wave, v_readlane) for the remainder code of large models
     src = src.replace("ilqr::wave_bcast<", "BC::template bcast<")
     for fn in ("dyn_wave", "dyn_rem_wave"):
         src = src.replace("__device__ __forceinline__ static void %s(" % fn,

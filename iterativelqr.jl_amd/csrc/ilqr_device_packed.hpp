@@ -12,7 +12,7 @@
 //     instance beta of the wave (element (r, c) on lane c + 4*beta + 16*r);
 //   * the time-parallel phases (cost, linearisation) and the rollout use the ROW mapping: instance q = lane >> 4 owns
 //     the 16 lanes of row q; the cooperative dynamics (one sincos / one division sequence for all arguments of a
-//     dependency level) exchange values inside a row with ds_swizzle (ilqr::Row16BC);
+//     dependency level) exchange values inside a row with 64-bit DPP row broadcasts (ilqr::RowBC);
 //   * the reference's per-instance control flow (AL outer loop, iLQR inner loop, Armijo trials) becomes a per-instance
 //     STATE MACHINE: the wave cycles  [outer-loop transitions] -> [line-search trial] -> [linearise + Riccati]  and an
 //     instance takes part in a phase when its state asks for it (predicated stores). An instance that rejects a trial
