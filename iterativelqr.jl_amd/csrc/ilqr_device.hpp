@@ -302,8 +302,19 @@ __device__ void gradients_small(Inst<M>& I, bool constrained) {
 #pragma unroll
                 for (int i = 0; i < n * m; ++i) I.fu[t * n * m + i] = fu[i];
             }
-            double gx[n], gu[m], hxx[n * n], huu[m * m], hux[m * n];
+            double gx[n], gu[m];
             M::cost_s_grad(xt, ut, w, gx, gu);
+            if constexpr (ncs == 0) {
+                // no stage constraints: the accumulated Hessians (HBM) change only where the stage cost's Hessian is structurally
+                // non-zero — read-modify-write THOSE entries (acrobot: 3 of 21 doubles per timestep) instead of the dense blocks
+                M::cost_s_hess_acc(xt, ut, w, I.gxx + t * n * n, I.guu + t * m * m, I.gux + t * m * n);   // `.+=` (src/costs.jl:74-80)
+#pragma unroll
+                for (int i = 0; i < n; ++i) I.gx[t * n + i] = gx[i];
+#pragma unroll
+                for (int i = 0; i < m; ++i) I.gu[t * m + i] = gu[i];
+                continue;
+            }
+            double hxx[n * n], huu[m * m], hux[m * n];
             M::cost_s_hess(xt, ut, w, hxx, huu, hux);
             double axx[n * n], auu[m * m], aux[m * n];
 #pragma unroll
