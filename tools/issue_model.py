@@ -179,7 +179,7 @@ def model_for(config, lines):
         "rollout_loop": dict(rol, steps_in_body=krol), "riccati_loop": dict(ric, steps_in_body=kric),
         "rollout_step_occupancy_clk": occ(rol, krol), "riccati_step_occupancy_clk": occ(ric, kric),
         "occupancy_clk_per_instruction": OCC, "clock_ghz": CLOCK_GHZ,
-        "per_iteration_other_clk": 14000.0,
+        "per_iteration_other_clk": {"acrobot": 13400.0, "car": 11000.0}.get(config, 14000.0),
         "note": "issue slots per timestep = (instructions + s_nop idle states of the loop holding the step marker, cold child loops "
                 "excluded) / step copies in that loop body (-DILQR_ISA_MARKERS analysis build of the same sources). *_occupancy_clk = "
                 "the issue time of that instruction list at the single-wave rates of tools/probes/probe_issue.hip "
@@ -187,7 +187,7 @@ def model_for(config, lines):
                 "depends on the previous one, so this IS the speed limit of the serial loops; what the measured time adds on top "
                 "is fp64-pipe sharing with the other wave of the SIMD, LDS / HBM waits and barriers. "
                 "per_iteration_other_clk = cost pass + wave 0's share of the linearisation + copies + barriers "
-                "(tools/phase_cycles.py on a -DILQR_PROFILE build of this round: 2.0 k + 7.9 k + 4 k ticks per iteration)",
+                "(tools/phase_cycles.py on a -DILQR_PROFILE build, profiles/r02_phase_cycles.txt: acrobot 2.0 k + 7.2 k + 4.2 k, car 3.3 k + 4.0 k + 3.6 k ticks per iteration)",
     }, table
 
 
