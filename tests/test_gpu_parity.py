@@ -981,3 +981,38 @@ def test_large_path_beyond_32_states_against_the_independent_restatement(pkg, nm
         assert np.abs(K[b] - Kr).max() <= 1e-7 * max(1.0, np.abs(Kr).max())
         assert abs(st["objective"][b] - s.objective) <= 1e-9 * max(1.0, abs(s.objective))
     sol.close()
+
+
+def test_cooperative_rollout_with_non_affine_trig_arguments(pkg):
+    """The generated cooperative rollout code forms AFFINE trig arguments from per-lane coefficients and falls back to one select
+    per angle otherwise (codegen.py). No built-in model takes the fallback: a user model with sin(x0 x1), cos(x0 + 2 x1^2)
+    next to an affine sin(x0), on all three small-model kernels, against the independent restatement run live."""
+    import sympy as sp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    h, n, m, T, B = 0.1, 2, 1, 21, 4
+    f = lambda x, u: [x[0] + h * (x[1] + 0.2 * sp.sin(x[0] * x[1])), x[1] + h * (u[0] - sp.sin(x[0]) + 0.1 * sp.cos(x[0] + 2.0 * x[1] * x[1]))]
+    ls = lambda x, u: 0.1 * (x[0] * x[0] + x[1] * x[1]) + 0.05 * u[0] * u[0]
+    lt = lambda x, u: 2.0 * (x[0] * x[0] + x[1] * x[1])
+    goal = lambda x, u: [x[0] - 0.5]
+    rng = np.random.default_rng(77)
+    x1 = 0.3 * rng.standard_normal((B, n)); ub = 0.5 * rng.standard_normal((B, T - 1, m))
+    rdyn = R.Dynamics(f, n, m)
+    rs = []
+    for b in range(B):
+        s = R.Solver([rdyn] * (T - 1), [R.Cost(ls, n, m)] * (T - 1) + [R.Cost(lt, n, 0)], [R.Constraint()] * (T - 1) + [R.Constraint(goal, n, 0)])
+        s.initialize_controls(ub[b]); s.initialize_states(R.rollout([rdyn] * (T - 1), x1[b], ub[b]))
+        s.solve()
+        rs.append(s)
+    dyn = pkg.Dynamics(f, n, m)
+    for variant in ("latency", "throughput", "packed"):
+        sol = pkg.Solver([dyn] * (T - 1), [pkg.Cost(ls, n, m)] * (T - 1) + [pkg.Cost(lt, n, 0)],
+                         [pkg.Constraint()] * (T - 1) + [pkg.Constraint(goal, n, 0)], batch=B, options=pkg.Options(verbose=0), name="nonaffine")
+        sol.set_kernel_variant_(variant)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        x, u = sol.get_trajectory(); st = sol.stats()
+        for b, s in enumerate(rs):
+            assert st["iterations"][b] == s.iterations and st["rollouts"][b] == s.rollouts, (variant, b)
+            assert np.abs(x[b] - np.stack(s.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s.nominal_actions[:-1])).max() < 1e-8
+        assert st["iterations"].min() >= 3
+        sol.close()
