@@ -1016,3 +1016,44 @@ def test_cooperative_rollout_with_non_affine_trig_arguments(pkg):
             assert np.abs(x[b] - np.stack(s.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s.nominal_actions[:-1])).max() < 1e-8
         assert st["iterations"].min() >= 3
         sol.close()
+
+
+def test_cooperative_rollout_with_many_angles_and_nested_trig(pkg):
+    """Ten distinct angles on one dependency level (two batches of trig pairs: eight + two) and a nested sin(0.5 cos(x0)) on a
+    second level, nx = 4, nu = 2, on all three small-model kernels, against the independent restatement run live."""
+    import sympy as sp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    h, n, m, T, B = 0.05, 4, 2, 17, 3
+
+    def f(x, u):
+        s = sp.sin
+        a = [s(x[0]), sp.cos(x[1]), s(x[2]), sp.cos(x[3]), s(x[0] + x[1]), s(x[1] + x[2]), s(x[2] + x[3]), s(x[0] - x[3]), s(2.0 * x[0]), s(3.0 * x[1])]
+        nest = s(0.5 * sp.cos(x[0]))
+        return [x[0] + h * (x[2] + 0.1 * (a[0] + a[4] + a[8]) + 0.05 * nest),
+                x[1] + h * (x[3] + 0.1 * (a[1] + a[5] + a[9])),
+                x[2] + h * (u[0] - 0.3 * a[2] + 0.1 * a[6]),
+                x[3] + h * (u[1] - 0.3 * a[3] + 0.1 * a[7])]
+    ls = lambda x, u: 0.1 * sum(xi * xi for xi in x) + 0.05 * (u[0] * u[0] + u[1] * u[1])
+    lt = lambda x, u: 2.0 * sum(xi * xi for xi in x)
+    goal = lambda x, u: [x[0] - 0.4, x[1] + 0.2]
+    rng = np.random.default_rng(78)
+    x1 = 0.3 * rng.standard_normal((B, n)); ub = 0.5 * rng.standard_normal((B, T - 1, m))
+    rdyn = R.Dynamics(f, n, m)
+    rs = []
+    for b in range(B):
+        s_ = R.Solver([rdyn] * (T - 1), [R.Cost(ls, n, m)] * (T - 1) + [R.Cost(lt, n, 0)], [R.Constraint()] * (T - 1) + [R.Constraint(goal, n, 0)])
+        s_.initialize_controls(ub[b]); s_.initialize_states(R.rollout([rdyn] * (T - 1), x1[b], ub[b]))
+        s_.solve()
+        rs.append(s_)
+    dyn = pkg.Dynamics(f, n, m)
+    for variant in ("latency", "throughput", "packed"):
+        sol = pkg.Solver([dyn] * (T - 1), [pkg.Cost(ls, n, m)] * (T - 1) + [pkg.Cost(lt, n, 0)],
+                         [pkg.Constraint()] * (T - 1) + [pkg.Constraint(goal, n, 0)], batch=B, options=pkg.Options(verbose=0), name="manyangles")
+        sol.set_kernel_variant_(variant)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        x, u = sol.get_trajectory(); st = sol.stats()
+        for b, s_ in enumerate(rs):
+            assert st["iterations"][b] == s_.iterations and st["rollouts"][b] == s_.rollouts, (variant, b, st["iterations"][b], s_.iterations)
+            assert np.abs(x[b] - np.stack(s_.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s_.nominal_actions[:-1])).max() < 1e-8
+        sol.close()
