@@ -1057,3 +1057,39 @@ def test_cooperative_rollout_with_many_angles_and_nested_trig(pkg):
             assert st["iterations"][b] == s_.iterations and st["rollouts"][b] == s_.rollouts, (variant, b, st["iterations"][b], s_.iterations)
             assert np.abs(x[b] - np.stack(s_.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s_.nominal_actions[:-1])).max() < 1e-8
         sol.close()
+
+
+def test_cooperative_rollout_with_a_parameter_inside_a_trig_argument(pkg):
+    """θ_t (src/dynamics.jl:23: f(x, u, w)) inside an affine trig argument, sin(x0 + w0), per instance and timestep, on all three
+    small-model kernels against the independent restatement run live."""
+    import sympy as sp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    h, n, m, T, B = 0.1, 2, 1, 19, 3
+    f = lambda x, u, w: [x[0] + h * x[1], x[1] + h * (u[0] - sp.sin(x[0] + w[0]) + 0.2 * sp.cos(2.0 * x[0] - 0.5 * w[0]))]
+    ls = lambda x, u, w: 0.1 * (x[0] * x[0] + x[1] * x[1]) + 0.05 * u[0] * u[0]
+    lt = lambda x, u, w: 2.0 * (x[0] * x[0] + x[1] * x[1])
+    goal = lambda x, u, w: [x[0] - 0.5]
+    rng = np.random.default_rng(79)
+    x1 = 0.3 * rng.standard_normal((B, n)); ub = 0.5 * rng.standard_normal((B, T - 1, m)); th = 0.4 * rng.standard_normal((B, T, 1))
+    rdyn = R.Dynamics(f, n, m, 1)
+    rs = []
+    for b in range(B):
+        par = [th[b, t] for t in range(T)]
+        s_ = R.Solver([rdyn] * (T - 1), [R.Cost(ls, n, m, 1)] * (T - 1) + [R.Cost(lt, n, 0, 1)],
+                      [R.Constraint()] * (T - 1) + [R.Constraint(goal, n, 0, num_parameter=1)], parameters=par)
+        s_.initialize_controls(ub[b]); s_.initialize_states(R.rollout([rdyn] * (T - 1), x1[b], ub[b], par))
+        s_.solve()
+        rs.append(s_)
+    dyn = pkg.Dynamics(f, n, m, 1)
+    for variant in ("latency", "throughput", "packed"):
+        sol = pkg.Solver([dyn] * (T - 1), [pkg.Cost(ls, n, m, 1)] * (T - 1) + [pkg.Cost(lt, n, 0, 1)],
+                         [pkg.Constraint()] * (T - 1) + [pkg.Constraint(goal, n, 0, num_parameter=1)], batch=B, options=pkg.Options(verbose=0), name="thetatrig")
+        sol.set_kernel_variant_(variant)
+        sol.set_parameters_(th)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        x, u = sol.get_trajectory(); st = sol.stats()
+        for b, s_ in enumerate(rs):
+            assert st["iterations"][b] == s_.iterations and st["rollouts"][b] == s_.rollouts, (variant, b, st["iterations"][b], s_.iterations)
+            assert np.abs(x[b] - np.stack(s_.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s_.nominal_actions[:-1])).max() < 1e-8
+        sol.close()
