@@ -568,6 +568,26 @@ __device__ __forceinline__ double from_lane_plus16_even_rows(double v) {
     const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double((int)b[1], (int)a[1]);
 }
+// value of the partner row of a row PAIR (0,1), (2,3): one v_permlane16_swap per half serves odd and even rows at once
+__device__ __forceinline__ double from_partner_row(double v, bool odd_row) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(odd_row ? (int)b[0] : (int)b[1], odd_row ? (int)a[0] : (int)a[1]);
+}
+// potrs('U') for a 2x2 factor on right-hand sides held as Y(r, c), the two rows of a set on lanes 16 apart: every lane fetches
+// its partner row ONCE and runs the whole 2x2 forward / backward substitution locally — the operations of the general
+// row-by-row form below, each rounded the same (y0 = b0 r0; y1 = (b1 - u01 y0) r1; x1 = y1 r1; x0 = (y0 - u01 x1) r0),
+// in 6 fp64 instructions, 6 selects and one row exchange instead of four dependent exchange-and-select rounds.
+__device__ __forceinline__ double solve2x2_rows(double Y, bool odd_row, double u01, double r0, double r1) {
+    const double oth = from_partner_row(Y, odd_row);
+    const double b0 = odd_row ? oth : Y, b1 = odd_row ? Y : oth;
+    const double y0 = b0 * r0;
+    const double y1 = fma(-u01, y0, b1) * r1;
+    const double x1 = y1 * r1;
+    const double x0 = fma(-u01, x1, y0) * r0;
+    return (odd_row ? x1 : x0) * -1.0;                                  // K .*= -1, k .*= -1
+}
 __device__ __forceinline__ double mfma444(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
@@ -902,6 +922,7 @@ __device__ void backward_pass_split(Inst<M>& I) {
     };
     // potrs('U') of a right-hand-side set held as Y(r, c), given the factor's off-diagonal entries and inverted diagonal   (:70-75)
     auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m]) {
+        if constexpr (m == 2) return solve2x2_rows(Y, (r & 1) != 0, Uc[2], Ur[0], Ur[1]);
 #pragma unroll
         for (int i = 0; i < m; ++i) {                                   // U^T y = b
 #pragma unroll

@@ -337,6 +337,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     const int rr = (m == 2) ? (r & 1) : r;                              // row inside a right-hand-side set
     // potrs('U') of right-hand sides held as Y(r, c), rows on lanes 16 apart (m == 2: two sets, rows {0,1} and {2,3})   (:70-75)
     auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
+        if constexpr (m == 2) return solve2x2_rows(Y, (r & 1) != 0, Uc[2], Ur[0], Ur[1]);      // (ilqr_device.hpp)
         if (m == 1 && info == 0) {
             Y = Y * recip_fast(Uc[0]);                                  // see ilqr_device.hpp: 1x1 shortcut
         } else {
