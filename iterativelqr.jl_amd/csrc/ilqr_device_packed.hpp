@@ -85,6 +85,7 @@ struct PInst {
 template <class M>
 __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol, bool constrained, double& J_out, double& viol_out) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    constexpr int NCM = ncs > nct ? ncs : nct, NC = NCM > 0 ? NCM : 1;
     const Layout& L = I.L;
     const int T = L.T, N = T - 1;
     const double* X = I.g + Xo; const double* U = I.g + Uo;
@@ -92,16 +93,37 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
     const double* lamb = I.g + L.lam; const double* rho = I.g + L.rho;
     const double* W = I.g + L.w;
     double Jp = 0.0, vp = 0.0;
-    for (int t = (upd_J || upd_viol) ? I.j : T; t < T; t += 16) {
-        double w[cdim<M::NW>::v];
-        load_w<M::NW>(W, t, w);
-        double xt[n];
+    // A lane walks its timesteps t = j, j + 16, ...; every pass needs x_t, u_t, λ_t, ρ_t from HBM / L2 and nothing hides that
+    // round trip at one wave per SIMD (the pass used to cost one round trip per 16 timesteps: 9 of the 80 µs of a car cycle).
+    // The operands of the NEXT pass are requested before the current one is evaluated.
+    struct In { double x[n], u[m > 0 ? m : 1], w[cdim<M::NW>::v], lam[NC], rho[NC]; };
+    auto load = [&](In& o, int t) {
+        load_w<M::NW>(W, t, o.w);
 #pragma unroll
-        for (int i = 0; i < n; ++i) xt[i] = X[t * n + i];
+        for (int i = 0; i < n; ++i) o.x[i] = X[t * n + i];
+        if (t < N) {
+#pragma unroll
+            for (int i = 0; i < m; ++i) o.u[i] = U[t * m + i];
+        }
+        if (constrained && upd_J) {
+            const int off = t < N ? t * ncs : N * ncs, cnt = t < N ? ncs : nct;
+#pragma unroll
+            for (int i = 0; i < NCM; ++i)
+                if (i < cnt) { o.lam[i] = lamb[off + i]; o.rho[i] = rho[off + i]; }
+        }
+    };
+    const bool any = upd_J || upd_viol;
+    In cur, nxt;
+    int t = any ? I.j : T;
+    if (t < T) load(cur, t);
+    for (; t < T; t += 16) {
+        if (t + 16 < T) load(nxt, t + 16);
+        const double (&xt)[n] = cur.x;
+        const double (&w)[cdim<M::NW>::v] = cur.w;
         if (t < N) {
             double ut[m];
 #pragma unroll
-            for (int i = 0; i < m; ++i) ut[i] = U[t * m + i];
+            for (int i = 0; i < m; ++i) ut[i] = cur.u[i];
             if (upd_J) Jp += M::cost_s(xt, ut, w);
             if constexpr (ncs > 0) {
                 if (constrained) {
@@ -112,12 +134,12 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
                         double dot = 0.0, pen = 0.0;
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
-                            const double lam = lamb[off + i];
+                            const double lam = cur.lam[i];
                             const bool ineq = (M::INEQ_S >> i) & 1ull;
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
-                            if (!inactive) pen += 0.5 * rho[off + i] * (cv[i] * cv[i]);
+                            if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
                         }
                         Jp += dot;
                         Jp += pen;
@@ -143,12 +165,12 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
                         double dot = 0.0, pen = 0.0;
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {
-                            const double lam = lamb[off + i];
+                            const double lam = cur.lam[i];
                             const bool ineq = (M::INEQ_T >> i) & 1ull;
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
-                            if (!inactive) pen += 0.5 * rho[off + i] * (cv[i] * cv[i]);
+                            if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
                         }
                         Jp += dot;
                         Jp += pen;
@@ -164,6 +186,7 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
                 }
             }
         }
+        cur = nxt;
     }
     J_out = row_sum(Jp);
     viol_out = row_max(vp);
