@@ -460,6 +460,12 @@ def _table(name, rows):
     return ["    static constexpr double %s[%d][%d] = {" % (name, len(rows), len(rows[0])), body, "    };"]
 
 
+def _itable(name, vals):
+    """static constexpr int name[N] = {...};  (at least one element)"""
+    vals = list(vals) or [0]
+    return ["    static constexpr int %s[%d] = {%s};" % (name, len(vals), ", ".join(str(int(v)) for v in vals))]
+
+
 def _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu):
     """Extra members for models on the HBM-resident large path (ilqr_device_large.hpp):
 
@@ -493,7 +499,9 @@ def _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu):
     L.append("    static constexpr int JAC_NVAR = %d;   // state-dependent Jacobian entries (of %d)" % (len(var), n * n + n * m))
     L.extend(_table("JAC_CONST_FX", cfx))
     L.extend(_table("JAC_CONST_FU", cfu))
-    add("void", "dyn_jac_var_mem", sig_xu + ["double* __restrict__ fx", "double* __restrict__ fu"], dynamics, var)
+    # compact form: entry q of dyn_jac_var's output belongs at JAC_VAR_IDX[q] of the concatenation [fx (n*n) | fu (n*m)]
+    L.extend(_itable("JAC_VAR_IDX", [int(l[3:-1]) + (n * n if l.startswith("fu") else 0) for l, _ in var]))
+    add("void", "dyn_jac_var", sig_xu + [_arr("v", len(var), False)], dynamics, [("v[%d]" % q, e) for q, (_, e) in enumerate(var)])
     # --- affine split of the dynamics
     aff = [[0.0] * (n + m + 1) for _ in range(n)]
     rem = []
@@ -517,6 +525,66 @@ def _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu):
         [("r[%d]" % i, e) for i, e in enumerate(rem)], coop=True)
     L.append("#endif")
 
+
+
+def _emit_compact_hessians(L, add, add_al_c, al_terms, cost_stage, cost_term, con_stage, con_term, dynamics, n, m, ncs, nct, sig_xu, sig_x):
+    """Large path: the accumulated cost Hessians (reference quirk Q1, src/costs.jl:74) live in HBM as ONE compact row per
+    timestep holding only the structurally non-zero entries  [gxx | guu | gux]  (union of the cost Hessians and of the
+    Gauss-Newton AL terms of src/gradients.jl:54-80; terminal cost / constraint entries are part of the gxx set). The gxx
+    entries are sorted by the 16x16 MFMA tile they fall in (HESS_XX_TILE_START), so that the wave that owns a tile of Qxx adds
+    exactly its own entries. HESS_IDX[q] is the column-major index inside the entry's matrix."""
+    import re
+    TN = (n + 15) // 16
+    outs_s = [("gxx[%d]" % (j * n + i), cost_stage.hessian_state_state[i][j]) for j in range(n) for i in range(n)]
+    outs_s += [("guu[%d]" % (j * m + i), cost_stage.hessian_action_action[i][j]) for j in range(m) for i in range(m)]
+    outs_s += [("gux[%d]" % (j * m + i), cost_stage.hessian_action_state[i][j]) for j in range(n) for i in range(m)]
+    outs_s = [(l, e, "+=") for l, e in outs_s if sp.sympify(e) != 0]
+    outs_t = [("gxx[%d]" % (j * n + i), cost_term.hessian_state_state[i][j]) for j in range(n) for i in range(n)]
+    outs_t = [(l, e, "+=") for l, e in outs_t if sp.sympify(e) != 0]
+    al_s_o, al_s_unp = al_terms(con_stage, ncs, True) if ncs else ([], [])
+    al_t_o, al_t_unp = al_terms(con_term, nct, False) if nct else ([], [])
+    sets = {"gxx": set(), "guu": set(), "gux": set()}
+    for l, _, _ in outs_s + outs_t + al_s_o + al_t_o:
+        k_, idx = l[:3], l[4:-1]
+        if k_ in sets:
+            sets[k_].add(int(idx))
+
+    def tile_of(idx):
+        col, row = divmod(idx, n)
+        return (row // 16) * TN + (col // 16)
+
+    xx = sorted(sets["gxx"], key=lambda e: (tile_of(e), e))
+    uu, ux = sorted(sets["guu"]), sorted(sets["gux"])
+    starts = [0] * (TN * TN + 1)
+    for e in xx:
+        starts[tile_of(e) + 1] += 1
+    for q in range(TN * TN):
+        starts[q + 1] += starts[q]
+    pos = {("gxx", e): q for q, e in enumerate(xx)}
+    pos.update({("guu", e): len(xx) + q for q, e in enumerate(uu)})
+    pos.update({("gux", e): len(xx) + len(uu) + q for q, e in enumerate(ux)})
+    L.append("    // compact structural Hessian row: [gxx (tile-sorted) | guu | gux]")
+    L.append("    static constexpr int HESS_NXX = %d, HESS_NUU = %d, HESS_NUX = %d;" % (len(xx), len(uu), len(ux)))
+    L.extend(_itable("HESS_IDX", xx + uu + ux))
+    L.extend(_itable("HESS_XX_TILE_START", starts))
+
+    def compact(outs_):
+        res = []
+        for o in outs_:
+            l = o[0]
+            k_ = l[:3]
+            if k_ in sets:
+                res.append(("hs[%d]" % pos[(k_, int(l[4:-1]))],) + tuple(o[1:]))
+            else:
+                res.append(o)
+        return res
+
+    add("void", "cost_s_hess_c", sig_xu + ["double* __restrict__ hs"], cost_stage, compact(outs_s))
+    add("void", "cost_t_hess_c", sig_x + ["double* __restrict__ hs"], cost_term, compact(outs_t), with_u=False)
+    add_al_c("al_s_c", sig_xu + [_arr("ct", ncs), _arr("ir", ncs), _arr("gx", n, False), _arr("gu", m, False), "double* __restrict__ hs"],
+             con_stage if ncs else dynamics, compact(al_s_o), al_s_unp, True)
+    add_al_c("al_t_c", sig_x + [_arr("ct", nct), _arr("ir", nct), _arr("gx", n, False), "double* __restrict__ hs"],
+             con_term if nct else dynamics, compact(al_t_o), al_t_unp, False)
 
 
 def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None, con_term=None):
@@ -650,15 +718,17 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     def nz(pairs):
         return [(l, e, "+=") for l, e in pairs if sp.sympify(e) != 0]
 
-    outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
-    outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
-    add("void", "dyn_jac_mem", sig_xu + ["double* __restrict__ fx", "double* __restrict__ fu"], dynamics, outs)
-    outs = nz([("gxx[%d]" % (j * n + i), cost_stage.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
-    outs += nz([("guu[%d]" % (j * m + i), cost_stage.hessian_action_action[i][j]) for j in range(m) for i in range(m)])
-    outs += nz([("gux[%d]" % (j * m + i), cost_stage.hessian_action_state[i][j]) for j in range(n) for i in range(m)])
-    add("void", "cost_s_hess_acc", sig_xu + ["double* __restrict__ gxx", "double* __restrict__ guu", "double* __restrict__ gux"], cost_stage, outs)
-    outs = nz([("gxx[%d]" % (j * n + i), cost_term.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
-    add("void", "cost_t_hess_acc", sig_x + ["double* __restrict__ gxx"], cost_term, outs, with_u=False)
+    large = n > 4 or m > 4
+    if not large:
+        outs = [("fx[%d]" % (j * n + i), dynamics.jacobian_state[i][j]) for j in range(n) for i in range(n)]
+        outs += [("fu[%d]" % (j * n + i), dynamics.jacobian_action[i][j]) for j in range(m) for i in range(n)]
+        add("void", "dyn_jac_mem", sig_xu + ["double* __restrict__ fx", "double* __restrict__ fu"], dynamics, outs)
+        outs = nz([("gxx[%d]" % (j * n + i), cost_stage.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
+        outs += nz([("guu[%d]" % (j * m + i), cost_stage.hessian_action_action[i][j]) for j in range(m) for i in range(m)])
+        outs += nz([("gux[%d]" % (j * m + i), cost_stage.hessian_action_state[i][j]) for j in range(n) for i in range(m)])
+        add("void", "cost_s_hess_acc", sig_xu + ["double* __restrict__ gxx", "double* __restrict__ guu", "double* __restrict__ gux"], cost_stage, outs)
+        outs = nz([("gxx[%d]" % (j * n + i), cost_term.hessian_state_state[i][j]) for j in range(n) for i in range(n)])
+        add("void", "cost_t_hess_acc", sig_x + ["double* __restrict__ gxx"], cost_term, outs, with_u=False)
 
     def al_terms(con, nc, stage):
         ct = [sp.Symbol("ct%d" % i, real=True) for i in range(nc)]     # λ + Iρ c
@@ -691,13 +761,23 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         un = _prune_unpack(unpack_xu(obj, with_u) + unp, body)
         L.extend(_fn("void", fname, sig, un + body))
 
-    if n > 4 or m > 4:
-        _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu)
+    def add_al_c(fname, sig, obj, outs_, unp, with_u):
+        """AL Gauss-Newton terms with the Hessian part in compact structural form (outs_ already renamed)."""
+        if not outs_:
+            L.extend(_fn("void", fname, sig, []))
+            return
+        body = _emit_block(outs_, "t")
+        un = _prune_unpack(unpack_xu(obj, with_u) + unp, body)
+        L.extend(_fn("void", fname, sig, un + body))
 
-    add_al("al_s", sig_xu + [_arr("ct", ncs), _arr("ir", ncs), _arr("gx", n, False), _arr("gu", m, False),
-                             "double* __restrict__ gxx", "double* __restrict__ guu", "double* __restrict__ gux"], con_stage if ncs else dynamics, con_stage, ncs, True, True)
-    add_al("al_t", sig_x + [_arr("ct", nct), _arr("ir", nct), _arr("gx", n, False), "double* __restrict__ gxx"],
-           con_term if nct else dynamics, con_term, nct, False, False)
+    if large:
+        _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu)
+        _emit_compact_hessians(L, add, add_al_c, al_terms, cost_stage, cost_term, con_stage, con_term, dynamics, n, m, ncs, nct, sig_xu, sig_x)
+    else:
+        add_al("al_s", sig_xu + [_arr("ct", ncs), _arr("ir", ncs), _arr("gx", n, False), _arr("gu", m, False),
+                                 "double* __restrict__ gxx", "double* __restrict__ guu", "double* __restrict__ gux"], con_stage if ncs else dynamics, con_stage, ncs, True, True)
+        add_al("al_t", sig_x + [_arr("ct", nct), _arr("ir", nct), _arr("gx", n, False), "double* __restrict__ gxx"],
+               con_term if nct else dynamics, con_term, nct, False, False)
     L.append("};")
     src = "\n".join(L) + "\n"
     # the cooperative rollout code is generic over HOW a value travels from one lane of the cooperating group to all of

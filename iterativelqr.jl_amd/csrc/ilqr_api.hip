@@ -85,10 +85,10 @@ struct ilqr_handle {
     int num_simds;
     double* qv;           // optional action-value buffers Qx, Qu, Qxx, Quu, Qux (allocated on first use by a getter)
     ilqr::QLayout QL;
-    // lazy part of ilqr_reset for large (HBM-resident) models: the megabyte-sized per-instance arrays are zeroed only
-    // when something could observe them before the solve kernel rewrites them
-    bool jh_dirty;        // fx, fu, gxx, guu, gux hold pre-reset values (ilqr_solve zeroes / overwrites them itself)
-    bool P_dirty;         // P, p hold pre-reset values (only the backward-pass STAGE kernel writes them)
+    // large (HBM-resident) models: the kernels stream a COMPACT form of the Jacobians and Hessians (Layout::fv, ::hc, see
+    // ilqr_device_large.hpp); the reference's full jacobian_* / hessian_* arrays are a mirror written on demand
+    bool full_stale;      // the full fx, fu, gxx, guu, gux arrays do not reflect the compact form (a getter materialises them first)
+    bool P_dirty;         // P, p hold pre-reset values (only the backward-pass STAGE kernel writes them): zeroed lazily
     std::vector<BufferDesc> buffers;
     std::vector<BufferDesc> qbuffers;
 };
@@ -134,20 +134,26 @@ const BufferDesc* find_qbuffer(const ilqr_handle* h, const char* name) {
     return nullptr;
 }
 
-// the deferred part of ilqr_reset (see ilqr_handle::jh_dirty / P_dirty)
+// the deferred parts of ilqr_reset / of a solve on a large model (see ilqr_handle::full_stale / P_dirty)
 int settle_reset(ilqr_handle* h) {
-    if (!h->jh_dirty && !h->P_dirty) return ILQR_OK;
     const ilqr::Layout& L = h->L;
     const size_t pitch = (size_t)L.stride * 8;
-    if (h->jh_dirty) {
-        HIP_TRY(hipMemset2DAsync((char*)h->ws + (size_t)L.fx * 8, pitch, 0, (size_t)(L.P - L.fx) * 8, (size_t)h->B, h->stream));
-        h->jh_dirty = false;                 // (S_JAC_CONST was cleared with the scalars by ilqr_reset)
-    }
     if (h->P_dirty) {
         HIP_TRY(hipMemset2DAsync((char*)h->ws + (size_t)L.P * 8, pitch, 0, (size_t)(L.scal - L.P) * 8, (size_t)h->B, h->stream));
         h->P_dirty = false;
     }
     return ILQR_OK;
+}
+// full jacobian_* / hessian_* arrays <- compact form (dir 0) or the reverse (dir 1)
+int mirror(ilqr_handle* h, int dir) {
+    if (!h->vt->launch_mirror) return ILQR_OK;
+    ilqr::KArgs a = make_args(h);
+    if (h->vt->launch_mirror(&a, dir, h->stream) != 0) return fail(ILQR_ERR_HIP, "mirror kernel launch failed");
+    if (dir == 0) h->full_stale = false;
+    return ILQR_OK;
+}
+bool is_mirrored(const ilqr_handle* h, const BufferDesc* bd) {
+    return h->vt->launch_mirror != nullptr && bd->offset >= h->L.fx && bd->offset < h->L.P && bd->offset != h->L.ring;
 }
 
 const BufferDesc* find_buffer(const ilqr_handle* h, const char* name) {
@@ -159,7 +165,8 @@ const BufferDesc* find_buffer(const ilqr_handle* h, const char* name) {
 int copy_out(ilqr_handle* h, const BufferDesc* bd, double* out) {
     if (bd->len == 0) return ILQR_OK;
     HIP_TRY(hipSetDevice(h->device));
-    if (bd->offset >= h->L.fx && bd->offset < h->L.scal) { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
+    if (bd->offset >= h->L.P && bd->offset < h->L.scal) { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
+    if (is_mirrored(h, bd) && h->full_stale) { const int rc = mirror(h, 0); if (rc != ILQR_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy2D(out, (size_t)bd->len * 8, h->ws + bd->offset, (size_t)h->L.stride * 8,
                         (size_t)bd->len * 8, (size_t)h->B, hipMemcpyDeviceToHost));
@@ -169,7 +176,9 @@ int copy_out(ilqr_handle* h, const BufferDesc* bd, double* out) {
 int copy_in(ilqr_handle* h, const BufferDesc* bd, const double* in) {
     if (bd->len == 0) return ILQR_OK;
     HIP_TRY(hipSetDevice(h->device));
-    if (bd->offset >= h->L.fx && bd->offset < h->L.scal) { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
+    if (bd->offset >= h->L.P && bd->offset < h->L.scal) { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
+    const bool mirrored = is_mirrored(h, bd);
+    if (mirrored && h->full_stale) { const int rc = mirror(h, 0); if (rc != ILQR_OK) return rc; }     // the OTHER full arrays must be current before the gather below
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy2D(h->ws + bd->offset, (size_t)h->L.stride * 8, in, (size_t)bd->len * 8,
                         (size_t)bd->len * 8, (size_t)h->B, hipMemcpyHostToDevice));
@@ -177,6 +186,14 @@ int copy_in(ilqr_handle* h, const BufferDesc* bd, const double* in) {
     std::vector<double> zeros(h->B, 0.0);
     HIP_TRY(hipMemcpy2D(h->ws + h->L.scal + ilqr::S_STATES_EQ_NOMINAL, (size_t)h->L.stride * 8, zeros.data(), 8, 8,
                         (size_t)h->B, hipMemcpyHostToDevice));
+    if (mirrored) {
+        if (bd->offset == h->L.fx || bd->offset == h->L.fu) {       // host-written Jacobians count as evaluated
+            std::vector<double> ones(h->B, 1.0);
+            HIP_TRY(hipMemcpy2D(h->ws + h->L.scal + ilqr::S_JAC_VALID, (size_t)h->L.stride * 8, ones.data(), 8, 8, (size_t)h->B, hipMemcpyHostToDevice));
+        }
+        const int rc = mirror(h, 1);
+        if (rc != ILQR_OK) return rc;
+    }
     return ILQR_OK;
 }
 
@@ -330,12 +347,12 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     if (d->device < 0 || d->device >= ndev) return fail(ILQR_ERR_INVALID, "device ordinal out of range");
     ilqr_handle* h = new ilqr_handle();
     h->vt = vt; h->B = d->batch; h->device = d->device; h->constrained = d->constrained ? 1 : 0;
-    h->L = ilqr::make_layout(vt->nx, vt->nu, vt->nw, vt->ncs, vt->nct, d->horizon);
+    h->L = ilqr::make_layout(vt->nx, vt->nu, vt->nw, vt->ncs, vt->nct, d->horizon, vt->jac_nvar, vt->hess_nnz);
     h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu) * 8
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
     h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024;
-    h->qv = nullptr; h->QL = ilqr::make_qlayout(vt->nx, vt->nu, d->horizon); h->jh_dirty = false; h->P_dirty = false;
+    h->qv = nullptr; h->QL = ilqr::make_qlayout(vt->nx, vt->nu, d->horizon); h->full_stale = false; h->P_dirty = false;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
     h->lds_fits = h->lds_bytes <= 160 * 1024;
@@ -405,16 +422,17 @@ int ilqr_reset(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     if (ilqr::is_large_model(h->vt->nx, h->vt->nu) && h->vt->nw == 0) {
-        // HBM-resident models: zero the trajectories, gradients, gains, duals and scalars now; the megabyte-sized
-        // Jacobian / Hessian / value arrays are zeroed by the solve kernel itself (src/solve.jl:9-10) or, when
-        // a getter, setter or stage call could observe them first, by settle_reset()
+        // HBM-resident models: zero the trajectories, gradients, gains, duals, scalars and the compact Jacobian / Hessian rows
+        // now; the megabyte-sized full Jacobian / Hessian mirrors are rewritten from the compact form when a getter asks
+        // for them, the value arrays P, p are zeroed when a getter, setter or stage call could observe them
         const size_t pitch = (size_t)h->L.stride * 8;
         HIP_TRY(hipMemset2DAsync(h->ws, pitch, 0, (size_t)h->L.fx * 8, (size_t)h->B, h->stream));
         HIP_TRY(hipMemset2DAsync((char*)h->ws + (size_t)h->L.scal * 8, pitch, 0, pitch - (size_t)h->L.scal * 8, (size_t)h->B, h->stream));
-        h->jh_dirty = true; h->P_dirty = true;
+        h->full_stale = true; h->P_dirty = true;
     } else if (h->vt->nw == 0) {
         HIP_TRY(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
     } else {
+        h->full_stale = ilqr::is_large_model(h->vt->nx, h->vt->nu);
         // keep the parameters θ (they belong to the problem, not to the solver state)
         const size_t pitch = (size_t)h->L.stride * 8, w0 = (size_t)h->L.w * 8, w1 = (size_t)h->L.zslot * 8;
         HIP_TRY(hipMemset2DAsync(h->ws, pitch, 0, w0, (size_t)h->B, h->stream));
@@ -471,7 +489,7 @@ int ilqr_solve(ilqr_handle* h) {
     a.qv = nullptr;
     if (h->trace)      // rows of an earlier, longer solve must not survive
         HIP_TRY(hipMemsetAsync(h->trace, 0, (size_t)h->B * h->trace_cap * ilqr::TRACE_W * 8, h->stream));
-    h->jh_dirty = false;   // the kernel rewrites the Jacobians and zeroes the Hessians itself (src/solve.jl:9-16)
+    if (h->vt->launch_mirror) h->full_stale = true;   // the kernel works on the compact Jacobian / Hessian rows
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto drop = [&](int rc) { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); return rc; };
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, h->stream) != hipSuccess)
@@ -516,6 +534,7 @@ int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t fl
         if (h->vt->launch_stage_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
             return fail(ILQR_ERR_HIP, "stage (throughput variant) launch failed");
     } else if (h->vt->launch_stage(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "stage launch failed");
+    if (h->vt->launch_mirror) h->full_stale = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return ILQR_OK;
 }
@@ -611,10 +630,6 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
     if (!h || !name || !in) return fail(ILQR_ERR_INVALID, "null argument");
     const BufferDesc* bd = find_buffer(h, name);
     if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
-    if (!std::strncmp(name, "jacobian_", 9)) {     // host-written Jacobians: their constant entries are no longer known to be in place
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipMemset2DAsync(h->ws + h->L.scal + ilqr::S_JAC_CONST, (size_t)h->L.stride * 8, 0, 8, (size_t)h->B, h->stream));
-    }
     return copy_in(h, bd, in);
 }
 

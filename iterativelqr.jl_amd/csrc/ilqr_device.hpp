@@ -96,7 +96,7 @@ template <class M> struct slim_of<M, decltype((void)M::SLIM)> { static constexpr
 // sensitivity sweep while wave 0 runs the first rollout; the small-model Riccati recursion stays on wave 0 (a
 // 1 k-cycle step cannot pay for a barrier), the large-model one splits its MFMA tiles. Scalars produced by one
 // wave are handed to the other through LDS.
-template <class M> struct waves_of { static constexpr int value = slim_of<M>::value ? 1 : 2; };
+template <class M> struct waves_of { static constexpr int value = is_large<M>::value ? LARGE_WAVES : (slim_of<M>::value ? 1 : 2); };
 
 // parameters of timestep t (empty when NW == 0)
 template <int NW>
@@ -144,6 +144,7 @@ struct Inst {
     const double* w;       // parameters θ_t (problem.parameters, src/data/problem.jl:25-30), T x NW
     double *gxx, *guu, *gux, *P, *p, *scal;
     double *gbase;         // HBM: this instance's workspace block
+    int fv_off, hc_off;    // large path: offsets of the compact Jacobian / Hessian rows inside the block
     double *zs;            // LDS: zs[0] == 0.0 always, zs[1] is a write-only trash slot
     double *ring;          // LDS: Riccati hand-over ring between the two waves (small path)
     double *lds;           // large path: LDS staging area (the workspace itself stays in HBM)
@@ -165,6 +166,8 @@ struct Inst {
 
 // large-model path (ilqr_device_large.hpp)
 template <class M> __device__ void gradients_large(Inst<M>& I, bool constrained);
+template <class M> __device__ void cost_pass_large(Inst<M>& I, bool at_states, bool upd_J, bool upd_viol, bool constrained, double& J_out, double& viol_out);
+template <class M> __device__ void reset_model_objective_large(Inst<M>& I, bool literal);
 template <class M, bool STORE_VALUE> __device__ void backward_pass_large(Inst<M>& I);
 template <class M> __device__ void rollout_large(Inst<M>& I, double alpha, bool want_delta, double& delta_out);
 
@@ -270,7 +273,8 @@ __device__ void cost_bang(Inst<M>& I, bool mode_current, bool constrained) {
         const bool upd_J = pass == 0;
         const bool upd_viol = one_pass || pass == 1;
         double J, v;
-        cost_pass<M>(I, at_states ? I.x : I.xb, at_states ? I.u : I.ub, upd_J, upd_viol, constrained, J, v);
+        if constexpr (is_large<M>::value) cost_pass_large<M>(I, at_states, upd_J, upd_viol, constrained, J, v);
+        else cost_pass<M>(I, at_states ? I.x : I.xb, at_states ? I.u : I.ub, upd_J, upd_viol, constrained, J, v);
         if (upd_J) I.objective = J;
         if (upd_viol && constrained) I.max_violation = v;
     }
@@ -1368,8 +1372,10 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
         const double J = I.objective;
         if (J <= J_prev + c1 * I.step_size * delta) {                 // (:44) NaN ⇒ reject
             // update_nominal_trajectory! (src/data/methods.jl:32-39)
-            for (int i = I.lane; i < I.T * n; i += 64) I.xb[i] = I.x[i];
-            for (int i = I.lane; i < I.N * m; i += 64) I.ub[i] = I.u[i];
+            constexpr int CS = is_large<M>::value ? 64 * waves_of<M>::value : 64;     // large path: HBM arrays, each element once
+            const int c0 = is_large<M>::value ? (int)threadIdx.x : I.lane;
+            for (int i = c0; i < I.T * n; i += CS) I.xb[i] = I.x[i];
+            for (int i = c0; i < I.N * m; i += CS) I.ub[i] = I.u[i];
             I.states_eq_nominal = 1;
             I.status = 1;
             __syncthreads();
@@ -1385,14 +1391,12 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
 template <class M>
 __device__ void reset_model_objective(Inst<M>& I, bool literal = true) {
     constexpr int n = M::NX, m = M::NU;
-    // Inside the fused solve the Jacobians are overwritten (`.=`) by the gradients! call that follows at once
-    // (src/solve.jl:9-16), so zeroing them is unobservable; on the HBM-resident large path it would cost a
-    // megabyte of writes per instance and throw away the constant entries already in place (S_JAC_CONST).
-    if (literal || !is_large<M>::value) {
-        for (int i = I.lane; i < I.N * n * n; i += 64) I.fx[i] = 0.0;
-        for (int i = I.lane; i < I.N * n * m; i += 64) I.fu[i] = 0.0;
-        if (is_large<M>::value && I.lane == 0) I.scal[S_JAC_CONST] = 0.0;
+    if constexpr (is_large<M>::value) {       // compact representation, work split over the four waves
+        reset_model_objective_large<M>(I, literal);
+        return;
     }
+    for (int i = I.lane; i < I.N * n * n; i += 64) I.fx[i] = 0.0;
+    for (int i = I.lane; i < I.N * n * m; i += 64) I.fu[i] = 0.0;
     for (int i = I.lane; i < I.T * n; i += 64) I.gx[i] = 0.0;
     for (int i = I.lane; i < I.N * m; i += 64) I.gu[i] = 0.0;
     for (int i = I.lane; i < I.T * n * n; i += 64) I.gxx[i] = 0.0;
@@ -1486,7 +1490,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w; I.ring = smem + L.ring;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x & 63; I.wave = threadIdx.x >> 6;
-    I.lds = smem; I.gbase = g;
+    I.lds = smem; I.gbase = g; I.fv_off = 0; I.hc_off = 0;
     I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;
     I.Q = a.qv ? a.qv + (size_t)b * (size_t)a.QL.stride : nullptr; I.QL = a.QL;
@@ -1498,6 +1502,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
         I.K = g + L.K; I.k = g + L.k; I.Lx = g + L.Lx; I.Lu = g + L.Lu;
         I.c = g + L.c; I.lam = g + L.lam; I.rho = g + L.rho; I.act = g + L.act;
         I.zs = g + L.zslot; I.w = g + L.w;
+        I.fv_off = L.fv; I.hc_off = L.hc;
         if (threadIdx.x == 0) store_layout_lds<M>(L);     // read back by the phase functions (real calls) instead of twenty stack arguments
     } else {
         // LDS-resident set: one coalesced 16-B-per-lane stream from HBM
@@ -1546,7 +1551,7 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
 
 // solve!(solver) for every instance — src/solve.jl:137-143
 template <class M>
-__global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2) void solve_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -1580,7 +1585,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_slim(KArgs a) {
 // single stages for parity tests (STORE_VALUE: P, p and, when enabled, Qx..Qux are written to HBM); instantiated for
 // the latency mapping (M) and, for small models, the throughput mapping (Slim<M>)
 template <class M>
-__global__ __launch_bounds__(64 * waves_of<M>::value, is_large<M>::value ? 1 : 2) void stage_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * waves_of<M>::value, 2) void stage_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -1767,7 +1772,7 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 4   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+#define ILQR_MODEL_ABI_VERSION 5   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against
@@ -1780,6 +1785,10 @@ extern "C" struct ilqr_model_vtable {
     int (*launch_solve_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
     int (*launch_stage_slim)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);   // null for large models
     int (*launch_solve_packed)(const ilqr::KArgs* a, void* stream);                   // four instances per wave, no LDS; null for large models
+    // large models only (null otherwise): the compact representation the kernels stream — row lengths for make_layout and
+    // the kernel that writes the host-visible full arrays from it (dir 0) or reads them back (dir 1)
+    int jac_nvar, hess_nnz;
+    int (*launch_mirror)(const ilqr::KArgs* a, int dir, void* stream);
 };
 
 namespace ilqr {
@@ -1836,13 +1845,24 @@ struct ModelModule {
         else hipLaunchKernelGGL(init_rollout_kernel<M>, dim3((a->B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
+    static int launch_mirror(const KArgs* a, int dir, void* stream) {
+        if constexpr (is_large<M>::value) {
+            hipLaunchKernelGGL(mirror_large_kernel<M>, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a, dir);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        } else {
+            return -1;
+        }
+    }
+    template <class MM = M> static constexpr int jac_nvar() { if constexpr (is_large<MM>::value) return MM::JAC_NVAR; else return 0; }
+    template <class MM = M> static constexpr int hess_nnz() { if constexpr (is_large<MM>::value) return MM::HESS_NXX + MM::HESS_NUU + MM::HESS_NUX; else return 0; }
     static const ilqr_model_vtable* vtable() {
         static const ilqr_model_vtable vt = {ILQR_MODEL_ABI_VERSION, (int)sizeof(KArgs),
                                              M::NAME, M::NX, M::NU, M::NW, M::NCS, M::NCT, M::INEQ_S, M::INEQ_T,
                                              &launch_solve, &launch_stage, &launch_init,
                                              is_large<M>::value ? nullptr : &launch_solve_slim,
                                              is_large<M>::value ? nullptr : &launch_stage_slim,
-                                             packed_ok<M>::value ? &launch_solve_packed : nullptr};
+                                             packed_ok<M>::value ? &launch_solve_packed : nullptr,
+                                             jac_nvar(), hess_nnz(), is_large<M>::value ? &launch_mirror : nullptr};
         return &vt;
     }
 };

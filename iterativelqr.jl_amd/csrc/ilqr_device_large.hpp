@@ -1,24 +1,26 @@
 // Large-model path (nx > 4 or nu > 4, up to nx = 64 — one state component per lane — and nu = 16), e.g. BASELINE config "synth32".
 //
-// Differences from the LDS-resident small-model path of ilqr_device.hpp:
-//   * the per-instance workspace (2.4 MB for nx=32, nu=8, T=101) stays in HBM; the wave streams the
-//     per-timestep matrices through LDS staging buffers, fetching the next step's operands into registers
-//     while the current step computes;
-//   * every phase is a real (noinline) function with its own register allocation, taking typed global
-//     pointers; inside the fused solve kernel the dense model code otherwise pushes the Riccati loop into
-//     hundreds of spills whose scratch reloads wait for the HBM prefetch;
-//   * linearisation: the Jacobian entries that are constants (generated tables M::JAC_CONST_*) are written by
-//     coalesced wave-wide stores, only the state-dependent ones are evaluated per timestep
-//     (M::dyn_jac_var_mem); Hessians accumulate only their structurally non-zero entries
-//     (M::cost_*_hess_acc); the Gauss-Newton AL terms are derived symbolically (M::al_s / M::al_t);
-//   * the Riccati step's contractions fx^T P' fx, fu^T P' fx, ... are real matrix products here and run as
-//     register-blocked 16x16x4 fp64 MFMA tiles (v_mfma_f64_16x16x4_f64) out of zero-padded LDS operands
-//     (A[i][k]: i = lane&15, k = lane>>4; B[k][j]: k = lane>>4, j = lane&15;
-//      C/D[i][j]: j = lane&15, i = (lane>>4) + 4*reg  — cdna_hip_programming.md §3);
-//   * Cholesky of Quu runs on wave-uniform registers (dpotf2 order), the triangular solves one column per lane
-//     with the inverted diagonal;
-//   * rollout: one state component per lane — row i of the affine part of the dynamics (generated table
-//     M::DYN_AFF) on lane i, the nonlinear remainder in wave-cooperative form (M::dyn_rem_wave).
+// One problem instance per workgroup of FOUR waves (two instances per CU: two waves per SIMD, 256 VGPRs each). The per-instance
+// workspace stays in HBM; what the solve streams per timestep is COMPACT:
+//   * Jacobians: entries that do not depend on (x, u, θ) — 1248 of 1280 for synth32 — never touch HBM: the generated tables
+//     M::JAC_CONST_* are put into LDS once per Riccati pass and stay there; only the M::JAC_NVAR state-dependent entries are
+//     evaluated (M::dyn_jac_var), stored per timestep (Layout::fv) and patched into the LDS copy step by step;
+//   * accumulated cost Hessians (reference quirk Q1): one row per timestep with the structurally non-zero entries only
+//     (Layout::hc, order M::HESS_IDX: [gxx sorted by 16x16 tile | guu | gux]); the Riccati step adds them to Qxx, Quu, Qux
+//     where they fall — bitwise what adding the dense arrays gives, zeros contribute nothing;
+//   * the full jacobian_* / hessian_* arrays of the reference are a host-visible mirror, written on demand by
+//     materialise_large_kernel and read back into the compact form by gather_large_kernel after a host write.
+// Riccati step (src/backward_pass.jl:42-90): 132 v_mfma_f64_16x16x4_f64 tiles for n = 32, m = 8 around the serial
+// potrf / potrs chain, scheduled over the four waves in four windows (one workgroup barrier each):
+//     A   waves 0,1: ûx = fuᵀP′ (the tiles the chain waits for)          waves 2,3: first half of T = fxᵀP′
+//     B   waves 0,1: Qux = ûx fx, Quu = ûx fu; wave 1: Qu = fuᵀp′ + gu   waves 2,3: rest of T
+//     C   wave 0: + guu, gux; potrf; potrs → K, k (the serial chain)      waves 1-3: Qx = fxᵀp′ + gx; Qxx = T fx + gxx (registers)
+//     D   wave 0: ûxt = Quu K; p, ∇L                                      waves 1-3: P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx; all: patch fx, fu
+// Every tile is one generic call (tile_mm) with run-time tile coordinates; operand fragments are read from zero-padded LDS
+// matrices with odd leading dimensions (transposition = stride pattern, no bounds checks), the MFMAs of a tile issue back to back.
+// Forward sweep: wave 0 runs the closed-loop rollout (K x as four partial sums per action on the 64 lanes, the affine part of
+// row i of the dynamics on lane i, generated wave-cooperative remainder), wave 1 the sensitivity recursion Δz with ∇Lᵀ·Δz,
+// waves 2,3 stage K_t into an LDS ring a chunk ahead; a_t = α k_t + ū_t and b_t = K_t x̄_t are formed beforehand time-parallel.
 // Same reference semantics and citations as ilqr_device.hpp.
 #pragma once
 
@@ -29,76 +31,54 @@ constexpr int r4(int v) { return (v + 3) & ~3; }
 
 template <class M>
 struct LargeDims {
-    static constexpr int n = M::NX, m = M::NU;
+    static constexpr int n = M::NX, m = M::NU, W = LARGE_WAVES, NT = 64 * LARGE_WAVES;
     static constexpr int NP = r16(n), MP = r16(m);          // whole 16x16 tiles; the padding is kept at zero
+    static constexpr int TN = NP / 16;
     static constexpr int ld = NP + 1, ldm = MP + 1;         // odd leading dimensions: conflict-free LDS column walks
+    static constexpr int n4 = r4(n), m4 = r4(m);
+    static constexpr int JV = M::JAC_NVAR, JVP = pad2(JV > 0 ? JV : 1);
+    static constexpr int HXX = M::HESS_NXX, HUU = M::HESS_NUU, HUX = M::HESS_NUX, HS = HXX + HUU + HUX, HSP = pad2(HS > 0 ? HS : 1);
     // LDS carve (doubles); must match large_lds_doubles() of ilqr_layout.hpp
-    static constexpr int oP = 0, oFx = oP + NP * ld, oT = oFx + NP * ld, oFu = oT + NP * ld, oUh = oFu + MP * ld,
+    static constexpr int oFx = 0, oFu = oFx + NP * ld, oP = oFu + MP * ld, oT = oP + NP * ld, oUh = oT + NP * ld,
                          oQux = oUh + NP * ldm, oK = oQux + NP * ldm, oUxt = oK + NP * ldm, oQuu = oUxt + NP * ldm,
-                         oVec = oQuu + MP * ldm, oLay = oVec + 4 * NP + 4 * MP + 8, total = oLay + LAYOUT_LDS_DOUBLES;
+                         oBnc = oQuu + MP * ldm, oVec = oBnc + LARGE_BOUNCE, oLay = oVec + 2 * NP + 2 * MP + 8,
+                         total = oLay + LAYOUT_LDS_DOUBLES;
+    // forward sweep: fx, fu keep their place (sensitivity recursion); behind them the sweep's vectors and the K ring
+    static constexpr int oFw = oP, oRing = oFw + 2 * NP + 2 * MP, ringDoubles = oLay - oRing;
+    static constexpr int CH = ringDoubles / (2 * m * n) < 32 ? ringDoubles / (2 * m * n) : 32;     // timesteps per ring half
+    static_assert(CH >= 1, "LDS ring of the forward sweep holds at least one timestep of K per half");
 };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// D-layout of the tile: element r of lane (li, lk) is (row I0 + lk + 4r, column J0 + li)
+// D-layout of a tile: element r of lane (li, lk) is (row I0 + lk + 4r, column J0 + li)
 template <int LDD>
 __device__ __forceinline__ void tile_store(double* D, double4_t acc, int I0, int J0, int li, int lk) {
+    double* p = D + (J0 + li) * LDD + I0 + lk;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) D[(J0 + li) * LDD + I0 + lk + 4 * r] = acc[r];
-}
-// the same elements of a packed column-major global matrix (R x Cc), zero outside
-template <int R, int Cc, class Ptr>
-__device__ __forceinline__ double4_t tile_load_global(Ptr G, int I0, int J0, int li, int lk) {
-    double4_t v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = I0 + lk + 4 * r, col = J0 + li;
-        if constexpr (R % 16 == 0 && Cc % 16 == 0) v[r] = G[col * R + row];
-        else {                                      // clamped address + select: no exec-mask branch
-            const bool in = row < R && col < Cc;
-            const double x = G[in ? col * R + row : 0];
-            v[r] = in ? x : 0.0;
-        }
-    }
-    return v;
+    for (int r = 0; r < 4; ++r) p[4 * r] = acc[r];
 }
 
-// Register-blocked product of TR x TC output tiles on v_mfma_f64_16x16x4_f64: acc(a,c) += sum_{k<KD} A_a(i,k) B(k,j)
-// with A(i,k) at A[AI*i + AK*k] and B(k,j) at B[BK*k + BJ*j] (any transposition is just a stride pattern; strides
-// and KD are compile-time, operands zero-padded: no bounds checks). All operand fragments are read from LDS FIRST (TR*KD/4 + TC*KD/4
-// doubles per lane), then the MFMAs issue back to back, k-step outermost so that consecutive instructions hit
-// different accumulators. Row tile a takes its A operand from Aop[a] (so two matrices can share one B pass).
-template <int TR, int TC, int KD, int AI, int AK, int BK, int BJ>
-__device__ __forceinline__ void tiles_mac(double4_t (&acc)[TR * TC], const double* const (&Aop)[TR], const int (&Arow)[TR],
-                                          const double* B, int li, int lk, int c0 = 0) {
+// One 16x16 output tile on v_mfma_f64_16x16x4_f64: acc += sum_{k<KD} A(i,k) B(k,j), A(i,k) at Ab[AI*i + AK*k], B(k,j) at
+// Bb[BK*k + BJ*j] (i, j < 16: the caller offsets Ab / Bb to the tile; KD and the strides are compile-time; operands are
+// zero-padded, so there are no bounds checks). All fragments are read first, then the MFMAs issue back to back.
+// A[i][k]: i = lane&15, k = lane>>4; B[k][j]: k = lane>>4, j = lane&15; C/D[i][j]: j = lane&15, i = (lane>>4) + 4*reg.
+template <int KD, int AI, int AK, int BK, int BJ>
+__device__ __forceinline__ double4_t tile_mm(const double* Ab, const double* Bb, int li, int lk, double4_t acc = double4_t{0, 0, 0, 0}) {
     constexpr int KS = KD / 4;
-    double fa[TR][KS], fb[TC][KS];
+    double fa[KS], fb[KS];
+    const double* pa = Ab + AI * li + AK * lk;
+    const double* pb = Bb + BK * lk + BJ * li;
 #pragma unroll
-    for (int a = 0; a < TR; ++a) {
-        const double* pa = Aop[a] + AI * (Arow[a] + li) + AK * lk;
+    for (int s = 0; s < KS; ++s) { fa[s] = pa[AK * 4 * s]; fb[s] = pb[BK * 4 * s]; }
 #pragma unroll
-        for (int s = 0; s < KS; ++s) fa[a][s] = pa[AK * 4 * s];
-    }
-#pragma unroll
-    for (int c = 0; c < TC; ++c) {
-        const double* pb = B + BK * lk + BJ * (16 * (c0 + c) + li);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) fb[c][s] = pb[BK * 4 * s];
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int a = 0; a < TR; ++a)
-#pragma unroll
-            for (int c = 0; c < TC; ++c)
-                acc[a * TC + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][s], fb[c][s], acc[a * TC + c], 0, 0, 0);
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s], fb[s], acc, 0, 0, 0);
+    return acc;
 }
 
-// The phase is a real (noinline) function: the fused solve kernel inlines every other phase (dense 32-state model
-// code included), and inside that one register allocation the Riccati loop ended up with hundreds of spills
-// whose scratch reloads wait on vmcnt(0), i.e. on the HBM prefetch. As a function it gets its own allocation.
-// Pointers cross the call with their address space attached (a plain double* would turn every access into a
-// flat_load), LDS is re-derived from the dynamic shared symbol.
+// Phases are real (noinline) functions: each gets its own register allocation (the dense 32-state model code inlined next to
+// the Riccati loop once pushed that loop into hundreds of spills). Pointers cross the call with their address space attached
+// (a plain double* would turn every access into a flat_load); LDS is re-derived from the dynamic shared symbol.
 typedef __attribute__((address_space(1))) double gdbl;
 template <class T> __device__ __forceinline__ gdbl* as_global(T* p) { return (gdbl*)p; }
 // LDS traffic of ONE wave is in order: a wave-local exchange between lanes needs no workgroup barrier
@@ -108,11 +88,10 @@ __device__ __forceinline__ gdbl* uniform_ptr(gdbl* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (gdbl*)(((unsigned long long)hi << 32) | lo);
 }
-// What the large-path phase functions need of one instance. They are real calls: a struct of twenty pointers would travel
-// on the stack (scratch), so only the instance's block pointer crosses the call; the Layout is read back from the tail of
-// the dynamic LDS, where the kernel parked it (store_layout_lds), and the pointers are rebuilt wave-uniform in the callee.
+// What the phase functions need of one instance. Only the instance's block pointer crosses the call; the Layout is read back
+// from the tail of the dynamic LDS, where the kernel parked it (store_layout_lds), and the pointers are rebuilt wave-uniform.
 struct LargeArgs {
-    gdbl *xb, *ub, *x, *u, *fx, *fu, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act, *w, *gxx, *guu, *gux, *P, *p, *scal;
+    gdbl *xb, *ub, *x, *u, *gx, *gu, *K, *k, *Lx, *Lu, *c, *lam, *rho, *act, *w, *P, *p, *scal, *fv, *hc, *ab;
     int T, N;
 };
 template <class M>
@@ -134,65 +113,154 @@ __device__ __forceinline__ LargeArgs large_args_from_lds(gdbl* base) {
     ILQR_LAYOUT_FIELDS(ILQR_X)
 #undef ILQR_X
     gdbl* g = uniform_ptr(base);
-    return LargeArgs{g + L.xb, g + L.ub, g + L.x, g + L.u, g + L.fx, g + L.fu, g + L.gx, g + L.gu, g + L.K, g + L.k, g + L.Lx, g + L.Lu,
-                     g + L.c, g + L.lam, g + L.rho, g + L.act, g + L.w, g + L.gxx, g + L.guu, g + L.gux, g + L.P, g + L.p, g + L.scal,
+    return LargeArgs{g + L.xb, g + L.ub, g + L.x, g + L.u, g + L.gx, g + L.gu, g + L.K, g + L.k, g + L.Lx, g + L.Lu,
+                     g + L.c, g + L.lam, g + L.rho, g + L.act, g + L.w, g + L.P, g + L.p, g + L.scal, g + L.fv, g + L.hc, g + L.ab,
                      L.T, L.T - 1};
 }
 
-// ---------------------------------------------------------------- gradients! (one timestep per lane)
-// Jacobian entries that do not depend on (x, u, θ) — 1248 of 1280 for synth32 — come from the generated tables
-// M::JAC_CONST_* and are written by coalesced wave-wide stores; only the M::JAC_NVAR state-dependent entries
-// are evaluated per timestep (M::dyn_jac_var_mem). Same `.=` semantics as src/dynamics.jl:45-46 every call.
+// ---------------------------------------------------------------- cost! (one timestep per thread of the workgroup)
+// cost_pass of ilqr_device.hpp for the four-wave workgroup: every timestep is evaluated by exactly one thread; the per-lane
+// partial sums of the waves are combined through LDS in wave order (the order a single wave walking t = lane, lane + 64, ...
+// would add them in), then summed over the lanes.
 template <class M>
-__attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int constrained) {
-    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, W = waves_of<M>::value;
+__attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int at_states, int upd_J, int upd_viol, int constrained,
+                                                               double* viol_out) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, NT = LargeDims<M>::NT, W = LargeDims<M>::W;
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
-    constrained = __builtin_amdgcn_readfirstlane(constrained);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), T = A.T, N = A.N;
-    constexpr bool split = M::JAC_NVAR < n * n + n * m;
-    if constexpr (split) {
-        // The constant entries are written once per buffer lifetime: 10 KB per timestep and instance that would
-        // otherwise be re-sent to HBM every iteration (530 MB per call for 512 synth32 instances — that alone
-        // was half of this phase). ilqr_reset and ilqr_set_buffer on the Jacobians clear the flag.
-        const bool fresh = A.scal[S_JAC_CONST] == 0.0;   // read by both waves BEFORE anyone may set it ...
-        __syncthreads();                                  // ... so that both take the same branch (barriers inside)
-        if (fresh) {
-            constexpr int EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
-            double cfx[EFX], cfu[EFU];
+    at_states = __builtin_amdgcn_readfirstlane(at_states); upd_J = __builtin_amdgcn_readfirstlane(upd_J);
+    upd_viol = __builtin_amdgcn_readfirstlane(upd_viol); constrained = __builtin_amdgcn_readfirstlane(constrained);
+    const gdbl* X = at_states ? A.x : A.xb;
+    const gdbl* U = at_states ? A.u : A.ub;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), T = A.T, N = A.N;
+    double Jp = 0.0, vp = 0.0;
+    for (int t = tid; t < T; t += NT) {
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>((const double*)A.w, t, w);
+        double xt[n];
 #pragma unroll
-            for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; cfx[q] = e < n * n ? M::JAC_CONST_FX[0][e] : 0.0; }
+        for (int i = 0; i < n; ++i) xt[i] = X[t * n + i];
+        if (t < N) {
+            double ut[m];
 #pragma unroll
-            for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; cfu[q] = e < n * m ? M::JAC_CONST_FU[0][e] : 0.0; }
-            for (int t = wave; t < N; t += W) {
+            for (int i = 0; i < m; ++i) ut[i] = U[t * m + i];
+            if (upd_J) Jp += M::cost_s(xt, ut, w);
+            if constexpr (ncs > 0) {
+                if (constrained) {
+                    double cv[ncs];
+                    M::con_s(xt, ut, w, cv);
+                    const int off = t * ncs;
+                    if (upd_J) {
+                        double dot = 0.0, pen = 0.0;
 #pragma unroll
-                for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) A.fx[(size_t)t * n * n + e] = cfx[q]; }
+                        for (int i = 0; i < ncs; ++i) {
+                            const double lam = A.lam[off + i];
+                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
+                            A.act[off + i] = inactive ? 0.0 : 1.0;
+                            dot += lam * cv[i];
+                            if (!inactive) pen += 0.5 * A.rho[off + i] * (cv[i] * cv[i]);
+                        }
+                        Jp += dot;
+                        Jp += pen;
+                    }
+                    if (upd_viol) {
 #pragma unroll
-                for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) A.fu[(size_t)t * n * m + e] = cfu[q]; }
+                        for (int i = 0; i < ncs; ++i) {
+                            A.c[off + i] = cv[i];
+                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
+                        }
+                    }
+                }
             }
-            __syncthreads();             // the state-dependent entries below overwrite some of these addresses
-            if (lane == 0 && wave == 0) A.scal[S_JAC_CONST] = 1.0;
+        } else {
+            if (upd_J) Jp += M::cost_t(xt, w);
+            if constexpr (nct > 0) {
+                if (constrained) {
+                    double cv[nct];
+                    M::con_t(xt, w, cv);
+                    const int off = N * ncs;
+                    if (upd_J) {
+                        double dot = 0.0, pen = 0.0;
+#pragma unroll
+                        for (int i = 0; i < nct; ++i) {
+                            const double lam = A.lam[off + i];
+                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
+                            A.act[off + i] = inactive ? 0.0 : 1.0;
+                            dot += lam * cv[i];
+                            if (!inactive) pen += 0.5 * A.rho[off + i] * (cv[i] * cv[i]);
+                        }
+                        Jp += dot;
+                        Jp += pen;
+                    }
+                    if (upd_viol) {
+#pragma unroll
+                        for (int i = 0; i < nct; ++i) {
+                            A.c[off + i] = cv[i];
+                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
+                        }
+                    }
+                }
+            }
         }
     }
-    for (int t = lane + 64 * wave; t < T; t += 64 * W) {                 // Hessians accumulate: each timestep exactly once
+    // combine the waves: every wave ends with the same two numbers (identical control flow afterwards)
+    double* comb = lds_dyn;                               // 2 x W x 64 doubles at the head of the staging area (dead between phases)
+    comb[wave * 64 + lane] = Jp;
+    comb[(W + wave) * 64 + lane] = vp;
+    __syncthreads();
+    double Js = 0.0, vs = 0.0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) { Js += comb[q * 64 + lane]; vs = nanmax(vs, comb[(W + q) * 64 + lane]); }
+    const double J = wave_sum(Js);
+    *viol_out = wave_max(vs);
+    __syncthreads();
+    return J;
+}
+template <class M>
+__device__ __forceinline__ void cost_pass_large(Inst<M>& I, bool at_states, bool upd_J, bool upd_viol, bool constrained,
+                                                double& J_out, double& viol_out) {
+    ILQR_PROF_BEGIN();
+    double v = 0.0;
+    J_out = cost_pass_large_fn<M>(as_global(I.gbase), at_states ? 1 : 0, upd_J ? 1 : 0, upd_viol ? 1 : 0, constrained ? 1 : 0, &v);
+    viol_out = v;
+    ILQR_PROF_END(I, PROF_COST);
+}
+
+// ---------------------------------------------------------------- gradients! (one timestep per thread)
+// State-dependent Jacobian entries → fv (`.=`, src/dynamics.jl:45-46), cost gradients (`.=`, src/costs.jl:61,65), cost
+// Hessians and Gauss-Newton AL terms ACCUMULATED (`.+=`, src/costs.jl:74-80, src/gradients.jl:54-80) into the compact row hc[t].
+template <class M>
+__attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int constrained) {
+    typedef LargeDims<M> LD;
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, NT = LD::NT;
+    const LargeArgs A = large_args_from_lds<M>(base);
+    constrained = __builtin_amdgcn_readfirstlane(constrained);
+    const int tid = threadIdx.x, T = A.T, N = A.N;
+    for (int t = tid; t < T; t += NT) {                                  // Hessians accumulate: each timestep exactly once
         double w[cdim<M::NW>::v];
         load_w<M::NW>((const double*)A.w, t, w);
         double xt[n];
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = A.xb[t * n + i];
-        double* gxx = (double*)(A.gxx + (size_t)t * n * n);
+        double* hrow = (double*)(A.hc + (size_t)t * LD::HSP);
         if (t < N) {
             double ut[m];
 #pragma unroll
             for (int i = 0; i < m; ++i) ut[i] = A.ub[t * m + i];
-            double* fx = (double*)(A.fx + (size_t)t * n * n);
-            double* fu = (double*)(A.fu + (size_t)t * n * m);
-            double* guu = (double*)(A.guu + (size_t)t * m * m);
-            double* gux = (double*)(A.gux + (size_t)t * m * n);
-            if constexpr (split) M::dyn_jac_var_mem(xt, ut, w, fx, fu);                       // `.=`  (src/dynamics.jl:45-46)
-            else M::dyn_jac_mem(xt, ut, w, fx, fu);
+            {
+                double v[cdim<LD::JV>::v];
+                v[0] = 0.0;
+                M::dyn_jac_var(xt, ut, w, v);
+#pragma unroll
+                for (int q = 0; q < LD::JV; ++q) A.fv[(size_t)t * LD::JVP + q] = v[q];
+            }
             double gx[n], gu[m];
-            M::cost_s_grad(xt, ut, w, gx, gu);                                                // `.=`  (src/costs.jl:61,65)
-            M::cost_s_hess_acc(xt, ut, w, gxx, guu, gux);                                     // `.+=` (src/costs.jl:74-80)
+            M::cost_s_grad(xt, ut, w, gx, gu);
+            M::cost_s_hess_c(xt, ut, w, hrow);
             if constexpr (ncs > 0) {
                 if (constrained) {                                                            // src/gradients.jl:54-80
                     double ct[ncs], ir[ncs];
@@ -202,7 +270,7 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
                         ir[i] = A.rho[off + i] * A.act[off + i];
                         ct[i] = A.lam[off + i] + ir[i] * A.c[off + i];
                     }
-                    M::al_s(xt, ut, w, ct, ir, gx, gu, gxx, guu, gux);
+                    M::al_s_c(xt, ut, w, ct, ir, gx, gu, hrow);
                 }
             }
 #pragma unroll
@@ -212,7 +280,7 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
         } else {
             double gx[n];
             M::cost_t_grad(xt, w, gx);
-            M::cost_t_hess_acc(xt, w, gxx);
+            M::cost_t_hess_c(xt, w, hrow);
             if constexpr (nct > 0) {
                 if (constrained) {
                     double ct[nct], ir[nct];
@@ -222,13 +290,14 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
                         ir[i] = A.rho[off + i] * A.act[off + i];
                         ct[i] = A.lam[off + i] + ir[i] * A.c[off + i];
                     }
-                    M::al_t(xt, w, ct, ir, gx, gxx);
+                    M::al_t_c(xt, w, ct, ir, gx, hrow);
                 }
             }
 #pragma unroll
             for (int i = 0; i < n; ++i) A.gx[t * n + i] = gx[i];
         }
     }
+    if (tid == 0) A.scal[S_JAC_VALID] = 1.0;
     __syncthreads();
 }
 template <class M>
@@ -238,17 +307,27 @@ __device__ __forceinline__ void gradients_large(Inst<M>& I, bool constrained) {
     ILQR_PROF_END(I, PROF_GRAD);
 }
 
-// ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles)
-// One Riccati step (src/backward_pass.jl:42-90) for n = 32, m = 8 issues 132 tile MFMAs (64 cycles each on
-// gfx950 ⇒ 8.4 k cycles of one matrix pipe) around a serial Cholesky/solve chain of ~4 k cycles. The instance's
-// TWO waves (two SIMDs) split it:
-//     both    stage fx, fu (HBM → registers a step ahead → LDS);   [T; ûx] = [fx fu]ᵀ P′, one column tile each
-//     wave 0  Qx, Qux, Quu → potrf → potrs (K, k) → ûxt = Quu K → p, ∇L        (the serial chain)
-//     wave 1  Qu, Qxx = T fx + gxx (overlaps wave 0's chain) → ûxt → P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx
-// Three workgroup barriers per timestep. Operand fragments of a product are read from zero-padded LDS matrices first
-// (odd leading dimensions, transposition = stride pattern, no bounds checks), then the MFMAs issue back to back;
-// Qxx never leaves wave 1's accumulators; the cost Hessians are prefetched in the D-layout of the tiles they are
-// added to, by the wave that owns those tiles.
+// reset!(problem.model); reset!(problem.objective) (src/solve.jl:9-10) on the compact representation: the Jacobians are
+// overwritten (`.=`) by the gradients! call that follows at once, so only the accumulating Hessian rows and the gradients
+// are zeroed. literal = true (the stage entry point) also forgets the Jacobians.
+template <class M>
+__device__ __forceinline__ void reset_model_objective_large(Inst<M>& I, bool literal) {
+    typedef LargeDims<M> LD;
+    constexpr int n = M::NX, m = M::NU, NT = LD::NT;
+    const int tid = threadIdx.x;
+    double* hc = I.gbase + I.hc_off;
+    for (int i = tid; i < I.T * LD::HSP; i += NT) hc[i] = 0.0;
+    for (int i = tid; i < I.T * n; i += NT) I.gx[i] = 0.0;
+    for (int i = tid; i < I.N * m; i += NT) I.gu[i] = 0.0;
+    if (literal) {
+        double* fv = I.gbase + I.fv_off;
+        for (int i = tid; i < I.N * LD::JVP; i += NT) fv[i] = 0.0;
+        if (tid == 0) I.scal[S_JAC_VALID] = 0.0;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles, four waves)
 struct RiccatiOut {
     double gradient_norm; int potrf_info;
 #if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
@@ -259,176 +338,193 @@ struct RiccatiOut {
 template <class M, bool STORE_VALUE>
 __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* base, gdbl* Qbase) {
     typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, ldm = LD::ldm;
-    constexpr int n4 = r4(n), m4 = r4(m), TN = NP / 16, TM = MP / 16, NT = 128;
-    constexpr int EFX = (n * n + NT - 1) / NT, EFU = (n * m + NT - 1) / NT;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, ld = LD::ld, ldm = LD::ldm, TN = LD::TN, NT = LD::NT;
+    constexpr int n4 = LD::n4, m4 = LD::m4, JV = LD::JV, JVP = LD::JVP, HXX = LD::HXX, HUU = LD::HUU, HUX = LD::HUX, HSP = LD::HSP;
+    constexpr int NQ = TN * TN;                            // tiles of T, Qxx, P
+    constexpr int EJ = (JV + NT - 1) / NT > 0 ? (JV + NT - 1) / NT : 1;            // Jacobian patch entries per thread
+    constexpr int EU = (HUU + HUX + 63) / 64 > 0 ? (HUU + HUX + 63) / 64 : 1;      // guu / gux entries per lane of wave 0
+    constexpr int SLOTS = (NQ + 2) / 3;                    // Qxx / P tiles per owner wave (waves 1..3)
     static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
     static_assert(LD::total == large_lds_doubles(n, m), "LDS carve and host-side size disagree");
-    static_assert(waves_of<M>::value == 2, "the Riccati step is written for two waves per instance");
+    static_assert(waves_of<M>::value == LARGE_WAVES, "the Riccati step is scheduled over four waves per instance");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    struct { gdbl *fx, *fu, *gx, *gu, *gxx, *guu, *gux, *K, *k, *Lx, *Lu, *P, *p; int potrf_info; double prof[6]; } I;
     const LargeArgs A = large_args_from_lds<M>(base);
-    I.fx = A.fx; I.fu = A.fu; I.gx = A.gx; I.gu = A.gu; I.gxx = A.gxx; I.guu = A.guu; I.gux = A.gux; I.K = A.K;
-    I.k = A.k; I.Lx = A.Lx; I.Lu = A.Lu; I.P = A.P; I.p = A.p;
-    I.potrf_info = 0;
+    struct { double prof[6]; } I;
     for (int q = 0; q < 6; ++q) I.prof[q] = 0.0;
+    int potrf_info = 0;
     gdbl* const Qv = (STORE_VALUE && Qbase != nullptr) ? uniform_ptr(Qbase) : nullptr;   // optional action-value buffers (stage kernel only)
     const QLayout QL = make_qlayout(n, m, A.T);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = A.N, li = lane & 15, lk = lane >> 4;
-    const bool w0 = wave == 0;
     double* S = lds_dyn;
-    double *sP = S + LD::oP, *sFx = S + LD::oFx, *sT = S + LD::oT, *sFu = S + LD::oFu, *sUh = S + LD::oUh,
-           *sQux = S + LD::oQux, *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
-    double* sUxt0 = sT;                                                   // wave 0's copy of ûxt (T is dead by then)
-    double *sp = S + LD::oVec, *sQx = sp + NP, *sQu = sQx + NP, *sk = sQu + MP, *sOut = sk + MP;
-    for (int e = tid; e < LD::oLay; e += NT) S[e] = 0.0;                  // the tile padding must read as zero (the Layout copy behind it stays)
+    double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *sP = S + LD::oP, *sT = S + LD::oT, *sUh = S + LD::oUh, *sQux = S + LD::oQux,
+           *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
+    double *sp = S + LD::oVec, *sQx = sp + NP, *sQu = sQx + NP, *sk = sQu + LD::MP, *sOut = sk + LD::MP;
+    double* bnc = S + LD::oBnc + (wave > 0 ? wave - 1 : 0) * (16 * 17);        // this wave's 16x16 bounce tile (waves 1..3)
+
+    // ---- prologue: zero padding, constant Jacobian entries, P[H] = gxx[H], p[H] = gx[H]   (:39-40)
+    for (int e = tid; e < LD::oVec; e += NT) S[e] = 0.0;
     __syncthreads();
-    for (int e = tid; e < n * n; e += NT) {                               // P[H] .= gxx[H]  (:39)
-        const double v = I.gxx[(size_t)N * n * n + e];
-        sP[(e / n) * ld + e % n] = v;
-        if (STORE_VALUE) I.P[(size_t)N * n * n + e] = v;
+    for (int e = tid; e < n * n; e += NT) sFx[(e / n) * ld + e % n] = M::JAC_CONST_FX[0][e];
+    for (int e = tid; e < n * m; e += NT) sFu[(e / n) * ld + e % n] = M::JAC_CONST_FU[0][e];
+    for (int q = tid; q < HXX; q += NT) {
+        const int idx = M::HESS_IDX[q];
+        sP[(idx / n) * ld + idx % n] = A.hc[(size_t)N * HSP + q];
     }
-    for (int i = tid; i < n; i += NT) {                                   // p[H] .= gx[H]   (:40)
-        const double v = I.gx[N * n + i];
+    for (int i = tid; i < n; i += NT) {
+        const double v = A.gx[N * n + i];
         sp[i] = v;
-        if (STORE_VALUE) I.p[N * n + i] = v;
+        if (STORE_VALUE) A.p[N * n + i] = v;
     }
-    // register prefetch of step t's operands (each wave fetches what it will consume)
-    double rfx[EFX], rfu[EFU], rgv = 0.0;
-    double4_t rgxx[TN * TN], rguu[TM * TM], rgux[TM * TN];
-    auto fetch_early = [&](int t) {
+    // where this thread's entries go (offsets into S; -1 = none)
+    int poff[EJ];
 #pragma unroll
-        for (int q = 0; q < EFX; ++q) {
-            const int e = tid + NT * q;
-            if constexpr ((n * n) % NT == 0) rfx[q] = I.fx[(size_t)t * n * n + e];
-            else rfx[q] = e < n * n ? I.fx[(size_t)t * n * n + e] : 0.0;
+    for (int j = 0; j < EJ; ++j) {
+        const int q = tid + NT * j;
+        poff[j] = -1;
+        if (q < JV) {
+            const int idx = M::JAC_VAR_IDX[q];
+            poff[j] = idx < n * n ? LD::oFx + (idx / n) * ld + idx % n : LD::oFu + ((idx - n * n) / n) * ld + (idx - n * n) % n;
         }
+    }
+    int uoff[EU];
 #pragma unroll
-        for (int q = 0; q < EFU; ++q) {
-            const int e = tid + NT * q;
-            if constexpr ((n * m) % NT == 0) rfu[q] = I.fu[(size_t)t * n * m + e];
-            else rfu[q] = e < n * m ? I.fu[(size_t)t * n * m + e] : 0.0;
+    for (int j = 0; j < EU; ++j) {
+        const int q = lane + 64 * j;
+        uoff[j] = -1;
+        if (q < HUU + HUX) {
+            const int idx = M::HESS_IDX[HXX + q];
+            uoff[j] = (q < HUU ? LD::oQuu : LD::oQux) + (idx / m) * ldm + idx % m;
         }
-        rgv = w0 ? I.gx[t * n + (lane < n ? lane : 0)] : I.gu[t * m + (lane < m ? lane : 0)];
-    };
-    auto fetch_late = [&](int t) {
-        if (w0) {
+    }
+    // Qxx / P tiles of this wave (waves 1..3): slot s holds tile q = (wave - 1) + 3 s; its gxx entries sit at
+    // [HESS_XX_TILE_START[q], HESS_XX_TILE_START[q + 1]) of the compact row, lane x of them at +lane (+64, ...)
+    constexpr int EXT = 4;                                 // a 16x16 tile has at most 256 entries
+    int xcnt[SLOTS], xbeg[SLOTS], xoff[SLOTS][EXT];
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+    for (int s = 0; s < SLOTS; ++s) {
+        const int q = (wave - 1) + 3 * s;
+        const bool have = wave >= 1 && q < NQ;
+        xbeg[s] = have ? M::HESS_XX_TILE_START[have ? q : 0] : 0;
+        xcnt[s] = have ? M::HESS_XX_TILE_START[(have ? q : 0) + 1] - xbeg[s] : 0;
 #pragma unroll
-                for (int c = 0; c < TM; ++c) rguu[a * TM + c] = tile_load_global<m, m>(I.guu + (size_t)t * m * m, 16 * a, 16 * c, li, lk);
+        for (int x = 0; x < EXT; ++x) {
+            xoff[s][x] = -1;
+            const int e = lane + 64 * x;
+            if (e < xcnt[s]) {
+                const int idx = M::HESS_IDX[xbeg[s] + e];
+                xoff[s][x] = ((idx / n) & 15) * 17 + ((idx % n) & 15);
+            }
+        }
+    }
+    __syncthreads();
+    if (STORE_VALUE) {
+        for (int e = tid; e < n * n; e += NT) A.P[(size_t)N * n * n + e] = sP[(e / n) * ld + e % n];
+    }
+    // the state-dependent Jacobian entries of the first step
+    if (N > 0) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+        for (int j = 0; j < EJ; ++j)
+            if (poff[j] >= 0) S[poff[j]] = A.fv[(size_t)(N - 1) * JVP + tid + NT * j];
+    }
+    // register prefetch of step t's compact operands, one step ahead (each wave fetches what it will consume)
+    double pval[EJ], uval[EU], xval[SLOTS][EXT], gv = 0.0;
 #pragma unroll
-                for (int c = 0; c < TN; ++c) rgux[a * TN + c] = tile_load_global<m, n>(I.gux + (size_t)t * m * n, 16 * a, 16 * c, li, lk);
+    for (int j = 0; j < EJ; ++j) pval[j] = 0.0;
+    auto fetch = [&](int t, double (&uv)[EU], double (&xv)[SLOTS][EXT], double& g) {
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < EU; ++j) uv[j] = uoff[j] >= 0 ? A.hc[(size_t)t * HSP + HXX + lane + 64 * j] : 0.0;
         } else {
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
+            for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
-                for (int c = 0; c < TN; ++c) rgxx[a * TN + c] = tile_load_global<n, n>(I.gxx + (size_t)t * n * n, 16 * a, 16 * c, li, lk);
+                for (int x = 0; x < EXT; ++x) xv[s][x] = xoff[s][x] >= 0 ? A.hc[(size_t)t * HSP + xbeg[s] + lane + 64 * x] : 0.0;
+            if (wave == 1) g = lane < 32 ? A.gx[t * n + (lane < n ? lane : 0)] : A.gu[t * m + (lane - 32 < m ? lane - 32 : 0)];
+            if (wave == 1 && n > 32) g = A.gx[t * n + (lane < n ? lane : 0)];
         }
     };
-#pragma unroll
-    for (int q = 0; q < TN * TN; ++q) rgxx[q] = double4_t{0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < TM * TM; ++q) rguu[q] = double4_t{0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < TM * TN; ++q) rgux[q] = double4_t{0, 0, 0, 0};
-    if (N > 0) { fetch_early(N - 1); fetch_late(N - 1); }
+    double gu_hi = 0.0;                                    // n > 32: gu of wave 1 travels in its own register
+    if (N > 0) {
+        fetch(N - 1, uval, xval, gv);
+        if (n > 32 && wave == 1) gu_hi = A.gu[(N - 1) * m + (lane < m ? lane : 0)];
+    }
     double gmax = 0.0;
     __syncthreads();
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
         ILQR_SUB_BEGIN();
+        const int tn = t > 0 ? t - 1 : 0;                                 // (t = 0: a harmless re-read instead of a branch)
+        // operands of the NEXT step, requested now
+        double uval_n[EU], xval_n[SLOTS][EXT], gv_n = 0.0, gu_hi_n = 0.0;
+        fetch(tn, uval_n, xval_n, gv_n);
+        if (n > 32 && wave == 1) gu_hi_n = A.gu[tn * m + (lane < m ? lane : 0)];
 #pragma unroll
-        for (int q = 0; q < EFX; ++q) {
-            const int e = tid + NT * q;
-            if ((n * n) % NT == 0 || e < n * n) sFx[(e / n) * ld + e % n] = rfx[q];
+        for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)tn * JVP + tid + NT * j] : 0.0;
+        // ------------------------------------------------ window A: ûx = fuᵀP′ (:57) | first half of T = fxᵀP′ (:52)
+        const int tcnt = wave >= 2 ? (NQ - (wave - 2) + 1) / 2 : 0;       // T tiles of this wave: q = (wave - 2) + 2 k
+        const int tA = (tcnt + 1) / 2;
+        if (wave < 2) {
+            for (int c = wave; c < TN; c += 2) {
+                const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFu, sP + ld * 16 * c, li, lk);
+                tile_store<ldm>(sUh, acc, 0, 16 * c, li, lk);
+            }
+        } else {
+            for (int kq = 0; kq < tA; ++kq) {
+                const int q = (wave - 2) + 2 * kq, a = q / TN, c = q % TN;
+                const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
+                tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
+            }
         }
-#pragma unroll
-        for (int q = 0; q < EFU; ++q) {
-            const int e = tid + NT * q;
-            if ((n * m) % NT == 0 || e < n * m) sFu[(e / n) * ld + e % n] = rfu[q];
-        }
-        const double gv = rgv;
-        __syncthreads();                                                  // (1) fx, fu staged; P′, p′ of the previous step visible
-        fetch_early(t > 0 ? t - 1 : 0);                                   // (t = 0: a harmless re-read instead of a branch)
-        // Qx = fx^T p' + gx (wave 0), Qu = fu^T p' + gu (wave 1)   (:44-49): one output per lane
-        {
-            const int col = w0 ? (lane < n ? lane : 0) : (lane < m ? lane : 0);
-            const double* colp = w0 ? sFx + col * ld : sFu + col * ld;
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < n; ++l) acc += colp[l] * sp[l];
-            if (w0 && lane < n) sQx[lane] = acc + gv;
-            if (!w0 && lane < m) sQu[lane] = acc + gv;
-        }
+        __syncthreads();                                                  // (B1) ûx complete
         ILQR_SUB_MARK(I, 0);
-        // [T; ux_hat] = [fx fu]^T P'  (:52, :57, :62): each wave one column tile (wave 0 all of them when there is one)
-        {
-            constexpr int TR = TN + TM, TC = TN == 2 ? 1 : TN;
-            if (TN == 2 || w0) {
-                const int c0 = TN == 2 ? wave : 0;
-                double4_t acc[TR * TC];
+        // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | rest of T
+        if (wave < 2) {
+            for (int c = wave; c <= TN; c += 2) {
+                if (c < TN) {
+                    const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * c, li, lk);
+                    tile_store<ldm>(sQux, acc, 0, 16 * c, li, lk);
+                } else {
+                    const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
+                    tile_store<ldm>(sQuu, acc, 0, 0, li, lk);
+                }
+            }
+            if (wave == 1) {
+                // Qu = fuᵀp′ + gu: action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum
+                constexpr int JP = (n + 3) / 4;
+                const int i = li < m ? li : m - 1;
+                double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < TR * TC; ++q) acc[q] = double4_t{0, 0, 0, 0};
-                const double* Aop[TR]; int Arow[TR];
-#pragma unroll
-                for (int a = 0; a < TR; ++a) { Aop[a] = a < TN ? sFx : sFu; Arow[a] = a < TN ? 16 * a : 16 * (a - TN); }
-                tiles_mac<TR, TC, n4, ld, 1, 1, ld>(acc, Aop, Arow, sP, li, lk, c0);
-#pragma unroll
-                for (int a = 0; a < TR; ++a)
-#pragma unroll
-                    for (int c = 0; c < TC; ++c) {
-                        if (a < TN) tile_store<ld>(sT, acc[a * TC + c], 16 * a, 16 * (c0 + c), li, lk);
-                        else tile_store<ldm>(sUh, acc[a * TC + c], 16 * (a - TN), 16 * (c0 + c), li, lk);
-                    }
+                for (int q = 0; q < JP; ++q) {
+                    const int l = lk * JP + q;
+                    if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
+                }
+                acc += __shfl_xor(acc, 16);
+                acc += __shfl_xor(acc, 32);
+                const double gu_v = n > 32 ? __shfl(gu_hi, li) : __shfl(gv, 32 + li);
+                if (lane < m) sQu[lane] = acc + gu_v;
+            }
+        } else {
+            for (int kq = tA; kq < tcnt; ++kq) {
+                const int q = (wave - 2) + 2 * kq, a = q / TN, c = q % TN;
+                const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
+                tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
             }
         }
-        __syncthreads();                                                  // (2) T, ux_hat, Qx, Qu complete
+        __syncthreads();                                                  // (B2) Qux, Quu, Qu, T complete
         ILQR_SUB_MARK(I, 1);
-        double4_t qxx[TN * TN];
+        // ------------------------------------------------ window C: the serial chain | Qx, Qxx
+        double4_t qxx[SLOTS];
+        if (wave == 0) {
+            // Quu += guu, Qux += gux (:59, :64): the structurally non-zero entries only
 #pragma unroll
-        for (int q = 0; q < TN * TN; ++q) qxx[q] = double4_t{0, 0, 0, 0};
-        if (w0) {
-            // Qux = ux_hat fx + gux (:63-64), Quu = ux_hat fu + guu (:58-59): one pass over the ux_hat fragments
-            {
-                constexpr int KS = n4 / 4, TC = TN + TM;
-                double4_t acc[TM * TC];
-#pragma unroll
-                for (int q = 0; q < TM * TC; ++q) acc[q] = double4_t{0, 0, 0, 0};
-                double fa[TM][KS], fb[TC][KS];
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int sx = 0; sx < KS; ++sx) fa[a][sx] = sUh[(4 * sx + lk) * ldm + 16 * a + li];
-#pragma unroll
-                for (int c = 0; c < TC; ++c)
-#pragma unroll
-                    for (int sx = 0; sx < KS; ++sx)
-                        fb[c][sx] = c < TN ? sFx[(16 * c + li) * ld + 4 * sx + lk] : sFu[(16 * (c - TN) + li) * ld + 4 * sx + lk];
-#pragma unroll
-                for (int sx = 0; sx < KS; ++sx)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int c = 0; c < TC; ++c)
-                            acc[a * TC + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][sx], fb[c][sx], acc[a * TC + c], 0, 0, 0);
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int c = 0; c < TC; ++c) {
-                        if (c < TN) tile_store<ldm>(sQux, acc[a * TC + c] + rgux[a * TN + c], 16 * a, 16 * c, li, lk);
-                        else tile_store<ldm>(sQuu, acc[a * TC + c] + rguu[a * TM + (c - TN)], 16 * a, 16 * (c - TN), li, lk);
-                    }
-            }
-            wave_lds_fence();                                             // this wave's own Quu, Qux writes
+            for (int j = 0; j < EU; ++j)
+                if (uoff[j] >= 0) S[uoff[j]] += uval[j];
+            wave_lds_fence();
             if (STORE_VALUE && Qv != nullptr) {                           // policy.action_value.* (src/data/policy.jl:58-64)
                 for (int e = lane; e < m * n; e += 64) Qv[QL.Qux + (size_t)t * m * n + e] = sQux[(e / m) * ldm + e % m];
                 for (int e = lane; e < m * m; e += 64) Qv[QL.Quu + (size_t)t * m * m + e] = sQuu[(e / m) * ldm + e % m];
-                if (lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
+                if (lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
             }
-            ILQR_SUB_MARK(I, 2);
             // potrf('U') on wave-uniform registers (info ignored, :68-69)
             double Uc[m * m], Ur[m];
 #pragma unroll
@@ -436,9 +532,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
                 for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? sQuu[j * ldm + i] : 0.0;
             const int info = potrf_U<m>(Uc, Ur);
-            if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
-            fetch_late(t > 0 ? t - 1 : 0);
-            ILQR_SUB_MARK(I, 3);
+            if (info != 0 && potrf_info == 0) potrf_info = info;
+            ILQR_SUB_MARK(I, 2);
             // potrs('U'): column j of Qux per lane, Qu on lane n   (:70-75)
             // (nx = 64 leaves no lane for k: a second pass on lane 0)
 #pragma unroll
@@ -453,104 +548,142 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
                     for (int i = 0; i < m; ++i) {
                         const double v = b[i] * -1.0;
-                        if (j < n) { sK[j * ldm + i] = v; I.K[(size_t)t * m * n + j * m + i] = v; }
-                        else { sk[i] = v; I.k[t * m + i] = v; }
+                        if (j < n) { sK[j * ldm + i] = v; A.K[(size_t)t * m * n + j * m + i] = v; }
+                        else { sk[i] = v; A.k[t * m + i] = v; }
                     }
                 }
             }
+            ILQR_SUB_MARK(I, 3);
         } else {
-            // Qxx = T fx + gxx (:53-54): stays in this wave's accumulators, overlaps wave 0's Cholesky chain
-            const double* Aop[TN]; int Arow[TN];
+            if (wave == 1) {
+                // Qx = fxᵀp′ + gx (:44-46): state i on lanes i and i + 32 (half of the sum each) when n <= 32
+                if constexpr (n <= 32) {
+                    constexpr int JP = (n + 1) / 2;
+                    const int i = (lane & 31) < n ? (lane & 31) : n - 1, h = lane >> 5;
+                    double acc = 0.0;
 #pragma unroll
-            for (int a = 0; a < TN; ++a) { Aop[a] = sT; Arow[a] = 16 * a; }
-            tiles_mac<TN, TN, n4, 1, ld, 1, ld>(qxx, Aop, Arow, sFx, li, lk);
+                    for (int q = 0; q < JP; ++q) {
+                        const int l = h * JP + q;
+                        if ((n % 2 == 0) || l < n) acc += sFx[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
+                    }
+                    acc += __shfl_xor(acc, 32);
+                    if (lane < n) sQx[lane] = acc + gv;
+                } else {
+                    const int i = lane < n ? lane : n - 1;
+                    double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q < TN * TN; ++q) qxx[q] = qxx[q] + rgxx[q];
-            if (STORE_VALUE && Qv != nullptr) {
-                if (lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
+                    for (int l = 0; l < n; ++l) acc += sFx[i * ld + l] * sp[l];
+                    if (lane < n) sQx[lane] = acc + gv;
+                }
+                if (STORE_VALUE && Qv != nullptr && lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
+            }
+            // Qxx = T fx + gxx (:53-54): stays in this wave's registers until P; gxx through the wave's bounce tile
 #pragma unroll
-                for (int a = 0; a < TN; ++a)
+            for (int s = 0; s < SLOTS; ++s) {
+                const int q = (wave - 1) + 3 * s;
+                qxx[s] = double4_t{0, 0, 0, 0};
+                if (q < NQ) {
+                    const int a = q / TN, c = q % TN;
+                    double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
+                    if (xcnt[s] > 0) {
+                        tile_store<17>(bnc, acc, 0, 0, li, lk);
+                        wave_lds_fence();
 #pragma unroll
-                    for (int c = 0; c < TN; ++c)
+                        for (int x = 0; x < EXT; ++x)
+                            if (xoff[s][x] >= 0) bnc[xoff[s][x]] += xval[s][x];
+                        wave_lds_fence();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = bnc[li * 17 + lk + 4 * r];
+                        wave_lds_fence();
+                    }
+                    qxx[s] = acc;
+                    if (STORE_VALUE && Qv != nullptr) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
-                            if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = qxx[a * TN + c][r];
+                            if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = acc[r];
                         }
+                    }
+                }
             }
-            fetch_late(t > 0 ? t - 1 : 0);
         }
-        __syncthreads();                                                  // (3) K, k in LDS; T no longer needed
+        __syncthreads();                                                  // (B3) K, k, Qx in LDS; T, fx, fu no longer needed
         ILQR_SUB_MARK(I, 4);
-        // ux_tmp = Quu K   (:79): both waves, each into its own buffer (saves a barrier)
-        {
-            double4_t acc[TM * TN];
+        // ------------------------------------------------ window D: P (:79-84) | p, ∇L (:86-89, src/solve.jl:73-81); next step's Jacobian entries
+        if (t > 0) {
 #pragma unroll
-            for (int q = 0; q < TM * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
-            const double* Aop[TM]; int Arow[TM];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) { Aop[a] = sQuu; Arow[a] = 16 * a; }
-            tiles_mac<TM, TN, m4, 1, ldm, 1, ldm>(acc, Aop, Arow, sK, li, lk);
-            double* dst = w0 ? sUxt0 : sUxt;
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int c = 0; c < TN; ++c) tile_store<ldm>(dst, acc[a * TN + c], 16 * a, 16 * c, li, lk);
-            wave_lds_fence();
+            for (int j = 0; j < EJ; ++j)
+                if (poff[j] >= 0) S[poff[j]] = pval[j];
         }
-        if (!w0) {
-            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order
-            double4_t acc[TN * TN];
-#pragma unroll
-            for (int q = 0; q < TN * TN; ++q) acc[q] = double4_t{0, 0, 0, 0};
-            const double* Ak[TN]; const double* Aq[TN]; int Arow[TN];
-#pragma unroll
-            for (int a = 0; a < TN; ++a) { Ak[a] = sK; Aq[a] = sQux; Arow[a] = 16 * a; }
-            tiles_mac<TN, TN, m4, ldm, 1, 1, ldm>(acc, Ak, Arow, sUxt, li, lk);
-            tiles_mac<TN, TN, m4, ldm, 1, 1, ldm>(acc, Ak, Arow, sQux, li, lk);
-            tiles_mac<TN, TN, m4, ldm, 1, 1, ldm>(acc, Aq, Arow, sK, li, lk);
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int c = 0; c < TN; ++c) {
-                    const double4_t v = acc[a * TN + c] + qxx[a * TN + c];
-                    tile_store<ld>(sP, v, 16 * a, 16 * c, li, lk);
-                    if (STORE_VALUE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
-                            if (row < n && col < n) I.P[(size_t)t * n * n + col * n + row] = v[r];
-                        }
-                    }
-                }
-        } else {
+        if (wave == 0) {
+            // ux_tmp = Quu K (:79) for the vector chain, in this wave's own buffer
+            for (int c = 0; c < TN; ++c) {
+                const double4_t acc = tile_mm<m4, 1, ldm, 1, ldm>(sQuu, sK + ldm * 16 * c, li, lk);
+                tile_store<ldm>(sUxt, acc, 0, 16 * c, li, lk);
+            }
+            wave_lds_fence();
             // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89); Lagrangian gradient (src/solve.jl:73-81)
             if (lane < n) {
                 double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int l = 0; l < m; ++l) {
-                    a1 += sUxt0[lane * ldm + l] * sk[l];
+                    a1 += sUxt[lane * ldm + l] * sk[l];
                     a2 += sK[lane * ldm + l] * sQu[l];
                     a3 += sQux[lane * ldm + l] * sk[l];
                 }
                 const double pn = ((a1 + a2) + a3) + sQx[lane];
                 const double Lx = sQx[lane] - pn;
                 gmax = nanmax(gmax, fabs(Lx));
-                I.Lx[t * n + lane] = Lx;
-                if (STORE_VALUE) I.p[t * n + lane] = pn;
-                sp[lane] = pn;                                            // p' of the next step (read after barrier (1))
+                A.Lx[t * n + lane] = Lx;
+                if (STORE_VALUE) A.p[t * n + lane] = pn;
+                sp[lane] = pn;                                            // p' of the next step
             }
             if (lane < m) {
                 gmax = nanmax(gmax, fabs(sQu[lane]));
-                I.Lu[t * m + lane] = sQu[lane];
+                A.Lu[t * m + lane] = sQu[lane];
+            }
+        } else {
+            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order; ux_tmp = Quu K (:79) comes out
+            // of its MFMAs in exactly the layout the next MFMA's B operand wants (k = lane>>4 + 4 reg, j = lane&15)
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int q = (wave - 1) + 3 * s;
+                if (q < NQ) {
+                    const int a = q / TN, c = q % TN;
+                    const double4_t ux = tile_mm<m4, 1, ldm, 1, ldm>(sQuu, sK + ldm * 16 * c, li, lk);
+                    double4_t acc = double4_t{0, 0, 0, 0};
+                    {
+                        const double* pa = sK + ldm * (16 * a + li) + lk;                  // A(i,k) = K[k][i]
+#pragma unroll
+                        for (int sx = 0; sx < m4 / 4; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * sx], ux[sx], acc, 0, 0, 0);
+                    }
+                    acc = tile_mm<m4, ldm, 1, 1, ldm>(sK + ldm * 16 * a, sQux + ldm * 16 * c, li, lk, acc);
+                    acc = tile_mm<m4, ldm, 1, 1, ldm>(sQux + ldm * 16 * a, sK + ldm * 16 * c, li, lk, acc);
+                    const double4_t v = acc + qxx[s];
+                    tile_store<ld>(sP, v, 16 * a, 16 * c, li, lk);
+                    if (STORE_VALUE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
+                            if (row < n && col < n) A.P[(size_t)t * n * n + col * n + row] = v[r];
+                        }
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int j = 0; j < EU; ++j) uval[j] = uval_n[j];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+            for (int x = 0; x < EXT; ++x) xval[s][x] = xval_n[s][x];
+        gv = gv_n; gu_hi = gu_hi_n;
+        __syncthreads();                                                  // (B0) P′, p′, patched fx, fu visible
         ILQR_SUB_MARK(I, 5);
     }
-    __syncthreads();
-    // the serial chain lived on wave 0: hand its scalars to both waves (identical control flow afterwards)
+    // the serial chain lived on wave 0: hand its scalars to all waves (identical control flow afterwards)
     const double gn = wave_max(gmax);
-    if (tid == 0) { sOut[0] = gn; sOut[1] = (double)I.potrf_info; }
+    if (tid == 0) { sOut[0] = gn; sOut[1] = (double)potrf_info; }
     __syncthreads();
     RiccatiOut out;
     out.gradient_norm = sOut[0];
@@ -573,157 +706,188 @@ __device__ __forceinline__ void backward_pass_large(Inst<M>& I) {
 }
 
 // ---------------------------------------------------------------- forward sweep: rollout! ∥ trajectory_sensitivities
-// The closed-loop rollout (src/rollout.jl:1-31) and, on the first line-search trial, the sensitivity recursion with its
-// dot product (src/data/methods.jl:42-54, src/forward_pass.jl:20) are independent forward sweeps over t: wave 0 runs
-// the rollout while wave 1 runs the sensitivities. Each works in its own LDS staging (wave-local fences, no workgroup
-// barrier inside the sweep); one barrier at the end.
-//
-// rollout: u = αk + ū + Kx − Kx̄ (:24-28) with K x on lanes 0..m-1 and K x̄ on lanes 32..32+m-1 at the same time (K_t
-// staged in LDS, fetched from HBM a step ahead); dynamics: lane i evaluates row i of the affine part
-// y = DYN_AFF [x; u; 1] with its coefficient row held in registers for the whole rollout, plus the generated
-// remainder (wave-cooperative trig). x and u travel between lanes through LDS.
+// The closed-loop rollout (src/rollout.jl:1-31) and, on the first line-search trial, the sensitivity recursion with its dot
+// product (src/data/methods.jl:42-54, src/forward_pass.jl:20) are independent forward sweeps over t: wave 0 runs the rollout,
+// wave 1 the sensitivities, waves 2 and 3 copy K_t into an LDS ring one chunk of CH timesteps ahead (one workgroup barrier
+// per chunk). Before the sweep all four waves form a_t = α k_t + ū_t and b_t = K_t x̄_t (src/rollout.jl:24-28 is
+// u = ((α k + ū) + K x) − K x̄ in that order) for every t, so that the serial chain of a step is K x, the affine row and the
+// remainder only. K x and K x̄ use the same summation scheme (four partial sums per action, combined pairwise), so the
+// feedback term vanishes exactly where x = x̄.
 template <class M>
-__device__ __forceinline__ void rollout_large_body(const LargeArgs& A, double alpha, int lane) {
-    typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, EK = (m * n + 63) / 64;
-    static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
-    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    const int N = A.N;
-    double* sK = lds_dyn + LD::oK;                     // packed m x n
-    double* sx = lds_dyn + LD::oVec;                   // x (n), then x̄ (n), then u (m)
-    double* sxb = sx + LD::NP;
-    double* su = sxb + LD::NP;
-    const int row = lane < n ? lane : n - 1;
-    double aff[n + m + 1];
+__device__ __forceinline__ double kx_partial(const double* Kt, const double* xv, int li, int lk) {
+    // Σ_j K[i][j] x[j] for action i = li: lane (li, lk) sums the lk-th quarter of the states, then the quarters are combined
+    constexpr int n = M::NX, m = M::NU, JP = (n + 3) / 4;
+    const int i = li < m ? li : m - 1;
+    double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
-    double xl = lane < n ? A.xb[lane] : 0.0;                              // x[1] = x̄[1]  (:19)
-    if (lane < n) A.x[lane] = xl;
-    double rK[EK];
-    auto fetchK = [&](int t) {
-#pragma unroll
-        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; rK[q] = ((m * n) % 64 == 0 || e < m * n) ? A.K[(size_t)t * m * n + e] : 0.0; }
-    };
-    if (N > 0) fetchK(0);
-    double xbl = lane < n ? A.xb[lane] : 0.0;                             // x̄_t component of this lane
-    const bool hi = lane >= 32;                                           // lanes 32.. work on K x̄
-    const int ui = (lane & 31) < m ? (lane & 31) : m - 1;
-    for (int t = 0; t < N; ++t) {
-#pragma unroll
-        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; if ((m * n) % 64 == 0 || e < m * n) sK[e] = rK[q]; }
-        if (lane < n) { sx[lane] = xl; sxb[lane] = xbl; }
-        wave_lds_fence();
-        if (t + 1 < N) fetchK(t + 1);
-        const double xb_next = lane < n ? A.xb[(t + 1) * n + lane] : 0.0;
-        const double kv = A.k[t * m + ui], ubv = A.ub[t * m + ui];
-        double xa[n];
-#pragma unroll
-        for (int j = 0; j < n; ++j) xa[j] = sx[j];
-        const double* src = hi ? sxb : sx;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < n; ++j) acc += sK[j * m + ui] * src[j];       // K x (lanes < 32) | K x̄ (lanes >= 32)
-        const double a2 = __shfl(acc, lane + 32);
-        double v = kv * alpha;                                            // (:24-25)
-        v += ubv;                                                         // (:26)
-        v += acc;                                                         // (:27)
-        v += -1.0 * a2;                                                   // (:28)
-        if (lane < m) { su[lane] = v; A.u[t * m + lane] = v; }
-        wave_lds_fence();
-        double ua[m];
-#pragma unroll
-        for (int j = 0; j < m; ++j) ua[j] = su[j];
-        double y = aff[n + m];                                            // (:29) row `lane` of the dynamics
-#pragma unroll
-        for (int j = 0; j < n; ++j) y += aff[j] * xa[j];
-#pragma unroll
-        for (int j = 0; j < m; ++j) y += aff[n + j] * ua[j];
-        if constexpr (M::DYN_HAS_REM) {
-            double w[cdim<M::NW>::v], r[n];
-            load_w<M::NW>((const double*)A.w, t, w);
-            M::dyn_rem_wave(lane, xa, ua, w, r);
-            double rl = r[0];
-#pragma unroll
-            for (int i = 1; i < n; ++i) rl = (lane == i) ? r[i] : rl;
-            y += rl;
-        }
-        xl = y;
-        xbl = xb_next;
-        if (lane < n) A.x[(t + 1) * n + lane] = y;
-        wave_lds_fence();
+    for (int q = 0; q < JP; ++q) {
+        const int j = lk * JP + q;
+        if ((n % 4 == 0) || j < n) acc += Kt[(j < n ? j : 0) * m + i] * xv[j < n ? j : 0];
     }
-}
-
-// Δu = k + KΔx on lanes 0..m-1, Δx⁺ = fuΔu + fxΔx one row per lane; K, fx, fu staged in LDS (HBM fetch a step ahead).
-// Staging buffers disjoint from the rollout's.
-template <class M>
-__device__ __forceinline__ double delta_large_body(const LargeArgs& A, int lane) {
-    typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, ld = LD::ld;
-    constexpr int EK = (m * n + 63) / 64, EFX = (n * n + 63) / 64, EFU = (n * m + 63) / 64;
-    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    const int N = A.N;
-    double *sK = lds_dyn + LD::oQux, *sFx = lds_dyn + LD::oFx, *sFu = lds_dyn + LD::oFu;
-    double* zx = lds_dyn + LD::oVec + 2 * LD::NP + LD::MP;        // n   (behind the rollout's x, x̄, u)
-    double* zu = zx + LD::NP;                                     // m
-    double rK[EK], rfx[EFX], rfu[EFU];
-    auto fetch = [&](int t) {
-#pragma unroll
-        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; rK[q] = ((m * n) % 64 == 0 || e < m * n) ? A.K[(size_t)t * m * n + e] : 0.0; }
-#pragma unroll
-        for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; rfx[q] = ((n * n) % 64 == 0 || e < n * n) ? A.fx[(size_t)t * n * n + e] : 0.0; }
-#pragma unroll
-        for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; rfu[q] = ((n * m) % 64 == 0 || e < n * m) ? A.fu[(size_t)t * n * m + e] : 0.0; }
-    };
-    if (N > 0) fetch(0);
-    if (lane < n) zx[lane] = 0.0;
-    double dpart = 0.0;
-    const int ui = lane < m ? lane : m - 1, xi = lane < n ? lane : n - 1;
-    for (int t = 0; t < N; ++t) {
-#pragma unroll
-        for (int q = 0; q < EK; ++q) { const int e = lane + 64 * q; if ((m * n) % 64 == 0 || e < m * n) sK[e] = rK[q]; }
-#pragma unroll
-        for (int q = 0; q < EFX; ++q) { const int e = lane + 64 * q; if ((n * n) % 64 == 0 || e < n * n) sFx[(e / n) * ld + e % n] = rfx[q]; }
-#pragma unroll
-        for (int q = 0; q < EFU; ++q) { const int e = lane + 64 * q; if ((n * m) % 64 == 0 || e < n * m) sFu[(e / n) * ld + e % n] = rfu[q]; }
-        wave_lds_fence();
-        if (t + 1 < N) fetch(t + 1);
-        const double kv = A.k[t * m + ui], Luv = A.Lu[t * m + ui], Lxv = A.Lx[t * n + xi];
-        double za[n];
-#pragma unroll
-        for (int j = 0; j < n; ++j) za[j] = zx[j];
-        double acc = 0.0;                                                 // Δu = k + K Δx
-#pragma unroll
-        for (int j = 0; j < n; ++j) acc += sK[j * m + ui] * za[j];
-        const double du = kv + acc;
-        if (lane < m) { zu[lane] = du; dpart += Luv * du; }
-        if (lane < n) dpart += Lxv * zx[xi];
-        wave_lds_fence();
-        double a1 = 0.0, a2 = 0.0;                                        // Δx⁺ = fu Δu + fx Δx
-#pragma unroll
-        for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * zu[j];
-#pragma unroll
-        for (int j = 0; j < n; ++j) a2 += sFx[j * ld + xi] * za[j];
-        wave_lds_fence();
-        if (lane < n) zx[lane] = a1 + a2;
-        wave_lds_fence();
-    }
-    return wave_sum(dpart);
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    return acc;
 }
 
 template <class M>
 __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, double alpha, int want_delta) {
     typedef LargeDims<M> LD;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, NT = LD::NT, CH = LD::CH, KN = m * n, JV = LD::JV, JVP = LD::JVP;
+    constexpr int EJ = (JV + 63) / 64 > 0 ? (JV + 63) / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
     want_delta = __builtin_amdgcn_readfirstlane(want_delta);
-    double* sOut = lds_dyn + LD::oVec + 4 * LD::NP + 4 * LD::MP;
+    const int N = A.N;
+    double* S = lds_dyn;
+    double *sFx = S + LD::oFx, *sFu = S + LD::oFu;
+    double *sx = S + LD::oFw, *su = sx + NP, *zx = su + MP, *zu = zx + NP, *ring = S + LD::oRing;
+    double* sOut = S + LD::oVec + 2 * NP + 2 * MP;
+    // ---- a_t, b_t for every timestep (wave per timestep, same lane mapping as the rollout's K x)
+    for (int t = wave; t < N; t += LD::W) {
+        const int i = li < m ? li : m - 1;
+        constexpr int JP = (n + 3) / 4;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < JP; ++q) {
+            const int j = lk * JP + q;
+            if ((n % 4 == 0) || j < n) acc += A.K[(size_t)t * KN + (j < n ? j : 0) * m + i] * A.xb[t * n + (j < n ? j : 0)];
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (lane < m) {
+            double v = A.k[t * m + lane] * alpha;                         // (:24-25)
+            v += A.ub[t * m + lane];                                      // (:26)
+            A.ab[2 * t * m + lane] = v;
+            A.ab[(2 * t + 1) * m + lane] = acc;
+        }
+    }
+    // constant Jacobian entries for the sensitivity recursion
+    if (want_delta) {
+        for (int e = tid; e < LD::oP; e += NT) S[e] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < n * n; e += NT) sFx[(e / n) * ld + e % n] = M::JAC_CONST_FX[0][e];
+        for (int e = tid; e < n * m; e += NT) sFu[(e / n) * ld + e % n] = M::JAC_CONST_FU[0][e];
+    }
+    // ring: chunk 0
+    auto stage = [&](int c0, int nthreads, int me) {                      // K[c0 .. c0 + CH) into the ring half (c0 / CH) & 1
+        const int steps = (N - c0) < CH ? (N - c0) : CH;
+        double* dst = ring + ((c0 / CH) & 1) * CH * KN;
+        const gdbl* src = A.K + (size_t)c0 * KN;
+        for (int e = me; e < steps * KN; e += nthreads) dst[e] = src[e];
+    };
+    if (N > 0) stage(0, NT, tid);
+    __syncthreads();                                                      // a_t, b_t (global, this workgroup only) and ring visible
+    __threadfence_block();
     double d = 0.0;
-    if (wave == 0) rollout_large_body<M>(A, alpha, lane);
-    else if (want_delta) d = delta_large_body<M>(A, lane);
-    __syncthreads();
-    if (want_delta) {                     // hand wave 1's scalar to both waves (identical control flow afterwards)
+    // wave 0 state
+    const int row = lane < n ? lane : n - 1;
+    double aff[n + m + 1];
+    double xl = 0.0, a_t = 0.0, b_t = 0.0;
+    // wave 1 state
+    int poff[EJ];
+    double pval[EJ], dpart = 0.0, kv = 0.0, Luv = 0.0, Lxv = 0.0;
+    const int ui = lane < m ? lane : m - 1, xi = lane < n ? lane : n - 1;
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
+        xl = lane < n ? A.xb[lane] : 0.0;                                 // x[1] = x̄[1]  (:19)
+        if (lane < n) A.x[lane] = xl;
+        if (N > 0 && lane < m) { a_t = A.ab[lane]; b_t = A.ab[m + lane]; }
+    } else if (wave == 1 && want_delta) {
+#pragma unroll
+        for (int j = 0; j < EJ; ++j) {
+            const int q = lane + 64 * j;
+            poff[j] = -1; pval[j] = 0.0;
+            if (q < JV) {
+                const int idx = M::JAC_VAR_IDX[q];
+                poff[j] = idx < n * n ? LD::oFx + (idx / n) * ld + idx % n : LD::oFu + ((idx - n * n) / n) * ld + (idx - n * n) % n;
+                if (N > 0) pval[j] = A.fv[q];
+            }
+        }
+        if (lane < n) zx[lane] = 0.0;
+        if (N > 0) { kv = A.k[ui]; Luv = A.Lu[ui]; Lxv = A.Lx[xi]; }
+    }
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
+        if (wave == 0) {
+            for (int t = c0; t < c1; ++t) {
+                const double* Kt = ring + (t % (2 * CH)) * KN;
+                if (lane < n) sx[lane] = xl;
+                wave_lds_fence();
+                const int t1 = t + 1 < N ? t + 1 : t;
+                const double a_n = lane < m ? A.ab[2 * t1 * m + lane] : 0.0, b_n = lane < m ? A.ab[(2 * t1 + 1) * m + lane] : 0.0;
+                double xa[n];
+#pragma unroll
+                for (int j = 0; j < n; ++j) xa[j] = sx[j];
+                const double acc = kx_partial<M>(Kt, sx, li, lk);
+                double v = a_t;                                               // α k + ū   (:24-26)
+                v += acc;                                                     // + K x      (:27)
+                v += -1.0 * b_t;                                              // − K x̄     (:28)
+                if (lane < m) { su[lane] = v; A.u[t * m + lane] = v; }
+                wave_lds_fence();
+                double ua[m];
+#pragma unroll
+                for (int j = 0; j < m; ++j) ua[j] = su[j];
+                double y = aff[n + m];                                        // (:29) row `lane` of the dynamics
+#pragma unroll
+                for (int j = 0; j < n; ++j) y += aff[j] * xa[j];
+#pragma unroll
+                for (int j = 0; j < m; ++j) y += aff[n + j] * ua[j];
+                if constexpr (M::DYN_HAS_REM) {
+                    double w[cdim<M::NW>::v], r[n];
+                    load_w<M::NW>((const double*)A.w, t, w);
+                    M::dyn_rem_wave(lane, xa, ua, w, r);
+                    double rl = r[0];
+#pragma unroll
+                    for (int i = 1; i < n; ++i) rl = (lane == i) ? r[i] : rl;
+                    y += rl;
+                }
+                xl = y;
+                a_t = a_n; b_t = b_n;
+                if (lane < n) A.x[(t + 1) * n + lane] = y;
+                wave_lds_fence();
+            }
+        } else if (wave == 1 && want_delta) {
+            // Δu = k + KΔx on lanes 0..m-1 (quarter sums like the rollout), Δx⁺ = fuΔu + fxΔx one row per lane
+            for (int t = c0; t < c1; ++t) {
+                const double* Kt = ring + (t % (2 * CH)) * KN;
+#pragma unroll
+                for (int j = 0; j < EJ; ++j)
+                    if (poff[j] >= 0) S[poff[j]] = pval[j];
+                wave_lds_fence();
+                const int t1 = t + 1 < N ? t + 1 : t;
+#pragma unroll
+                for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)t1 * JVP + lane + 64 * j] : 0.0;
+                const double kv_n = A.k[t1 * m + ui], Luv_n = A.Lu[t1 * m + ui], Lxv_n = A.Lx[t1 * n + xi];
+                double za[n];
+#pragma unroll
+                for (int j = 0; j < n; ++j) za[j] = zx[j];
+                const double acc = kx_partial<M>(Kt, zx, li, lk);
+                const double du = kv + acc;
+                if (lane < m) { zu[lane] = du; dpart += Luv * du; }
+                if (lane < n) dpart += Lxv * zx[xi];
+                wave_lds_fence();
+                double a1 = 0.0, a2 = 0.0;                                    // Δx⁺ = fu Δu + fx Δx
+#pragma unroll
+                for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * zu[j];
+#pragma unroll
+                for (int j = 0; j < n; ++j) a2 += sFx[j * ld + xi] * za[j];
+                wave_lds_fence();
+                if (lane < n) zx[lane] = a1 + a2;
+                kv = kv_n; Luv = Luv_n; Lxv = Lxv_n;
+                wave_lds_fence();
+            }
+        } else if (wave >= 2 || !want_delta) {
+            if (c1 < N) {                                                     // the stagers: next chunk into the other ring half
+                const int first = want_delta ? 2 : 1, cnt = LD::W - first;
+                stage(c1, 64 * cnt, tid - 64 * first);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 1 && want_delta) d = wave_sum(dpart);
+    if (want_delta) {                     // hand wave 1's scalar to all waves (identical control flow afterwards)
         if (tid == 64) sOut[2] = d;
         __syncthreads();
         d = sOut[2];
@@ -739,6 +903,57 @@ __device__ __forceinline__ void rollout_large(Inst<M>& I, double alpha, bool wan
     I.rollouts += 1;
     I.states_eq_nominal = 0;
     ILQR_PROF_END(I, PROF_ROLLOUT);
+}
+
+// ---------------------------------------------------------------- host-visible mirror of the compact representation
+// dir = 0: materialise — jacobian_state / jacobian_action = generated constants + fv (all zero while the Jacobians have not
+// been evaluated since the last reset), hessian_* = zeros + hc.   dir = 1: gather — the reverse, after the host wrote one of
+// the full arrays (entries outside the structural pattern cannot be represented and are dropped; the constant Jacobian
+// entries are the generated ones whatever the host wrote there).
+template <class M>
+__global__ __launch_bounds__(256) void mirror_large_kernel(KArgs a, int dir) {
+    typedef LargeDims<M> LD;
+    constexpr int n = M::NX, m = M::NU;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= a.B) return;
+    const Layout& L = a.L;
+    double* g = a.ws + (size_t)b * (size_t)L.stride;
+    const int T = L.T, N = T - 1;
+    if (dir == 0) {
+        const bool valid = g[L.scal + S_JAC_VALID] != 0.0;
+        for (int e = tid; e < N * n * n; e += 256) g[L.fx + e] = valid ? M::JAC_CONST_FX[0][e % (n * n)] : 0.0;
+        for (int e = tid; e < N * n * m; e += 256) g[L.fu + e] = valid ? M::JAC_CONST_FU[0][e % (n * m)] : 0.0;
+        for (int e = tid; e < T * n * n; e += 256) g[L.gxx + e] = 0.0;
+        for (int e = tid; e < N * m * m; e += 256) g[L.guu + e] = 0.0;
+        for (int e = tid; e < N * m * n; e += 256) g[L.gux + e] = 0.0;
+        __syncthreads();
+        if (valid)
+            for (int e = tid; e < N * LD::JV; e += 256) {
+                const int t = e / (LD::JV > 0 ? LD::JV : 1), q = e % (LD::JV > 0 ? LD::JV : 1), idx = M::JAC_VAR_IDX[q];
+                if (idx < n * n) g[L.fx + t * n * n + idx] = g[L.fv + t * LD::JVP + q];
+                else g[L.fu + t * n * m + idx - n * n] = g[L.fv + t * LD::JVP + q];
+            }
+        for (int e = tid; e < T * LD::HS; e += 256) {
+            const int t = e / (LD::HS > 0 ? LD::HS : 1), q = e % (LD::HS > 0 ? LD::HS : 1), idx = M::HESS_IDX[q];
+            const double v = g[L.hc + t * LD::HSP + q];
+            if (q < LD::HXX) g[L.gxx + t * n * n + idx] = v;
+            else if (t < N && q < LD::HXX + LD::HUU) g[L.guu + t * m * m + idx] = v;
+            else if (t < N) g[L.gux + t * m * n + idx] = v;
+        }
+    } else {
+        for (int e = tid; e < N * LD::JV; e += 256) {
+            const int t = e / (LD::JV > 0 ? LD::JV : 1), q = e % (LD::JV > 0 ? LD::JV : 1), idx = M::JAC_VAR_IDX[q];
+            g[L.fv + t * LD::JVP + q] = idx < n * n ? g[L.fx + t * n * n + idx] : g[L.fu + t * n * m + idx - n * n];
+        }
+        for (int e = tid; e < T * LD::HS; e += 256) {
+            const int t = e / (LD::HS > 0 ? LD::HS : 1), q = e % (LD::HS > 0 ? LD::HS : 1), idx = M::HESS_IDX[q];
+            double v = 0.0;
+            if (q < LD::HXX) v = g[L.gxx + t * n * n + idx];
+            else if (t < N && q < LD::HXX + LD::HUU) v = g[L.guu + t * m * m + idx];
+            else if (t < N) v = g[L.gux + t * m * n + idx];
+            g[L.hc + t * LD::HSP + q] = v;
+        }
+    }
 }
 
 }  // namespace ilqr

@@ -14,7 +14,8 @@ enum {
     S_OBJECTIVE = 0, S_MAX_VIOLATION, S_STEP_SIZE, S_STATUS, S_ITERATIONS, S_GRADIENT_NORM,
     S_OUTER_ITERATIONS, S_POTRF_INFO, S_ROLLOUTS, S_STATES_EQ_NOMINAL,
     S_PROF = 10,        // ..15: per-phase cycle counters of an ILQR_PROFILE build
-    S_JAC_CONST = 16,   // large path: the constant entries of this instance's fx/fu buffers are in place
+    S_JAC_VALID = 16,   // large path: the Jacobians have been evaluated (or set by the host) since the last reset — the full
+                        // jacobian_state / jacobian_action arrays are then the generated constant tables plus the compact entries
     S_DONE = 17,        // host-stepped AL loop only: instance finished
     S_DELTA = 18,       // delta_grad_product = ∇Lᵀ·Δz of the last forward_pass! (src/forward_pass.jl:20)
     S_TRACE_LEN = 19,   // rows of the per-iteration trace written by the last solve
@@ -36,10 +37,15 @@ struct Layout {
     int lds_doubles_slim;                                               // ... without fx, fu (throughput variant)
     int ring;                                                           // LDS: two half-rings of RING_STEPS x {Quu, Qux, ux_tmp} (4x4 each)
     int gxx, guu, gux, P, p, scal, gzero;                               // HBM-only set (gzero: a 0.0)
+    // large path only (0 otherwise): what the solve kernels actually stream. fv: the JV state-dependent Jacobian entries per
+    // timestep (the constant ones come from generated tables); hc: the HS structurally non-zero entries of the accumulated
+    // Hessians [gxx | guu | gux] per timestep; ab: a_t = alpha k_t + u_t and b_t = K_t x_t of the running line-search trial.
+    // The full fx, fu, gxx, guu, gux arrays above are a host-visible mirror written on demand (materialise_large_kernel).
+    int JV, HS, fv, hc, ab;
     int stride;
 };
 
-inline __host__ __device__ int pad2(int v) { return (v + 1) & ~1; }   // keep 16-B alignment
+constexpr __host__ __device__ int pad2(int v) { return (v + 1) & ~1; }   // keep 16-B alignment
 
 // Optional action-value buffers Qx, Qu, Qxx, Quu, Qux (src/data/policy.jl:58-64), written by the backward-pass STAGE
 // kernel only (parity tests; the fused solve keeps them in registers). One block of `stride` doubles per instance.
@@ -61,18 +67,18 @@ inline __host__ __device__ QLayout make_qlayout(int nx, int nu, int T) {
 inline __host__ __device__ bool is_large_model(int nx, int nu) { return nx > 4 || nu > 4; }
 // LDS staging of the large path (must match LargeDims<M>::total); the tail holds a copy of the Layout so that the
 // phase functions (real calls) take one pointer instead of twenty on the stack
-enum { LAYOUT_LDS_DOUBLES = 24 };
+enum { LAYOUT_LDS_DOUBLES = 24, LARGE_WAVES = 4, LARGE_BOUNCE = 3 * 16 * 17 };
 constexpr __host__ __device__ int large_lds_doubles(int n, int m) {
     const int NP = (n + 15) & ~15, MP = (m + 15) & ~15, ld = NP + 1, ldm = MP + 1;
-    return 3 * NP * ld + MP * ld + 4 * NP * ldm + MP * ldm + 4 * NP + 4 * MP + 8 + LAYOUT_LDS_DOUBLES;
+    return 3 * NP * ld + MP * ld + 4 * NP * ldm + MP * ldm + LARGE_BOUNCE + 2 * NP + 2 * MP + 8 + LAYOUT_LDS_DOUBLES;
 }
 
 #define ILQR_LAYOUT_FIELDS(X) X(T) X(nx) X(nu) X(nw) X(ncs) X(nct) X(C) X(xb) X(ub) X(x) X(u) X(fx) X(fu) X(gx) X(gu) X(K) X(k) X(Lx) X(Lu) \
-    X(c) X(lam) X(rho) X(act) X(w) X(zslot) X(lds_doubles) X(lds_doubles_slim) X(ring) X(gxx) X(guu) X(gux) X(P) X(p) X(scal) X(gzero) X(stride)
-enum { LAYOUT_INTS = 36 };
+    X(c) X(lam) X(rho) X(act) X(w) X(zslot) X(lds_doubles) X(lds_doubles_slim) X(ring) X(gxx) X(guu) X(gux) X(P) X(p) X(scal) X(gzero) X(JV) X(HS) X(fv) X(hc) X(ab) X(stride)
+enum { LAYOUT_INTS = 41 };
 static_assert(LAYOUT_INTS * 4 <= LAYOUT_LDS_DOUBLES * 8, "layout copy fits its LDS slot");
 
-inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, int nct, int T) {
+inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, int nct, int T, int jac_nvar = 0, int hess_nnz = 0) {
     Layout L;
     const int N = T - 1;
     L.T = T; L.nx = nx; L.nu = nu; L.nw = nw; L.ncs = ncs; L.nct = nct;
@@ -106,6 +112,13 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.p = o; o += pad2(T * nx);
     L.scal = o; o += S_COUNT;
     L.gzero = o; o += 2;
+    L.JV = 0; L.HS = 0; L.fv = L.hc = L.ab = o;
+    if (is_large_model(nx, nu)) {
+        L.JV = pad2(jac_nvar > 0 ? jac_nvar : 1); L.HS = pad2(hess_nnz > 0 ? hess_nnz : 1);
+        L.fv = o; o += N * L.JV;
+        L.hc = o; o += T * L.HS;
+        L.ab = o; o += pad2(2 * N * nu);
+    }
     L.stride = (o + 15) & ~15;   // 128-B aligned instance blocks
     return L;
 }

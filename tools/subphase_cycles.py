@@ -9,7 +9,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "synth32"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 names = sys.argv[3].split(",") if len(sys.argv) > 3 else ["stage+matvec", "gemm [T;Uh]", "gemm Qxx,Qux,Quu", "potrf", "potrs", "Uxt,P,p"]
 model, T, x1, ub = pkg.workloads.make_inputs(cfg, B)
-sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(cfg, {})))
 for _ in range(2):
     sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()
 sc = sol.buffer("_scalars"); st = sol.stats()
