@@ -524,6 +524,23 @@ def _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu):
     add("void", "dyn_rem_wave", ["const int lane"] + sig_xu + [_arr("r", n, False)], dynamics,
         [("r[%d]" % i, e) for i, e in enumerate(rem)], coop=True)
     L.append("#endif")
+    # elementwise remainder: r_i = g(x_i; u, w) with ONE expression g for every row (e.g. x⁺ = A x + B u + c sin x): the lane that
+    # owns row i evaluates g on its own state component, no cross-lane traffic at all
+    own = sp.Symbol("xl", real=True)
+    g0, elementwise = None, any(sp.sympify(r) != 0 for r in rem)
+    for i, r in enumerate(rem):
+        r = sp.sympify(r)
+        if any(s_ in r.free_symbols for k_, s_ in enumerate(xs) if k_ != i):
+            elementwise = False
+            break
+        gi = r.subs(xs[i], own)
+        if g0 is None:
+            g0 = gi
+        elif gi != g0:
+            elementwise = False
+            break
+    L.append("    static constexpr bool DYN_REM_ELEMENTWISE = %s;" % ("true" if elementwise else "false"))
+    add("double", "dyn_rem_own", ["const double xl", _arr("u", m), _arr("w", nw)], dynamics, [], ret_expr=(g0 if elementwise else sp.Integer(0)))
 
 
 

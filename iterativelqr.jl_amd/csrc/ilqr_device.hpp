@@ -1740,25 +1740,7 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
         if (lane < m) { su[lane] = ul; g[L.ub + t * m + lane] = ul; }
         wave_lds_fence();
         const double u_next = (lane < m && t + 1 < N) ? a.u_in[((size_t)b * N + t + 1) * m + lane] : 0.0;
-        double xa[n], ua[m];
-#pragma unroll
-        for (int j = 0; j < n; ++j) xa[j] = sx[j];
-#pragma unroll
-        for (int j = 0; j < m; ++j) ua[j] = su[j];
-        double y = aff[n + m];
-#pragma unroll
-        for (int j = 0; j < n; ++j) y += aff[j] * xa[j];
-#pragma unroll
-        for (int j = 0; j < m; ++j) y += aff[n + j] * ua[j];
-        if constexpr (M::DYN_HAS_REM) {
-            double w[cdim<M::NW>::v], r[n];
-            load_w<M::NW>(g + L.w, t, w);
-            M::dyn_rem_wave(lane, xa, ua, w, r);
-            double rl = r[0];
-#pragma unroll
-            for (int i = 1; i < n; ++i) rl = (lane == i) ? r[i] : rl;
-            y += rl;
-        }
+        const double y = dyn_row<M>(aff, sx, su, xl, lane, g + L.w, t);
         xl = y;
         ul = u_next;
         if (lane < n) g[L.xb + (t + 1) * n + lane] = y;

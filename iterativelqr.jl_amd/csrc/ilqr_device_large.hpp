@@ -14,7 +14,7 @@
 // potrf / potrs chain, scheduled over the four waves in four windows (one workgroup barrier each):
 //     A   waves 0,1: ûx = fuᵀP′ (the tiles the chain waits for)          waves 2,3: first half of T = fxᵀP′
 //     B   waves 0,1: Qux = ûx fx, Quu = ûx fu; wave 1: Qu = fuᵀp′ + gu   waves 2,3: rest of T
-//     C   wave 0: + guu, gux; potrf; potrs → K, k (the serial chain)      waves 1-3: Qx = fxᵀp′ + gx; Qxx = T fx + gxx (registers)
+//     C   wave 0: + guu, gux; potrf; potrs → K, k (the serial chain)      waves 1-3: Qx = fxᵀp′ + gx; Qxx = T fx + gxx into P′'s place
 //     D   wave 0: ûxt = Quu K; p, ∇L                                      waves 1-3: P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx; all: patch fx, fu
 // Every tile is one generic call (tile_mm) with run-time tile coordinates; operand fragments are read from zero-padded LDS
 // matrices with odd leading dimensions (transposition = stride pattern, no bounds checks), the MFMAs of a tile issue back to back.
@@ -40,11 +40,11 @@ struct LargeDims {
     static constexpr int HXX = M::HESS_NXX, HUU = M::HESS_NUU, HUX = M::HESS_NUX, HS = HXX + HUU + HUX, HSP = pad2(HS > 0 ? HS : 1);
     // LDS carve (doubles); must match large_lds_doubles() of ilqr_layout.hpp
     static constexpr int oFx = 0, oFu = oFx + NP * ld, oP = oFu + MP * ld, oT = oP + NP * ld, oUh = oT + NP * ld,
-                         oQux = oUh + NP * ldm, oK = oQux + NP * ldm, oUxt = oK + NP * ldm, oQuu = oUxt + NP * ldm,
-                         oBnc = oQuu + MP * ldm, oVec = oBnc + LARGE_BOUNCE, oLay = oVec + 2 * NP + 2 * MP + 8,
+                         oQux = oUh + NP * ldm, oK = oQux + (NP + 1) * ldm, oUxt = oK + (NP + 1) * ldm, oQuu = oUxt + NP * ldm,
+                         oChol = oQuu + MP * ldm, oVec = oChol + LARGE_CHOL, oLay = oVec + 2 * NP + 8,      // Qux, K: one more column for Qu, k
                          total = oLay + LAYOUT_LDS_DOUBLES;
     // forward sweep: fx, fu keep their place (sensitivity recursion); behind them the sweep's vectors and the K ring
-    static constexpr int oFw = oP, oRing = oFw + 2 * NP + 2 * MP, ringDoubles = oLay - oRing;
+    static constexpr int oFw = oP, oRing = oFw + 2 * NP + 2 * MP, ringDoubles = oVec - oRing;
     static constexpr int CH = ringDoubles / (2 * m * n) < 32 ? ringDoubles / (2 * m * n) : 32;     // timesteps per ring half
     static_assert(CH >= 1, "LDS ring of the forward sweep holds at least one timestep of K per half");
 };
@@ -327,6 +327,94 @@ __device__ __forceinline__ void reset_model_objective_large(Inst<M>& I, bool lit
     __syncthreads();
 }
 
+// v + (v of the partner row of the 16-lane row pair (0,1), (2,3)) and v + (v of the other 32-lane half): gfx950 v_permlane16_swap /
+// v_permlane32_swap, no LDS crossbar trip. swap(v, v) = {[r0 r0 r2 r2], [r1 r1 r3 r3]} resp. {[lo lo], [hi hi]}, so every lane
+// adds the two partial sums in the same order.
+__device__ __forceinline__ double sum_row_pairs(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double sum_halves(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double sum_quarters(double v) { return sum_halves(sum_row_pairs(v)); }   // (r0 + r1) + (r2 + r3)
+
+// potrf('U') on the common path, column c = lane & 15 of the matrix on every lane of the four 16-lane rows (four identical
+// copies): the entries of column j a lane needs arrive by ONE v_mov_b64_dpp row_newbcast each and stay in VGPRs; no compare
+// steers the pivots — the factorisation runs through and reports whether every pivot was positive. If not (rare: diverged
+// instances) the caller repeats it with potrf_U_lanes, which reproduces what dpotf2 leaves behind after a failure.
+template <int m, int J = 0>
+__device__ __forceinline__ void potrf_U_rows_step(double (&a)[m], double (&R)[m], int col, bool& bad) {
+    if constexpr (J < m) {
+        double v = a[J];
+#pragma unroll
+        for (int l = 0; l < J; ++l) v -= row_bcast<J>(a[l]) * a[l];             // A(j,c) - sum_l U(l,j) U(l,c); on lane j: the pivot
+        const double ajj = row_bcast<J>(v);
+        bad = bad || !(ajj > 0.0);
+        double d, r;
+        sqrt_rsqrt_fast(ajj, d, r);
+        a[J] = (col == J) ? d : v * r;
+        R[J] = r;
+        potrf_U_rows_step<m, J + 1>(a, R, col, bad);
+    }
+}
+template <int m>
+__device__ __forceinline__ bool potrf_U_rows(double (&a)[m], double (&R)[m], int col) {
+    bool bad = false;
+    potrf_U_rows_step<m, 0>(a, R, col, bad);
+    return bad;
+}
+// potrf('U') with column c of the matrix on lane c (a[i] = A(i, c), i <= c): dpotf2 order, element for element the arithmetic of
+// potrf_U (ilqr_device.hpp) — there every lane repeats the whole factorisation (m^3/3 FMAs on the serial chain), here a lane
+// updates its own column and the entries of column j it needs arrive by v_readlane: 3 instructions per (pivot, row) pair
+// instead of one per (pivot, row, column) triple. R[j] = 1 / U(j,j), wave-uniform. Returns LAPACK's info.
+template <int m>
+__device__ __forceinline__ int potrf_U_lanes(double (&a)[m], double (&R)[m], int lane) {
+    int info = 0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+        double v = a[j];
+#pragma unroll
+        for (int l = 0; l < j; ++l) v -= lane_bcast(a[l], j) * a[l];        // A(j,c) - sum_l U(l,j) U(l,c); on lane j: the pivot
+        const double ajj = lane_bcast(v, j);
+        const bool ok = (info == 0) && (ajj > 0.0);
+        const bool fail_now = (info == 0) && !(ajj > 0.0);
+        info = fail_now ? j + 1 : info;
+        double d, r;
+        sqrt_rsqrt_fast(ok ? ajj : 1.0, d, r);
+        if (__builtin_expect(!ok, 0)) {                                       // rare (diverged instances): what potrf_U leaves behind
+            d = fail_now ? ajj : lane_bcast(a[j], j);
+            r = 1.0 / d;
+        }
+        a[j] = (lane == j) ? d : (ok ? v * r : a[j]);
+        R[j] = r;
+    }
+    return info;
+}
+// potrs('U') with the factor in LDS (column c at U + c m, broadcast reads) and the inverted diagonal R; one right-hand side per lane
+template <int m>
+__device__ __forceinline__ void potrs_U_lds(const double* U, const double (&R)[m], double (&b)[m]) {
+#pragma unroll
+    for (int i = 0; i < m; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int l = 0; l < i; ++l) v -= U[i * m + l] * b[l];
+        b[i] = v * R[i];
+    }
+#pragma unroll
+    for (int i = m - 1; i >= 0; --i) {
+        double v = b[i];
+#pragma unroll
+        for (int l = i + 1; l < m; ++l) v -= U[l * m + i] * b[l];
+        b[i] = v * R[i];
+    }
+}
+
 // ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles, four waves)
 struct RiccatiOut {
     double gradient_norm; int potrf_info;
@@ -343,7 +431,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     constexpr int NQ = TN * TN;                            // tiles of T, Qxx, P
     constexpr int EJ = (JV + NT - 1) / NT > 0 ? (JV + NT - 1) / NT : 1;            // Jacobian patch entries per thread
     constexpr int EU = (HUU + HUX + 63) / 64 > 0 ? (HUU + HUX + 63) / 64 : 1;      // guu / gux entries per lane of wave 0
-    constexpr int SLOTS = (NQ + 2) / 3;                    // Qxx / P tiles per owner wave (waves 1..3)
+    constexpr int SLOTS = (NQ + 2) / 3;                    // Qxx tiles per wave in window C (waves 1..3)
     static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
     static_assert(LD::total == large_lds_doubles(n, m), "LDS carve and host-side size disagree");
     static_assert(waves_of<M>::value == LARGE_WAVES, "the Riccati step is scheduled over four waves per instance");
@@ -359,8 +447,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     double* S = lds_dyn;
     double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *sP = S + LD::oP, *sT = S + LD::oT, *sUh = S + LD::oUh, *sQux = S + LD::oQux,
            *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
-    double *sp = S + LD::oVec, *sQx = sp + NP, *sQu = sQx + NP, *sk = sQu + LD::MP, *sOut = sk + LD::MP;
-    double* bnc = S + LD::oBnc + (wave > 0 ? wave - 1 : 0) * (16 * 17);        // this wave's 16x16 bounce tile (waves 1..3)
+    double *sp = S + LD::oVec, *sQx = sp + NP, *sOut = sQx + NP;
+    double *sQu = sQux + NP * ldm, *sk = sK + NP * ldm;              // Qu and k ride along as column NP of Qux and K
+    double* sU = S + LD::oChol;                                            // the Cholesky factor, column c at sU + c m
 
     // ---- prologue: zero padding, constant Jacobian entries, P[H] = gxx[H], p[H] = gx[H]   (:39-40)
     for (int e = tid; e < LD::oVec; e += NT) S[e] = 0.0;
@@ -397,13 +486,13 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             uoff[j] = (q < HUU ? LD::oQuu : LD::oQux) + (idx / m) * ldm + idx % m;
         }
     }
-    // Qxx / P tiles of this wave (waves 1..3): slot s holds tile q = (wave - 1) + 3 s; its gxx entries sit at
+    // Qxx tiles of this wave in window C (waves 2, 3, 1 in turn): slot s holds tile q = (wave + 1) % 3 + 3 s; its gxx entries sit at
     // [HESS_XX_TILE_START[q], HESS_XX_TILE_START[q + 1]) of the compact row, lane x of them at +lane (+64, ...)
     constexpr int EXT = 4;                                 // a 16x16 tile has at most 256 entries
     int xcnt[SLOTS], xbeg[SLOTS], xoff[SLOTS][EXT];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const int q = (wave - 1) + 3 * s;
+        const int q = (wave + 1) % 3 + 3 * s;
         const bool have = wave >= 1 && q < NQ;
         xbeg[s] = have ? M::HESS_XX_TILE_START[have ? q : 0] : 0;
         xcnt[s] = have ? M::HESS_XX_TILE_START[(have ? q : 0) + 1] - xbeg[s] : 0;
@@ -413,7 +502,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             const int e = lane + 64 * x;
             if (e < xcnt[s]) {
                 const int idx = M::HESS_IDX[xbeg[s] + e];
-                xoff[s][x] = ((idx / n) & 15) * 17 + ((idx % n) & 15);
+                xoff[s][x] = LD::oP + (idx / n) * ld + idx % n;
             }
         }
     }
@@ -498,8 +587,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                     const int l = lk * JP + q;
                     if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
                 }
-                acc += __shfl_xor(acc, 16);
-                acc += __shfl_xor(acc, 32);
+                acc = sum_quarters(acc);
                 const double gu_v = n > 32 ? __shfl(gu_hi, li) : __shfl(gv, 32 + li);
                 if (lane < m) sQu[lane] = acc + gu_v;
             }
@@ -513,7 +601,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         __syncthreads();                                                  // (B2) Qux, Quu, Qu, T complete
         ILQR_SUB_MARK(I, 1);
         // ------------------------------------------------ window C: the serial chain | Qx, Qxx
-        double4_t qxx[SLOTS];
         if (wave == 0) {
             // Quu += guu, Qux += gux (:59, :64): the structurally non-zero entries only
 #pragma unroll
@@ -525,31 +612,41 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 for (int e = lane; e < m * m; e += 64) Qv[QL.Quu + (size_t)t * m * m + e] = sQuu[(e / m) * ldm + e % m];
                 if (lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
             }
-            // potrf('U') on wave-uniform registers (info ignored, :68-69)
-            double Uc[m * m], Ur[m];
+            // potrf('U'), column c of Quu on lanes c, c + 16, ... (info ignored, :68-69); the factor goes to LDS for the solves
+            double Ua[m], Ur[m];
+            const int ucol = li < m ? li : m - 1;
 #pragma unroll
-            for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) Ua[i] = sQuu[ucol * ldm + i];
+            if (__builtin_expect(potrf_U_rows<m>(Ua, Ur, li), 0)) {
 #pragma unroll
-                for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? sQuu[j * ldm + i] : 0.0;
-            const int info = potrf_U<m>(Uc, Ur);
-            if (info != 0 && potrf_info == 0) potrf_info = info;
+                for (int i = 0; i < m; ++i) Ua[i] = sQuu[ucol * ldm + i];
+                const int info = potrf_U_lanes<m>(Ua, Ur, lane);
+                if (info != 0 && potrf_info == 0) potrf_info = info;
+            }
+            if (lane < m) {
+#pragma unroll
+                for (int i = 0; i < m; ++i) sU[lane * m + i] = Ua[i];
+            }
+            wave_lds_fence();
             ILQR_SUB_MARK(I, 2);
-            // potrs('U'): column j of Qux per lane, Qu on lane n   (:70-75)
+            // potrs('U'): column j of [Qux | Qu] per lane (Qu is column NP of the LDS matrix, k of K's)   (:70-75)
             // (nx = 64 leaves no lane for k: a second pass on lane 0)
 #pragma unroll
             for (int pass = 0; pass < (n < 64 ? 1 : 2); ++pass) {
                 const bool mine = n < 64 ? lane <= n : (pass == 0 || lane == 0);
                 if (mine) {
                     const int j = (n < 64 || pass == 0) ? lane : n;
+                    const int col = j < n ? j : NP;
                     double b[m];
 #pragma unroll
-                    for (int i = 0; i < m; ++i) b[i] = j < n ? sQux[j * ldm + i] : sQu[i];
-                    potrs_U_rdiag<m, 1>(Uc, Ur, b);       // inverted diagonal from the factorisation: no divisions here
+                    for (int i = 0; i < m; ++i) b[i] = sQux[col * ldm + i];
+                    potrs_U_lds<m>(sU, Ur, b);            // inverted diagonal from the factorisation: no divisions here
+                    gdbl* dst = j < n ? A.K + (size_t)t * m * n + j * m : A.k + t * m;
 #pragma unroll
                     for (int i = 0; i < m; ++i) {
                         const double v = b[i] * -1.0;
-                        if (j < n) { sK[j * ldm + i] = v; A.K[(size_t)t * m * n + j * m + i] = v; }
-                        else { sk[i] = v; A.k[t * m + i] = v; }
+                        sK[col * ldm + i] = v;
+                        dst[i] = v;
                     }
                 }
             }
@@ -566,7 +663,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         const int l = h * JP + q;
                         if ((n % 2 == 0) || l < n) acc += sFx[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
                     }
-                    acc += __shfl_xor(acc, 32);
+                    acc = sum_halves(acc);
                     if (lane < n) sQx[lane] = acc + gv;
                 } else {
                     const int i = lane < n ? lane : n - 1;
@@ -577,31 +674,27 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
                 if (STORE_VALUE && Qv != nullptr && lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
             }
-            // Qxx = T fx + gxx (:53-54): stays in this wave's registers until P; gxx through the wave's bounce tile
+            // Qxx = T fx + gxx (:53-54), written where P′ was (nobody reads P′ after window B); the wave that stored a tile adds
+            // the tile's own gxx entries
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                const int q = (wave - 1) + 3 * s;
-                qxx[s] = double4_t{0, 0, 0, 0};
+                const int q = (wave + 1) % 3 + 3 * s;
                 if (q < NQ) {
                     const int a = q / TN, c = q % TN;
-                    double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
+                    const double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
+                    tile_store<ld>(sP, acc, 16 * a, 16 * c, li, lk);
                     if (xcnt[s] > 0) {
-                        tile_store<17>(bnc, acc, 0, 0, li, lk);
                         wave_lds_fence();
 #pragma unroll
                         for (int x = 0; x < EXT; ++x)
-                            if (xoff[s][x] >= 0) bnc[xoff[s][x]] += xval[s][x];
-                        wave_lds_fence();
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[r] = bnc[li * 17 + lk + 4 * r];
-                        wave_lds_fence();
+                            if (xoff[s][x] >= 0) S[xoff[s][x]] += xval[s][x];
                     }
-                    qxx[s] = acc;
                     if (STORE_VALUE && Qv != nullptr) {
+                        wave_lds_fence();
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
-                            if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = acc[r];
+                            if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = sP[col * ld + row];
                         }
                     }
                 }
@@ -614,6 +707,47 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
             for (int j = 0; j < EJ; ++j)
                 if (poff[j] >= 0) S[poff[j]] = pval[j];
+        }
+        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order, tile q on wave 1 + q % 3 (wave 0 has the
+        // vector chain); ux_tmp = Quu K (:79) comes out of its MFMAs in exactly the layout the next MFMA's B operand wants
+        // (k = lane>>4 + 4 reg, j = lane&15). All fragments of a tile are read first, then its eight MFMAs issue back to back.
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int q = (wave - 1) + 3 * s;
+            if (wave >= 1 && q < NQ) {
+                constexpr int KS = m4 / 4;
+                const int a = q / TN, c = q % TN;
+                const double* pKa = sK + ldm * (16 * a + li) + lk;                     // A(i,k) = K[k][16a + i]
+                const double* pKc = sK + ldm * (16 * c + li) + lk;                     // B(k,j) = K[k][16c + j]
+                const double* pQa = sQux + ldm * (16 * a + li) + lk;                   // A(i,k) = Qux[k][16a + i]
+                const double* pQc = sQux + ldm * (16 * c + li) + lk;                   // B(k,j) = Qux[k][16c + j]
+                const double* pU = sQuu + li + ldm * lk;                               // A(i,k) = Quu[i][k]
+                const double* pq = sP + (16 * c + li) * ld + 16 * a + lk;              // Qxx tile (D layout)
+                double fKa[KS], fKc[KS], fQa[KS], fQc[KS], fU[KS];
+                double4_t qxx;
+#pragma unroll
+                for (int sx = 0; sx < KS; ++sx) { fU[sx] = pU[4 * ldm * sx]; fKc[sx] = pKc[4 * sx]; fKa[sx] = pKa[4 * sx]; fQc[sx] = pQc[4 * sx]; fQa[sx] = pQa[4 * sx]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qxx[r] = pq[4 * r];
+                double4_t ux = double4_t{0, 0, 0, 0}, acc = double4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int sx = 0; sx < KS; ++sx) ux = __builtin_amdgcn_mfma_f64_16x16x4f64(fU[sx], fKc[sx], ux, 0, 0, 0);
+#pragma unroll
+                for (int sx = 0; sx < KS; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fKa[sx], ux[sx], acc, 0, 0, 0);
+#pragma unroll
+                for (int sx = 0; sx < KS; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fKa[sx], fQc[sx], acc, 0, 0, 0);
+#pragma unroll
+                for (int sx = 0; sx < KS; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fQa[sx], fKc[sx], acc, 0, 0, 0);
+                const double4_t v = acc + qxx;
+                tile_store<ld>(sP, v, 16 * a, 16 * c, li, lk);
+                if (STORE_VALUE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
+                        if (row < n && col < n) A.P[(size_t)t * n * n + col * n + row] = v[r];
+                    }
+                }
+            }
         }
         if (wave == 0) {
             // ux_tmp = Quu K (:79) for the vector chain, in this wave's own buffer
@@ -641,34 +775,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             if (lane < m) {
                 gmax = nanmax(gmax, fabs(sQu[lane]));
                 A.Lu[t * m + lane] = sQu[lane];
-            }
-        } else {
-            // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order; ux_tmp = Quu K (:79) comes out
-            // of its MFMAs in exactly the layout the next MFMA's B operand wants (k = lane>>4 + 4 reg, j = lane&15)
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int q = (wave - 1) + 3 * s;
-                if (q < NQ) {
-                    const int a = q / TN, c = q % TN;
-                    const double4_t ux = tile_mm<m4, 1, ldm, 1, ldm>(sQuu, sK + ldm * 16 * c, li, lk);
-                    double4_t acc = double4_t{0, 0, 0, 0};
-                    {
-                        const double* pa = sK + ldm * (16 * a + li) + lk;                  // A(i,k) = K[k][i]
-#pragma unroll
-                        for (int sx = 0; sx < m4 / 4; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * sx], ux[sx], acc, 0, 0, 0);
-                    }
-                    acc = tile_mm<m4, ldm, 1, 1, ldm>(sK + ldm * 16 * a, sQux + ldm * 16 * c, li, lk, acc);
-                    acc = tile_mm<m4, ldm, 1, 1, ldm>(sQux + ldm * 16 * a, sK + ldm * 16 * c, li, lk, acc);
-                    const double4_t v = acc + qxx[s];
-                    tile_store<ld>(sP, v, 16 * a, 16 * c, li, lk);
-                    if (STORE_VALUE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
-                            if (row < n && col < n) A.P[(size_t)t * n * n + col * n + row] = v[r];
-                        }
-                    }
-                }
             }
         }
 #pragma unroll
@@ -724,25 +830,155 @@ __device__ __forceinline__ double kx_partial(const double* Kt, const double* xv,
         const int j = lk * JP + q;
         if ((n % 4 == 0) || j < n) acc += Kt[(j < n ? j : 0) * m + i] * xv[j < n ? j : 0];
     }
-    acc += __shfl_xor(acc, 16);
-    acc += __shfl_xor(acc, 32);
-    return acc;
+    return sum_quarters(acc);
+}
+
+// row `lane` of x⁺ = f(x, u) (src/rollout.jl:29): affine part from the lane's coefficient row, remainder either elementwise on
+// the lane's own component (M::dyn_rem_own) or through the generated wave-cooperative code
+template <class M>
+__device__ __forceinline__ double dyn_row(const double (&aff)[M::NX + M::NU + 1], const double* sx, const double* su, double xl, int lane,
+                                          const double* W, int t) {
+    constexpr int n = M::NX, m = M::NU;
+    double ua[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) ua[j] = su[j];
+    double y = aff[n + m];
+#pragma unroll
+    for (int j = 0; j < n; ++j) y += aff[j] * sx[j];
+#pragma unroll
+    for (int j = 0; j < m; ++j) y += aff[n + j] * ua[j];
+    if constexpr (M::DYN_HAS_REM) {
+        double w[cdim<M::NW>::v];
+        load_w<M::NW>(W, t, w);
+        if constexpr (M::DYN_REM_ELEMENTWISE) {
+            y += M::dyn_rem_own(xl, ua, w);
+        } else {
+            double xa[n], r[n];
+#pragma unroll
+            for (int j = 0; j < n; ++j) xa[j] = sx[j];
+            M::dyn_rem_wave(lane, xa, ua, w, r);
+            double rl = r[0];
+#pragma unroll
+            for (int i = 1; i < n; ++i) rl = (lane == i) ? r[i] : rl;
+            y += rl;
+        }
+    }
+    return y;
+}
+
+// wave 0: the closed-loop rollout, one chunk of the K ring per workgroup barrier
+template <class M>
+__attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
+    typedef LargeDims<M> LD;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, CH = LD::CH, KN = m * n;
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    const LargeArgs A = large_args_from_lds<M>(base);
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, N = A.N;
+    double *sx = lds_dyn + LD::oFw, *su = sx + NP, *ring = lds_dyn + LD::oRing;
+    const int row = lane < n ? lane : n - 1;
+    double aff[n + m + 1];
+#pragma unroll
+    for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
+    double xl = lane < n ? A.xb[lane] : 0.0;                                  // x[1] = x̄[1]  (:19)
+    if (lane < n) A.x[lane] = xl;
+    double a_t = 0.0, b_t = 0.0;
+    if (N > 0 && lane < m) { a_t = A.ab[lane]; b_t = A.ab[m + lane]; }
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
+        for (int t = c0; t < c1; ++t) {
+            const double* Kt = ring + (t % (2 * CH)) * KN;
+            if (lane < n) sx[lane] = xl;
+            wave_lds_fence();
+            const int t1 = t + 1 < N ? t + 1 : t;
+            const double a_n = lane < m ? A.ab[2 * t1 * m + lane] : 0.0, b_n = lane < m ? A.ab[(2 * t1 + 1) * m + lane] : 0.0;
+            const double acc = kx_partial<M>(Kt, sx, li, lk);
+            double v = a_t;                                                   // α k + ū   (:24-26)
+            v += acc;                                                         // + K x      (:27)
+            v += -1.0 * b_t;                                                  // − K x̄     (:28)
+            if (lane < m) { su[lane] = v; A.u[t * m + lane] = v; }
+            wave_lds_fence();
+            const double y = dyn_row<M>(aff, sx, su, xl, lane, (const double*)A.w, t);      // (:29)
+            xl = y;
+            a_t = a_n; b_t = b_n;
+            if (lane < n) A.x[(t + 1) * n + lane] = y;
+            wave_lds_fence();
+        }
+        __syncthreads();
+    }
+}
+
+// wave 1 on the first line-search trial: Δu = k + KΔx on lanes 0..m-1 (quarter sums like the rollout), Δx⁺ = fuΔu + fxΔx one row
+// per lane, and gradientᵀ·Δz along the way (src/data/methods.jl:42-54, src/forward_pass.jl:20)
+template <class M>
+__attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
+    typedef LargeDims<M> LD;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, CH = LD::CH, KN = m * n, JV = LD::JV, JVP = LD::JVP;
+    constexpr int EJ = (JV + 63) / 64 > 0 ? (JV + 63) / 64 : 1;
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    const LargeArgs A = large_args_from_lds<M>(base);
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, N = A.N;
+    double* S = lds_dyn;
+    double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *zx = S + LD::oFw + NP + MP, *zu = zx + NP, *ring = S + LD::oRing;
+    int poff[EJ];
+    double pval[EJ], dpart = 0.0, kv = 0.0, Luv = 0.0, Lxv = 0.0;
+    const int ui = lane < m ? lane : m - 1, xi = lane < n ? lane : n - 1;
+#pragma unroll
+    for (int j = 0; j < EJ; ++j) {
+        const int q = lane + 64 * j;
+        poff[j] = -1; pval[j] = 0.0;
+        if (q < JV) {
+            const int idx = M::JAC_VAR_IDX[q];
+            poff[j] = idx < n * n ? LD::oFx + (idx / n) * ld + idx % n : LD::oFu + ((idx - n * n) / n) * ld + (idx - n * n) % n;
+            if (N > 0) pval[j] = A.fv[q];
+        }
+    }
+    if (lane < n) zx[lane] = 0.0;
+    if (N > 0) { kv = A.k[ui]; Luv = A.Lu[ui]; Lxv = A.Lx[xi]; }
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
+        for (int t = c0; t < c1; ++t) {
+            const double* Kt = ring + (t % (2 * CH)) * KN;
+#pragma unroll
+            for (int j = 0; j < EJ; ++j)
+                if (poff[j] >= 0) S[poff[j]] = pval[j];
+            wave_lds_fence();
+            const int t1 = t + 1 < N ? t + 1 : t;
+#pragma unroll
+            for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)t1 * JVP + lane + 64 * j] : 0.0;
+            const double kv_n = A.k[t1 * m + ui], Luv_n = A.Lu[t1 * m + ui], Lxv_n = A.Lx[t1 * n + xi];
+            const double acc = kx_partial<M>(Kt, zx, li, lk);
+            const double du = kv + acc;
+            const double zown = zx[xi];
+            if (lane < m) { zu[lane] = du; dpart += Luv * du; }
+            if (lane < n) dpart += Lxv * zown;
+            wave_lds_fence();
+            double a1 = 0.0, a2 = 0.0;                                        // Δx⁺ = fu Δu + fx Δx
+#pragma unroll
+            for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * zu[j];
+#pragma unroll
+            for (int j = 0; j < n; ++j) a2 += sFx[j * ld + xi] * zx[j];
+            wave_lds_fence();
+            if (lane < n) zx[lane] = a1 + a2;
+            kv = kv_n; Luv = Luv_n; Lxv = Lxv_n;
+            wave_lds_fence();
+        }
+        __syncthreads();
+    }
+    return wave_sum(dpart);
 }
 
 template <class M>
 __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, double alpha, int want_delta) {
     typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, NT = LD::NT, CH = LD::CH, KN = m * n, JV = LD::JV, JVP = LD::JVP;
-    constexpr int EJ = (JV + 63) / 64 > 0 ? (JV + 63) / 64 : 1;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, NT = LD::NT, CH = LD::CH, KN = m * n;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
     want_delta = __builtin_amdgcn_readfirstlane(want_delta);
     const int N = A.N;
     double* S = lds_dyn;
-    double *sFx = S + LD::oFx, *sFu = S + LD::oFu;
-    double *sx = S + LD::oFw, *su = sx + NP, *zx = su + MP, *zu = zx + NP, *ring = S + LD::oRing;
-    double* sOut = S + LD::oVec + 2 * NP + 2 * MP;
+    double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *ring = S + LD::oRing;
+    double* sOut = S + LD::oVec + 2 * NP;
     // ---- a_t, b_t for every timestep (wave per timestep, same lane mapping as the rollout's K x)
     for (int t = wave; t < N; t += LD::W) {
         const int i = li < m ? li : m - 1;
@@ -753,8 +989,7 @@ __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, d
             const int j = lk * JP + q;
             if ((n % 4 == 0) || j < n) acc += A.K[(size_t)t * KN + (j < n ? j : 0) * m + i] * A.xb[t * n + (j < n ? j : 0)];
         }
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
+        acc = sum_quarters(acc);
         if (lane < m) {
             double v = A.k[t * m + lane] * alpha;                         // (:24-25)
             v += A.ub[t * m + lane];                                      // (:26)
@@ -769,7 +1004,6 @@ __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, d
         for (int e = tid; e < n * n; e += NT) sFx[(e / n) * ld + e % n] = M::JAC_CONST_FX[0][e];
         for (int e = tid; e < n * m; e += NT) sFu[(e / n) * ld + e % n] = M::JAC_CONST_FU[0][e];
     }
-    // ring: chunk 0
     auto stage = [&](int c0, int nthreads, int me) {                      // K[c0 .. c0 + CH) into the ring half (c0 / CH) & 1
         const int steps = (N - c0) < CH ? (N - c0) : CH;
         double* dst = ring + ((c0 / CH) & 1) * CH * KN;
@@ -777,116 +1011,17 @@ __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, d
         for (int e = me; e < steps * KN; e += nthreads) dst[e] = src[e];
     };
     if (N > 0) stage(0, NT, tid);
-    __syncthreads();                                                      // a_t, b_t (global, this workgroup only) and ring visible
-    __threadfence_block();
+    __syncthreads();                                                      // a_t, b_t (global, this workgroup only) and the ring visible
     double d = 0.0;
-    // wave 0 state
-    const int row = lane < n ? lane : n - 1;
-    double aff[n + m + 1];
-    double xl = 0.0, a_t = 0.0, b_t = 0.0;
-    // wave 1 state
-    int poff[EJ];
-    double pval[EJ], dpart = 0.0, kv = 0.0, Luv = 0.0, Lxv = 0.0;
-    const int ui = lane < m ? lane : m - 1, xi = lane < n ? lane : n - 1;
-    if (wave == 0) {
-#pragma unroll
-        for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
-        xl = lane < n ? A.xb[lane] : 0.0;                                 // x[1] = x̄[1]  (:19)
-        if (lane < n) A.x[lane] = xl;
-        if (N > 0 && lane < m) { a_t = A.ab[lane]; b_t = A.ab[m + lane]; }
-    } else if (wave == 1 && want_delta) {
-#pragma unroll
-        for (int j = 0; j < EJ; ++j) {
-            const int q = lane + 64 * j;
-            poff[j] = -1; pval[j] = 0.0;
-            if (q < JV) {
-                const int idx = M::JAC_VAR_IDX[q];
-                poff[j] = idx < n * n ? LD::oFx + (idx / n) * ld + idx % n : LD::oFu + ((idx - n * n) / n) * ld + (idx - n * n) % n;
-                if (N > 0) pval[j] = A.fv[q];
-            }
+    if (wave == 0) fw_rollout_wave<M>(base);
+    else if (wave == 1 && want_delta) d = fw_delta_wave<M>(base);
+    else {
+        const int first = want_delta ? 2 : 1, cnt = LD::W - first;        // the stagers: next chunk into the other ring half
+        for (int c0 = 0; c0 < N; c0 += CH) {
+            if (c0 + CH < N) stage(c0 + CH, 64 * cnt, tid - 64 * first);
+            __syncthreads();
         }
-        if (lane < n) zx[lane] = 0.0;
-        if (N > 0) { kv = A.k[ui]; Luv = A.Lu[ui]; Lxv = A.Lx[xi]; }
     }
-    for (int c0 = 0; c0 < N; c0 += CH) {
-        const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
-        if (wave == 0) {
-            for (int t = c0; t < c1; ++t) {
-                const double* Kt = ring + (t % (2 * CH)) * KN;
-                if (lane < n) sx[lane] = xl;
-                wave_lds_fence();
-                const int t1 = t + 1 < N ? t + 1 : t;
-                const double a_n = lane < m ? A.ab[2 * t1 * m + lane] : 0.0, b_n = lane < m ? A.ab[(2 * t1 + 1) * m + lane] : 0.0;
-                double xa[n];
-#pragma unroll
-                for (int j = 0; j < n; ++j) xa[j] = sx[j];
-                const double acc = kx_partial<M>(Kt, sx, li, lk);
-                double v = a_t;                                               // α k + ū   (:24-26)
-                v += acc;                                                     // + K x      (:27)
-                v += -1.0 * b_t;                                              // − K x̄     (:28)
-                if (lane < m) { su[lane] = v; A.u[t * m + lane] = v; }
-                wave_lds_fence();
-                double ua[m];
-#pragma unroll
-                for (int j = 0; j < m; ++j) ua[j] = su[j];
-                double y = aff[n + m];                                        // (:29) row `lane` of the dynamics
-#pragma unroll
-                for (int j = 0; j < n; ++j) y += aff[j] * xa[j];
-#pragma unroll
-                for (int j = 0; j < m; ++j) y += aff[n + j] * ua[j];
-                if constexpr (M::DYN_HAS_REM) {
-                    double w[cdim<M::NW>::v], r[n];
-                    load_w<M::NW>((const double*)A.w, t, w);
-                    M::dyn_rem_wave(lane, xa, ua, w, r);
-                    double rl = r[0];
-#pragma unroll
-                    for (int i = 1; i < n; ++i) rl = (lane == i) ? r[i] : rl;
-                    y += rl;
-                }
-                xl = y;
-                a_t = a_n; b_t = b_n;
-                if (lane < n) A.x[(t + 1) * n + lane] = y;
-                wave_lds_fence();
-            }
-        } else if (wave == 1 && want_delta) {
-            // Δu = k + KΔx on lanes 0..m-1 (quarter sums like the rollout), Δx⁺ = fuΔu + fxΔx one row per lane
-            for (int t = c0; t < c1; ++t) {
-                const double* Kt = ring + (t % (2 * CH)) * KN;
-#pragma unroll
-                for (int j = 0; j < EJ; ++j)
-                    if (poff[j] >= 0) S[poff[j]] = pval[j];
-                wave_lds_fence();
-                const int t1 = t + 1 < N ? t + 1 : t;
-#pragma unroll
-                for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)t1 * JVP + lane + 64 * j] : 0.0;
-                const double kv_n = A.k[t1 * m + ui], Luv_n = A.Lu[t1 * m + ui], Lxv_n = A.Lx[t1 * n + xi];
-                double za[n];
-#pragma unroll
-                for (int j = 0; j < n; ++j) za[j] = zx[j];
-                const double acc = kx_partial<M>(Kt, zx, li, lk);
-                const double du = kv + acc;
-                if (lane < m) { zu[lane] = du; dpart += Luv * du; }
-                if (lane < n) dpart += Lxv * zx[xi];
-                wave_lds_fence();
-                double a1 = 0.0, a2 = 0.0;                                    // Δx⁺ = fu Δu + fx Δx
-#pragma unroll
-                for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * zu[j];
-#pragma unroll
-                for (int j = 0; j < n; ++j) a2 += sFx[j * ld + xi] * za[j];
-                wave_lds_fence();
-                if (lane < n) zx[lane] = a1 + a2;
-                kv = kv_n; Luv = Luv_n; Lxv = Lxv_n;
-                wave_lds_fence();
-            }
-        } else if (wave >= 2 || !want_delta) {
-            if (c1 < N) {                                                     // the stagers: next chunk into the other ring half
-                const int first = want_delta ? 2 : 1, cnt = LD::W - first;
-                stage(c1, 64 * cnt, tid - 64 * first);
-            }
-        }
-        __syncthreads();
-    }
-    if (wave == 1 && want_delta) d = wave_sum(dpart);
     if (want_delta) {                     // hand wave 1's scalar to all waves (identical control flow afterwards)
         if (tid == 64) sOut[2] = d;
         __syncthreads();

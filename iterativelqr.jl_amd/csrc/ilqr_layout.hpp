@@ -67,10 +67,10 @@ inline __host__ __device__ QLayout make_qlayout(int nx, int nu, int T) {
 inline __host__ __device__ bool is_large_model(int nx, int nu) { return nx > 4 || nu > 4; }
 // LDS staging of the large path (must match LargeDims<M>::total); the tail holds a copy of the Layout so that the
 // phase functions (real calls) take one pointer instead of twenty on the stack
-enum { LAYOUT_LDS_DOUBLES = 24, LARGE_WAVES = 4, LARGE_BOUNCE = 3 * 16 * 17 };
+enum { LAYOUT_LDS_DOUBLES = 24, LARGE_WAVES = 4, LARGE_CHOL = 16 * 16 };
 constexpr __host__ __device__ int large_lds_doubles(int n, int m) {
     const int NP = (n + 15) & ~15, MP = (m + 15) & ~15, ld = NP + 1, ldm = MP + 1;
-    return 3 * NP * ld + MP * ld + 4 * NP * ldm + MP * ldm + LARGE_BOUNCE + 2 * NP + 2 * MP + 8 + LAYOUT_LDS_DOUBLES;
+    return 3 * NP * ld + MP * ld + (4 * NP + 2) * ldm + MP * ldm + LARGE_CHOL + 2 * NP + 8 + LAYOUT_LDS_DOUBLES;
 }
 
 #define ILQR_LAYOUT_FIELDS(X) X(T) X(nx) X(nu) X(nw) X(ncs) X(nct) X(C) X(xb) X(ub) X(x) X(u) X(fx) X(fu) X(gx) X(gu) X(K) X(k) X(Lx) X(Lu) \
