@@ -348,7 +348,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     ilqr_handle* h = new ilqr_handle();
     h->vt = vt; h->B = d->batch; h->device = d->device; h->constrained = d->constrained ? 1 : 0;
     h->L = ilqr::make_layout(vt->nx, vt->nu, vt->nw, vt->ncs, vt->nct, d->horizon, vt->jac_nvar, vt->hess_nnz);
-    h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu) * 8
+    h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu, vt->hess_nnz) * 8
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
     h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024;

@@ -42,7 +42,8 @@ struct LargeDims {
     static constexpr int oFx = 0, oFu = oFx + NP * ld, oP = oFu + MP * ld, oT = oP + NP * ld, oUh = oT + NP * ld,
                          oQux = oUh + NP * ldm, oK = oQux + (NP + 1) * ldm, oUxt = oK + (NP + 1) * ldm, oQuu = oUxt + NP * ldm,
                          oChol = oQuu + MP * ldm, oVec = oChol + LARGE_CHOL, oLay = oVec + 2 * NP + 8,      // Qux, K: one more column for Qu, k
-                         total = oLay + LAYOUT_LDS_DOUBLES;
+                         oStg = oLay + LAYOUT_LDS_DOUBLES, STG = large_stage_doubles(n, m, HS), total = oStg + STG;
+    static constexpr bool STAGE = STG > 0;                  // next step's compact Hessian row and cost gradients staged in LDS
     // forward sweep: fx, fu keep their place (sensitivity recursion); behind them the sweep's vectors and the K ring
     static constexpr int oFw = oP, oRing = oFw + 2 * NP + 2 * MP, ringDoubles = oVec - oRing;
     static constexpr int CH = ringDoubles / (2 * m * n) < 32 ? ringDoubles / (2 * m * n) : 32;     // timesteps per ring half
@@ -71,6 +72,7 @@ __device__ __forceinline__ double4_t tile_mm(const double* Ab, const double* Bb,
     const double* pb = Bb + BK * lk + BJ * li;
 #pragma unroll
     for (int s = 0; s < KS; ++s) { fa[s] = pa[AK * 4 * s]; fb[s] = pb[BK * 4 * s]; }
+    __builtin_amdgcn_sched_barrier(0);        // all fragment reads in flight before the first MFMA: one LDS round trip per tile, not one per k-step
 #pragma unroll
     for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s], fb[s], acc, 0, 0, 0);
     return acc;
@@ -416,6 +418,62 @@ __device__ __forceinline__ void potrs_U_lds(const double* U, const double (&R)[m
 }
 
 // ---------------------------------------------------------------- backward_pass! (MFMA 16x16x4 tiles, four waves)
+// Static schedule of the tiles of one Riccati step over (window, wave). Windows end in one workgroup barrier each:
+//   A  ûx = fuᵀP′ (TN tiles, what the chain waits for)          B  Qux = ûx fx (TN), Quu = ûx fu (1)
+//   C  wave 0: the potrf / potrs chain; others Qxx = T fx + gxx  D  P tiles (waves 1..3); wave 0: p, ∇L
+// T = fxᵀP′ (NQ = TN² tiles, needed by Qxx only) fills the idle slots of A and B and, for what is left, the head of C.
+// TN = 2 (17 <= nx <= 32, e.g. synth32) is scheduled by hand so that no wave has more than one tile in A or in B:
+//   A: w0 ûx0, w1 ûx1, w2 T(0,0), w3 T(0,1)   B: w0 Qux0, w1 Qux1 (+ Qu), w2 Quu, w3 T(1,0)
+//   C: w1 Qx, Qxx(0,0); w2 Qxx(0,1); w3 T(1,1), Qxx(1,0), Qxx(1,1)   D: w1 P0, P3; w2 P1; w3 P2
+// Other sizes: critical tiles alternate over waves 0, 1; T tiles over waves 2, 3 (half in A, half in B); Qxx / P over waves 1..3.
+enum { RIC_UH = 1 << 5, RIC_T = 2 << 5, RIC_QUX = 3 << 5, RIC_QUU = 4 << 5, RIC_END = 0xff };   // task byte: kind << 5 | tile index
+template <int TN>
+struct RicSchedule {
+    static constexpr int NQ = TN * TN, MAXL = 8, SLOTS = (NQ + 2) / 3;       // a task list is one 64-bit word: eight task bytes
+    struct Tab {
+        int a[4][MAXL], b[4][MAXL], ct[4][MAXL], qxx[4][SLOTS], p[4][SLOTS];
+        unsigned long long wa[4], wb[4], wc[4];                               // the lists packed, RIC_END-terminated
+    };
+    static constexpr Tab make() {
+        Tab t{};
+        int na[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0}, nc[4] = {0, 0, 0, 0}, nq[4] = {0, 0, 0, 0}, np[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 4; ++w) {
+            for (int i = 0; i < MAXL; ++i) { t.a[w][i] = -1; t.b[w][i] = -1; t.ct[w][i] = -1; }
+            for (int i = 0; i < SLOTS; ++i) { t.qxx[w][i] = -1; t.p[w][i] = -1; }
+        }
+        if (TN == 2) {
+            t.a[0][na[0]++] = RIC_UH + 0; t.a[1][na[1]++] = RIC_UH + 1; t.a[2][na[2]++] = RIC_T + 0; t.a[3][na[3]++] = RIC_T + 1;
+            t.b[0][nb[0]++] = RIC_QUX + 0; t.b[1][nb[1]++] = RIC_QUX + 1; t.b[2][nb[2]++] = RIC_QUU; t.b[3][nb[3]++] = RIC_T + 2;
+            t.ct[3][nc[3]++] = RIC_T + 3;
+            t.qxx[1][nq[1]++] = 0; t.qxx[2][nq[2]++] = 1; t.qxx[3][nq[3]++] = 2; t.qxx[3][nq[3]++] = 3;
+            t.p[1][np[1]++] = 0; t.p[1][np[1]++] = 3; t.p[2][np[2]++] = 1; t.p[3][np[3]++] = 2;
+        } else {
+            for (int c = 0; c < TN; ++c) { const int w = c % 2; t.a[w][na[w]++] = RIC_UH + c; }
+            for (int v = 2; v < 4; ++v) {
+                const int cnt = (NQ - (v - 2) + 1) / 2, first = (cnt + 1) / 2;
+                for (int k = 0; k < cnt; ++k) {
+                    const int q = (v - 2) + 2 * k;
+                    if (k < first) t.a[v][na[v]++] = RIC_T + q; else t.b[v][nb[v]++] = RIC_T + q;
+                }
+            }
+            for (int i = 0; i <= TN; ++i) { const int w = i % 2; t.b[w][nb[w]++] = i < TN ? RIC_QUX + i : RIC_QUU; }
+            for (int q = 0; q < NQ; ++q) { const int w = 1 + (q + 1) % 3; t.qxx[w][nq[w]++] = q; }
+            for (int q = 0; q < NQ; ++q) { const int w = 1 + q % 3; t.p[w][np[w]++] = q; }
+        }
+        for (int w = 0; w < 4; ++w) {
+            t.wa[w] = 0; t.wb[w] = 0; t.wc[w] = 0;
+            for (int i = MAXL - 1; i >= 0; --i) {
+                t.wa[w] = (t.wa[w] << 8) | (unsigned long long)(t.a[w][i] < 0 ? RIC_END : t.a[w][i]);
+                t.wb[w] = (t.wb[w] << 8) | (unsigned long long)(t.b[w][i] < 0 ? RIC_END : t.b[w][i]);
+                t.wc[w] = (t.wc[w] << 8) | (unsigned long long)(t.ct[w][i] < 0 ? RIC_END : t.ct[w][i]);
+            }
+        }
+        return t;
+    }
+    static constexpr Tab tab = make();
+    static_assert(NQ <= 16, "tile index fits five bits; at most eight tasks per list (TN <= 4)");
+};
+
 struct RiccatiOut {
     double gradient_norm; int potrf_info;
 #if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
@@ -429,11 +487,13 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     constexpr int n = M::NX, m = M::NU, NP = LD::NP, ld = LD::ld, ldm = LD::ldm, TN = LD::TN, NT = LD::NT;
     constexpr int n4 = LD::n4, m4 = LD::m4, JV = LD::JV, JVP = LD::JVP, HXX = LD::HXX, HUU = LD::HUU, HUX = LD::HUX, HSP = LD::HSP;
     constexpr int NQ = TN * TN;                            // tiles of T, Qxx, P
-    constexpr int EJ = (JV + NT - 1) / NT > 0 ? (JV + NT - 1) / NT : 1;            // Jacobian patch entries per thread
+    constexpr int NS = NT - 64;                            // threads that fetch the next step's operands: waves 1..3 (wave 0 only stores)
+    constexpr int EJ = (JV + NS - 1) / NS > 0 ? (JV + NS - 1) / NS : 1;            // Jacobian patch entries per fetching thread
     constexpr int EU = (HUU + HUX + 63) / 64 > 0 ? (HUU + HUX + 63) / 64 : 1;      // guu / gux entries per lane of wave 0
-    constexpr int SLOTS = (NQ + 2) / 3;                    // Qxx tiles per wave in window C (waves 1..3)
+    typedef RicSchedule<TN> RS;
+    constexpr int SLOTS = RS::SLOTS;                       // Qxx / P tiles per wave (waves 1..3)
     static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
-    static_assert(LD::total == large_lds_doubles(n, m), "LDS carve and host-side size disagree");
+    static_assert(LD::total == large_lds_doubles(n, m, LD::HS), "LDS carve and host-side size disagree");
     static_assert(waves_of<M>::value == LARGE_WAVES, "the Riccati step is scheduled over four waves per instance");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
@@ -469,9 +529,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     int poff[EJ];
 #pragma unroll
     for (int j = 0; j < EJ; ++j) {
-        const int q = tid + NT * j;
+        const int q = (tid - 64) + NS * j;
         poff[j] = -1;
-        if (q < JV) {
+        if (tid >= 64 && q < JV) {
             const int idx = M::JAC_VAR_IDX[q];
             poff[j] = idx < n * n ? LD::oFx + (idx / n) * ld + idx % n : LD::oFu + ((idx - n * n) / n) * ld + (idx - n * n) % n;
         }
@@ -486,14 +546,14 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             uoff[j] = (q < HUU ? LD::oQuu : LD::oQux) + (idx / m) * ldm + idx % m;
         }
     }
-    // Qxx tiles of this wave in window C (waves 2, 3, 1 in turn): slot s holds tile q = (wave + 1) % 3 + 3 s; its gxx entries sit at
+    // Qxx tiles of this wave in window C: slot s holds tile RS::tab.qxx[wave][s]; its gxx entries sit at
     // [HESS_XX_TILE_START[q], HESS_XX_TILE_START[q + 1]) of the compact row, lane x of them at +lane (+64, ...)
     constexpr int EXT = 4;                                 // a 16x16 tile has at most 256 entries
     int xcnt[SLOTS], xbeg[SLOTS], xoff[SLOTS][EXT];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const int q = (wave + 1) % 3 + 3 * s;
-        const bool have = wave >= 1 && q < NQ;
+        const int q = RS::tab.qxx[wave][s];
+        const bool have = q >= 0;
         xbeg[s] = have ? M::HESS_XX_TILE_START[have ? q : 0] : 0;
         xcnt[s] = have ? M::HESS_XX_TILE_START[(have ? q : 0) + 1] - xbeg[s] : 0;
 #pragma unroll
@@ -514,89 +574,94 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     if (N > 0) {
 #pragma unroll
         for (int j = 0; j < EJ; ++j)
-            if (poff[j] >= 0) S[poff[j]] = A.fv[(size_t)(N - 1) * JVP + tid + NT * j];
+            if (poff[j] >= 0) S[poff[j]] = A.fv[(size_t)(N - 1) * JVP + (tid - 64) + NS * j];
     }
-    // register prefetch of step t's compact operands, one step ahead (each wave fetches what it will consume)
-    double pval[EJ], uval[EU], xval[SLOTS][EXT], gv = 0.0;
+    // Compact operands of a step: the state-dependent Jacobian entries go straight into the LDS copies of fx, fu (pval), the
+    // Hessian row and the cost gradients [hc | gx | gu] into an LDS staging row. Both are requested at the top of the PREVIOUS
+    // step by the threads of waves 1..3 alike (thread-indexed; wave 0 only ever stores, so its load counter never makes it wait) and written to LDS at its end, so that no load is in
+    // flight across the loop edge and no role's code path can reuse a register another role's load is still aimed at (the
+    // in-order load counter would stall it until those loads land).
+    constexpr bool STAGE = LD::STAGE;
+    constexpr int NG = n + m, ER = (HSP + NG + NS - 1) / NS;
+    double *sH = S + LD::oStg, *sG = sH + HSP;
+    double pval[EJ], rval[ER];
 #pragma unroll
     for (int j = 0; j < EJ; ++j) pval[j] = 0.0;
-    auto fetch = [&](int t, double (&uv)[EU], double (&xv)[SLOTS][EXT], double& g) {
-        if (wave == 0) {
+    // (one load per element through a selected ADDRESS: selecting among three loaded values would need them at once)
+    const long gx_rel = A.gx - A.hc, gu_rel = A.gu - A.hc;                // the three arrays sit in the same instance block
+    auto stage_load = [&](int t, double (&R)[ER]) {
 #pragma unroll
-            for (int j = 0; j < EU; ++j) uv[j] = uoff[j] >= 0 ? A.hc[(size_t)t * HSP + HXX + lane + 64 * j] : 0.0;
-        } else {
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s)
-#pragma unroll
-                for (int x = 0; x < EXT; ++x) xv[s][x] = xoff[s][x] >= 0 ? A.hc[(size_t)t * HSP + xbeg[s] + lane + 64 * x] : 0.0;
-            if (wave == 1) g = lane < 32 ? A.gx[t * n + (lane < n ? lane : 0)] : A.gu[t * m + (lane - 32 < m ? lane - 32 : 0)];
-            if (wave == 1 && n > 32) g = A.gx[t * n + (lane < n ? lane : 0)];
+        for (int j = 0; j < ER; ++j) {
+            const int e = (tid - 64) + NS * j;
+            const long off = e < HSP ? (long)t * HSP + e : (e < HSP + n ? gx_rel + t * n + (e - HSP) : gu_rel + t * m + (e - HSP - n));
+            R[j] = (tid >= 64 && e < HSP + NG) ? (double)A.hc[off] : 0.0;
         }
     };
-    double gu_hi = 0.0;                                    // n > 32: gu of wave 1 travels in its own register
-    if (N > 0) {
-        fetch(N - 1, uval, xval, gv);
-        if (n > 32 && wave == 1) gu_hi = A.gu[(N - 1) * m + (lane < m ? lane : 0)];
-    }
+    auto stage_store = [&](const double (&R)[ER]) {
+#pragma unroll
+        for (int j = 0; j < ER; ++j) {
+            const int e = (tid - 64) + NS * j;
+            if (tid >= 64 && e < HSP + NG) sH[e] = R[j];
+        }
+    };
+    if (STAGE && N > 0) { stage_load(N - 1, rval); stage_store(rval); }
     double gmax = 0.0;
+    // this wave's part of the static schedule, read once
+    auto uniform64 = [](unsigned long long v) {
+        return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    const unsigned long long list_a = uniform64(RS::tab.wa[wave]), list_b = uniform64(RS::tab.wb[wave]), list_c = uniform64(RS::tab.wc[wave]);
+    int qxx_tile[SLOTS], p_tile[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        qxx_tile[s] = __builtin_amdgcn_readfirstlane(RS::tab.qxx[wave][s]);
+        p_tile[s] = __builtin_amdgcn_readfirstlane(RS::tab.p[wave][s]);
+    }
     __syncthreads();
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
         ILQR_SUB_BEGIN();
         const int tn = t > 0 ? t - 1 : 0;                                 // (t = 0: a harmless re-read instead of a branch)
         // operands of the NEXT step, requested now
-        double uval_n[EU], xval_n[SLOTS][EXT], gv_n = 0.0, gu_hi_n = 0.0;
-        fetch(tn, uval_n, xval_n, gv_n);
-        if (n > 32 && wave == 1) gu_hi_n = A.gu[tn * m + (lane < m ? lane : 0)];
+        if (STAGE) stage_load(tn, rval);
 #pragma unroll
-        for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)tn * JVP + tid + NT * j] : 0.0;
-        // ------------------------------------------------ window A: ûx = fuᵀP′ (:57) | first half of T = fxᵀP′ (:52)
-        const int tcnt = wave >= 2 ? (NQ - (wave - 2) + 1) / 2 : 0;       // T tiles of this wave: q = (wave - 2) + 2 k
-        const int tA = (tcnt + 1) / 2;
-        if (wave < 2) {
-            for (int c = wave; c < TN; c += 2) {
-                const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFu, sP + ld * 16 * c, li, lk);
-                tile_store<ldm>(sUh, acc, 0, 16 * c, li, lk);
-            }
-        } else {
-            for (int kq = 0; kq < tA; ++kq) {
-                const int q = (wave - 2) + 2 * kq, a = q / TN, c = q % TN;
-                const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
-                tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
-            }
-        }
-        __syncthreads();                                                  // (B1) ûx complete
-        ILQR_SUB_MARK(I, 0);
-        // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | rest of T
-        if (wave < 2) {
-            for (int c = wave; c <= TN; c += 2) {
-                if (c < TN) {
-                    const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * c, li, lk);
-                    tile_store<ldm>(sQux, acc, 0, 16 * c, li, lk);
+        for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)tn * JVP + (tid - 64) + NS * j] : 0.0;
+        // ------------------------------------------------ window A: ûx = fuᵀP′ (:57) | T = fxᵀP′ (:52)
+        auto run_tiles = [&](unsigned long long lst) {                    // the task bytes of this wave, in a scalar register pair
+            for (; (lst & 0xff) != RIC_END; lst = (lst >> 8) | (0xffull << 56)) {
+                const int task = (int)(lst & 0xff), kind = task & 0xe0, idx = task & 0x1f;
+                if (kind == RIC_UH) {
+                    const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFu, sP + ld * 16 * idx, li, lk);
+                    tile_store<ldm>(sUh, acc, 0, 16 * idx, li, lk);
+                } else if (kind == RIC_T) {
+                    const int a = idx / TN, c = idx % TN;
+                    const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
+                    tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
+                } else if (kind == RIC_QUX) {
+                    const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
+                    tile_store<ldm>(sQux, acc, 0, 16 * idx, li, lk);
                 } else {
                     const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
                     tile_store<ldm>(sQuu, acc, 0, 0, li, lk);
                 }
             }
-            if (wave == 1) {
-                // Qu = fuᵀp′ + gu: action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum
-                constexpr int JP = (n + 3) / 4;
-                const int i = li < m ? li : m - 1;
-                double acc = 0.0;
+        };
+        run_tiles(list_a);
+        __syncthreads();                                                  // (B1) ûx complete
+        ILQR_SUB_MARK(I, 0);
+        // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | T
+        run_tiles(list_b);
+        if (wave == 1) {
+            // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum
+            constexpr int JP = (n + 3) / 4;
+            const int i = li < m ? li : m - 1;
+            double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < JP; ++q) {
-                    const int l = lk * JP + q;
-                    if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
-                }
-                acc = sum_quarters(acc);
-                const double gu_v = n > 32 ? __shfl(gu_hi, li) : __shfl(gv, 32 + li);
-                if (lane < m) sQu[lane] = acc + gu_v;
+            for (int q = 0; q < JP; ++q) {
+                const int l = lk * JP + q;
+                if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
             }
-        } else {
-            for (int kq = tA; kq < tcnt; ++kq) {
-                const int q = (wave - 2) + 2 * kq, a = q / TN, c = q % TN;
-                const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
-                tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
-            }
+            acc = sum_quarters(acc);
+            if (lane < m) sQu[lane] = acc + (STAGE ? sG[n + lane] : (double)A.gu[t * m + lane]);
         }
         __syncthreads();                                                  // (B2) Qux, Quu, Qu, T complete
         ILQR_SUB_MARK(I, 1);
@@ -605,12 +670,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             // Quu += guu, Qux += gux (:59, :64): the structurally non-zero entries only
 #pragma unroll
             for (int j = 0; j < EU; ++j)
-                if (uoff[j] >= 0) S[uoff[j]] += uval[j];
+                if (uoff[j] >= 0) S[uoff[j]] += STAGE ? sH[HXX + lane + 64 * j] : (double)A.hc[(size_t)t * HSP + HXX + lane + 64 * j];
             wave_lds_fence();
             if (STORE_VALUE && Qv != nullptr) {                           // policy.action_value.* (src/data/policy.jl:58-64)
                 for (int e = lane; e < m * n; e += 64) Qv[QL.Qux + (size_t)t * m * n + e] = sQux[(e / m) * ldm + e % m];
                 for (int e = lane; e < m * m; e += 64) Qv[QL.Quu + (size_t)t * m * m + e] = sQuu[(e / m) * ldm + e % m];
-                if (lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
             }
             // potrf('U'), column c of Quu on lanes c, c + 16, ... (info ignored, :68-69); the factor goes to LDS for the solves
             double Ua[m], Ur[m];
@@ -664,22 +728,24 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         if ((n % 2 == 0) || l < n) acc += sFx[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
                     }
                     acc = sum_halves(acc);
-                    if (lane < n) sQx[lane] = acc + gv;
+                    if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
                 } else {
                     const int i = lane < n ? lane : n - 1;
                     double acc = 0.0;
 #pragma unroll
                     for (int l = 0; l < n; ++l) acc += sFx[i * ld + l] * sp[l];
-                    if (lane < n) sQx[lane] = acc + gv;
+                    if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
                 }
                 if (STORE_VALUE && Qv != nullptr && lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
+                if (STORE_VALUE && Qv != nullptr && lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
             }
+            run_tiles(list_c);                                  // what is left of T (this wave's own Qxx rows need it)
             // Qxx = T fx + gxx (:53-54), written where P′ was (nobody reads P′ after window B); the wave that stored a tile adds
             // the tile's own gxx entries
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                const int q = (wave + 1) % 3 + 3 * s;
-                if (q < NQ) {
+                const int q = qxx_tile[s];
+                if (q >= 0) {
                     const int a = q / TN, c = q % TN;
                     const double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
                     tile_store<ld>(sP, acc, 16 * a, 16 * c, li, lk);
@@ -687,7 +753,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         wave_lds_fence();
 #pragma unroll
                         for (int x = 0; x < EXT; ++x)
-                            if (xoff[s][x] >= 0) S[xoff[s][x]] += xval[s][x];
+                            if (xoff[s][x] >= 0) S[xoff[s][x]] += STAGE ? sH[xbeg[s] + lane + 64 * x] : (double)A.hc[(size_t)t * HSP + xbeg[s] + lane + 64 * x];
                     }
                     if (STORE_VALUE && Qv != nullptr) {
                         wave_lds_fence();
@@ -703,18 +769,13 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         __syncthreads();                                                  // (B3) K, k, Qx in LDS; T, fx, fu no longer needed
         ILQR_SUB_MARK(I, 4);
         // ------------------------------------------------ window D: P (:79-84) | p, ∇L (:86-89, src/solve.jl:73-81); next step's Jacobian entries
-        if (t > 0) {
-#pragma unroll
-            for (int j = 0; j < EJ; ++j)
-                if (poff[j] >= 0) S[poff[j]] = pval[j];
-        }
-        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order, tile q on wave 1 + q % 3 (wave 0 has the
+        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order, on waves 1..3 (wave 0 has the
         // vector chain); ux_tmp = Quu K (:79) comes out of its MFMAs in exactly the layout the next MFMA's B operand wants
         // (k = lane>>4 + 4 reg, j = lane&15). All fragments of a tile are read first, then its eight MFMAs issue back to back.
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int q = (wave - 1) + 3 * s;
-            if (wave >= 1 && q < NQ) {
+            const int q = p_tile[s];
+            if (q >= 0) {
                 constexpr int KS = m4 / 4;
                 const int a = q / TN, c = q % TN;
                 const double* pKa = sK + ldm * (16 * a + li) + lk;                     // A(i,k) = K[k][16a + i]
@@ -729,6 +790,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 for (int sx = 0; sx < KS; ++sx) { fU[sx] = pU[4 * ldm * sx]; fKc[sx] = pKc[4 * sx]; fKa[sx] = pKa[4 * sx]; fQc[sx] = pQc[4 * sx]; fQa[sx] = pQa[4 * sx]; }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) qxx[r] = pq[4 * r];
+                __builtin_amdgcn_sched_barrier(0);
                 double4_t ux = double4_t{0, 0, 0, 0}, acc = double4_t{0, 0, 0, 0};
 #pragma unroll
                 for (int sx = 0; sx < KS; ++sx) ux = __builtin_amdgcn_mfma_f64_16x16x4f64(fU[sx], fKc[sx], ux, 0, 0, 0);
@@ -749,41 +811,54 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
             }
         }
+        // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx (:86-89) with ux_tmp^T k = (Quu K)^T k formed as K^T (Quu^T k): the m-vector Quu^T k
+        // costs m FMAs on m lanes where the tiles of ux_tmp cost four MFMAs and two LDS round trips on wave 0's chain;
+        // Lagrangian gradient (src/solve.jl:73-81): values first ...
+        double pn = 0.0, Lxv = 0.0, Luv = 0.0;
         if (wave == 0) {
-            // ux_tmp = Quu K (:79) for the vector chain, in this wave's own buffer
-            for (int c = 0; c < TN; ++c) {
-                const double4_t acc = tile_mm<m4, 1, ldm, 1, ldm>(sQuu, sK + ldm * 16 * c, li, lk);
-                tile_store<ldm>(sUxt, acc, 0, 16 * c, li, lk);
+            double* sQk = sUxt;                                           // Quu^T k
+            if (lane < m) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < m; ++r) acc += sQuu[lane * ldm + r] * sk[r];
+                sQk[lane] = acc;
             }
             wave_lds_fence();
-            // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx   (:86-89); Lagrangian gradient (src/solve.jl:73-81)
             if (lane < n) {
                 double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int l = 0; l < m; ++l) {
-                    a1 += sUxt[lane * ldm + l] * sk[l];
-                    a2 += sK[lane * ldm + l] * sQu[l];
+                    const double Kl = sK[lane * ldm + l];
+                    a1 += Kl * sQk[l];
+                    a2 += Kl * sQu[l];
                     a3 += sQux[lane * ldm + l] * sk[l];
                 }
-                const double pn = ((a1 + a2) + a3) + sQx[lane];
-                const double Lx = sQx[lane] - pn;
-                gmax = nanmax(gmax, fabs(Lx));
-                A.Lx[t * n + lane] = Lx;
+                pn = ((a1 + a2) + a3) + sQx[lane];
+                Lxv = sQx[lane] - pn;
+                gmax = nanmax(gmax, fabs(Lxv));
+            }
+            if (lane < m) {
+                Luv = sQu[lane];
+                gmax = nanmax(gmax, fabs(Luv));
+            }
+        }
+        // ... then, by all threads alike, the next step's operands into LDS (waits for the loads requested at the top of the step;
+        // placed here so that the acknowledgements of wave 0's K, k stores are not waited for as well) ...
+        // (unconditional: at t = 0 it rewrites step 0's own values, and the loads must be consumed on every path through the loop —
+        // a path that skipped them would leave them pending at the loop edge and every iteration would start by waiting)
+#pragma unroll
+        for (int j = 0; j < EJ; ++j)
+            if (poff[j] >= 0) S[poff[j]] = pval[j];
+        if (STAGE) stage_store(rval);
+        // ... and the stores last
+        if (wave == 0) {
+            if (lane < n) {
+                A.Lx[t * n + lane] = Lxv;
                 if (STORE_VALUE) A.p[t * n + lane] = pn;
                 sp[lane] = pn;                                            // p' of the next step
             }
-            if (lane < m) {
-                gmax = nanmax(gmax, fabs(sQu[lane]));
-                A.Lu[t * m + lane] = sQu[lane];
-            }
+            if (lane < m) A.Lu[t * m + lane] = Luv;
         }
-#pragma unroll
-        for (int j = 0; j < EU; ++j) uval[j] = uval_n[j];
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-#pragma unroll
-            for (int x = 0; x < EXT; ++x) xval[s][x] = xval_n[s][x];
-        gv = gv_n; gu_hi = gu_hi_n;
         __syncthreads();                                                  // (B0) P′, p′, patched fx, fu visible
         ILQR_SUB_MARK(I, 5);
     }

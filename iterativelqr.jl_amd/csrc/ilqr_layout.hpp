@@ -67,10 +67,19 @@ inline __host__ __device__ QLayout make_qlayout(int nx, int nu, int T) {
 inline __host__ __device__ bool is_large_model(int nx, int nu) { return nx > 4 || nu > 4; }
 // LDS staging of the large path (must match LargeDims<M>::total); the tail holds a copy of the Layout so that the
 // phase functions (real calls) take one pointer instead of twenty on the stack
-enum { LAYOUT_LDS_DOUBLES = 24, LARGE_WAVES = 4, LARGE_CHOL = 16 * 16 };
-constexpr __host__ __device__ int large_lds_doubles(int n, int m) {
+enum { LAYOUT_LDS_DOUBLES = 24, LARGE_WAVES = 4, LARGE_CHOL = 16 * 17 };
+// hess_nnz: structurally non-zero Hessian entries per timestep (the compact row). The row of the NEXT Riccati step and its
+// cost gradients are staged in LDS when that still fits a CU's 160 KiB (large_stage_doubles > 0).
+constexpr __host__ __device__ int large_lds_base_doubles(int n, int m) {
     const int NP = (n + 15) & ~15, MP = (m + 15) & ~15, ld = NP + 1, ldm = MP + 1;
     return 3 * NP * ld + MP * ld + (4 * NP + 2) * ldm + MP * ldm + LARGE_CHOL + 2 * NP + 8 + LAYOUT_LDS_DOUBLES;
+}
+constexpr __host__ __device__ int large_stage_doubles(int n, int m, int hess_nnz) {
+    const int want = pad2(pad2(hess_nnz > 0 ? hess_nnz : 1) + n + m);
+    return large_lds_base_doubles(n, m) + want <= 160 * 1024 / 8 ? want : 0;
+}
+constexpr __host__ __device__ int large_lds_doubles(int n, int m, int hess_nnz) {
+    return large_lds_base_doubles(n, m) + large_stage_doubles(n, m, hess_nnz);
 }
 
 #define ILQR_LAYOUT_FIELDS(X) X(T) X(nx) X(nu) X(nw) X(ncs) X(nct) X(C) X(xb) X(ub) X(x) X(u) X(fx) X(fu) X(gx) X(gu) X(K) X(k) X(Lx) X(Lu) \
