@@ -42,11 +42,13 @@ struct LargeDims {
     static constexpr int oFx = 0, oFu = oFx + NP * ld, oP = oFu + MP * ld, oT = oP + NP * ld, oUh = oT + NP * ld,
                          oQux = oUh + NP * ldm, oK = oQux + (NP + 1) * ldm, oUxt = oK + (NP + 1) * ldm, oQuu = oUxt + NP * ldm,
                          oChol = oQuu + MP * ldm, oVec = oChol + LARGE_CHOL, oLay = oVec + 2 * NP + 8,      // Qux, K: one more column for Qu, k
-                         oStg = oLay + LAYOUT_LDS_DOUBLES, STG = large_stage_doubles(n, m, HS), total = oStg + STG;
+                         oQxx = oLay + LAYOUT_LDS_DOUBLES, QXB = TN == 2 ? NP * ld : 0,                      // Qxx's own buffer (TN = 2 schedule)
+                         oStg = oQxx + QXB, STG = large_stage_doubles(n, m, HS), total = oStg + STG;
     static constexpr bool STAGE = STG > 0;                  // next step's compact Hessian row and cost gradients staged in LDS
     // forward sweep: fx, fu keep their place (sensitivity recursion); behind them the sweep's vectors and the K ring
     static constexpr int oFw = oP, oRing = oFw + 2 * NP + 2 * MP, ringDoubles = oVec - oRing;
-    static constexpr int CH = ringDoubles / (2 * m * n) < 32 ? ringDoubles / (2 * m * n) : 32;     // timesteps per ring half
+    static constexpr int RSTEP = m * n + 2 * m;             // ring entry of a timestep: K_t, a_t, b_t
+    static constexpr int CH = ringDoubles / (2 * RSTEP) < 32 ? ringDoubles / (2 * RSTEP) : 32;     // timesteps per ring half
     static_assert(CH >= 1, "LDS ring of the forward sweep holds at least one timestep of K per half");
 };
 
@@ -510,6 +512,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     double *sp = S + LD::oVec, *sQx = sp + NP, *sOut = sQx + NP;
     double *sQu = sQux + NP * ldm, *sk = sK + NP * ldm;              // Qu and k ride along as column NP of Qux and K
     double* sU = S + LD::oChol;                                            // the Cholesky factor, column c at sU + c m
+    constexpr int oQ = LD::QXB > 0 ? LD::oQxx : LD::oP;                    // where Qxx waits for P: its own buffer or P′'s place
+    double* sQ = S + oQ;
 
     // ---- prologue: zero padding, constant Jacobian entries, P[H] = gxx[H], p[H] = gx[H]   (:39-40)
     for (int e = tid; e < LD::oVec; e += NT) S[e] = 0.0;
@@ -562,7 +566,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             const int e = lane + 64 * x;
             if (e < xcnt[s]) {
                 const int idx = M::HESS_IDX[xbeg[s] + e];
-                xoff[s][x] = LD::oP + (idx / n) * ld + idx % n;
+                xoff[s][x] = oQ + (idx / n) * ld + idx % n;
             }
         }
     }
@@ -740,15 +744,15 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 if (STORE_VALUE && Qv != nullptr && lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
             }
             run_tiles(list_c);                                  // what is left of T (this wave's own Qxx rows need it)
-            // Qxx = T fx + gxx (:53-54), written where P′ was (nobody reads P′ after window B); the wave that stored a tile adds
-            // the tile's own gxx entries
+            // Qxx = T fx + gxx (:53-54), written where P′ was (generic schedule: nobody reads P′ after window B) or to its own buffer
+            // (TN = 2: a tile of T is still being formed from P′ in this window); the wave that stored a tile adds its gxx entries
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 const int q = qxx_tile[s];
                 if (q >= 0) {
                     const int a = q / TN, c = q % TN;
                     const double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
-                    tile_store<ld>(sP, acc, 16 * a, 16 * c, li, lk);
+                    tile_store<ld>(sQ, acc, 16 * a, 16 * c, li, lk);
                     if (xcnt[s] > 0) {
                         wave_lds_fence();
 #pragma unroll
@@ -760,7 +764,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * a + lk + 4 * r, col = 16 * c + li;
-                            if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = sP[col * ld + row];
+                            if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = sQ[col * ld + row];
                         }
                     }
                 }
@@ -783,7 +787,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 const double* pQa = sQux + ldm * (16 * a + li) + lk;                   // A(i,k) = Qux[k][16a + i]
                 const double* pQc = sQux + ldm * (16 * c + li) + lk;                   // B(k,j) = Qux[k][16c + j]
                 const double* pU = sQuu + li + ldm * lk;                               // A(i,k) = Quu[i][k]
-                const double* pq = sP + (16 * c + li) * ld + 16 * a + lk;              // Qxx tile (D layout)
+                const double* pq = sQ + (16 * c + li) * ld + 16 * a + lk;              // Qxx tile (D layout)
                 double fKa[KS], fKc[KS], fQa[KS], fQc[KS], fU[KS];
                 double4_t qxx;
 #pragma unroll
@@ -917,11 +921,14 @@ __device__ __forceinline__ double dyn_row(const double (&aff)[M::NX + M::NU + 1]
     double ua[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) ua[j] = su[j];
-    double y = aff[n + m];
+    // four interleaved partial sums: a dependent fp64 FMA chain advances one link per ~8 clk on a lone wave, forty links in a
+    // row were a third of the rollout step
+    double y4[4] = {aff[n + m], 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < n; ++j) y += aff[j] * sx[j];
+    for (int j = 0; j < n; ++j) y4[j & 3] += aff[j] * sx[j];
 #pragma unroll
-    for (int j = 0; j < m; ++j) y += aff[n + j] * ua[j];
+    for (int j = 0; j < m; ++j) y4[j & 3] += aff[n + j] * ua[j];
+    double y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
     if constexpr (M::DYN_HAS_REM) {
         double w[cdim<M::NW>::v];
         load_w<M::NW>(W, t, w);
@@ -956,16 +963,14 @@ __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
     for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
     double xl = lane < n ? A.xb[lane] : 0.0;                                  // x[1] = x̄[1]  (:19)
     if (lane < n) A.x[lane] = xl;
-    double a_t = 0.0, b_t = 0.0;
-    if (N > 0 && lane < m) { a_t = A.ab[lane]; b_t = A.ab[m + lane]; }
+    const int ui = lane < m ? lane : 0;
     for (int c0 = 0; c0 < N; c0 += CH) {
         const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
         for (int t = c0; t < c1; ++t) {
-            const double* Kt = ring + (t % (2 * CH)) * KN;
+            const double* Kt = ring + (t % (2 * CH)) * LD::RSTEP;
             if (lane < n) sx[lane] = xl;
             wave_lds_fence();
-            const int t1 = t + 1 < N ? t + 1 : t;
-            const double a_n = lane < m ? A.ab[2 * t1 * m + lane] : 0.0, b_n = lane < m ? A.ab[(2 * t1 + 1) * m + lane] : 0.0;
+            const double a_t = Kt[KN + ui], b_t = Kt[KN + m + ui];            // α k + ū and K x̄, formed beforehand (no global load on this chain)
             const double acc = kx_partial<M>(Kt, sx, li, lk);
             double v = a_t;                                                   // α k + ū   (:24-26)
             v += acc;                                                         // + K x      (:27)
@@ -974,7 +979,6 @@ __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
             wave_lds_fence();
             const double y = dyn_row<M>(aff, sx, su, xl, lane, (const double*)A.w, t);      // (:29)
             xl = y;
-            a_t = a_n; b_t = b_n;
             if (lane < n) A.x[(t + 1) * n + lane] = y;
             wave_lds_fence();
         }
@@ -1011,8 +1015,11 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
     if (N > 0) { kv = A.k[ui]; Luv = A.Lu[ui]; Lxv = A.Lx[xi]; }
     for (int c0 = 0; c0 < N; c0 += CH) {
         const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
+#ifdef ILQR_DBG_NODELTA      // timing experiment only: the sweep's barriers without its work
+        if (c1 > 0) { __syncthreads(); continue; }
+#endif
         for (int t = c0; t < c1; ++t) {
-            const double* Kt = ring + (t % (2 * CH)) * KN;
+            const double* Kt = ring + (t % (2 * CH)) * LD::RSTEP;
 #pragma unroll
             for (int j = 0; j < EJ; ++j)
                 if (poff[j] >= 0) S[poff[j]] = pval[j];
@@ -1079,14 +1086,30 @@ __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, d
         for (int e = tid; e < n * n; e += NT) sFx[(e / n) * ld + e % n] = M::JAC_CONST_FX[0][e];
         for (int e = tid; e < n * m; e += NT) sFu[(e / n) * ld + e % n] = M::JAC_CONST_FU[0][e];
     }
-    auto stage = [&](int c0, int nthreads, int me) {                      // K[c0 .. c0 + CH) into the ring half (c0 / CH) & 1
+    // K, a, b of [c0, c0 + CH) into the ring half (c0 / CH) & 1: every load of a thread is issued before its first LDS write
+    // (a load-store loop would pay one HBM round trip per element: seventeen in a row made the stagers slower than the rollout)
+    auto stage = [&](int c0, int nthreads, int me) {
+        constexpr int NE = (CH * LD::RSTEP + 127) / 128;                  // elements per thread with the fewest stagers (two waves)
         const int steps = (N - c0) < CH ? (N - c0) : CH;
-        double* dst = ring + ((c0 / CH) & 1) * CH * KN;
-        const gdbl* src = A.K + (size_t)c0 * KN;
-        for (int e = me; e < steps * KN; e += nthreads) dst[e] = src[e];
+        double* dst = ring + ((c0 / CH) & 1) * CH * LD::RSTEP;
+        const gdbl* srcK = A.K + (size_t)c0 * KN;
+        const long ab_rel = (A.ab + (size_t)c0 * 2 * m) - srcK;            // same instance block: one base, selected offsets
+        double v[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = me + nthreads * q, st = e / LD::RSTEP, r = e % LD::RSTEP;
+            const long off = r < KN ? (long)st * KN + r : ab_rel + st * 2 * m + (r - KN);
+            v[q] = e < steps * LD::RSTEP ? (double)srcK[off] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = me + nthreads * q;
+            if (e < steps * LD::RSTEP) dst[e] = v[q];
+        }
     };
+    __syncthreads();                                                      // a_t, b_t (global, written and read by this workgroup only) visible
     if (N > 0) stage(0, NT, tid);
-    __syncthreads();                                                      // a_t, b_t (global, this workgroup only) and the ring visible
+    __syncthreads();                                                      // ring half 0 ready
     double d = 0.0;
     if (wave == 0) fw_rollout_wave<M>(base);
     else if (wave == 1 && want_delta) d = fw_delta_wave<M>(base);

@@ -72,7 +72,10 @@ enum { LAYOUT_LDS_DOUBLES = 24, LARGE_WAVES = 4, LARGE_CHOL = 16 * 17 };
 // cost gradients are staged in LDS when that still fits a CU's 160 KiB (large_stage_doubles > 0).
 constexpr __host__ __device__ int large_lds_base_doubles(int n, int m) {
     const int NP = (n + 15) & ~15, MP = (m + 15) & ~15, ld = NP + 1, ldm = MP + 1;
-    return 3 * NP * ld + MP * ld + (4 * NP + 2) * ldm + MP * ldm + LARGE_CHOL + 2 * NP + 8 + LAYOUT_LDS_DOUBLES;
+    // 17 <= nx <= 32 (two tile rows): the hand-made schedule computes one tile of T while Qxx is being stored, so Qxx gets a
+    // buffer of its own there (elsewhere it is written over P', which nobody reads any more by then)
+    const int qxx = NP == 32 ? NP * ld : 0;
+    return 3 * NP * ld + MP * ld + (4 * NP + 2) * ldm + MP * ldm + LARGE_CHOL + 2 * NP + 8 + LAYOUT_LDS_DOUBLES + qxx;
 }
 constexpr __host__ __device__ int large_stage_doubles(int n, int m, int hess_nnz) {
     const int want = pad2(pad2(hess_nnz > 0 ? hess_nnz : 1) + n + m);
