@@ -5,8 +5,9 @@
  * this header is the boundary a Julia `ccall` wrapper (or the Python ctypes
  * mirror in iterativelqr.jl_amd/) binds to. Each entry point names the reference
  * interface it replaces (paths relative to /root/reference). One handle owns a
- * BATCH of independent problem instances of one model on one GPU; every
- * instance behaves exactly like one reference `Solver`.
+ * BATCH of independent problem instances of one model, on one GPU (ilqr_create)
+ * or split over several (ilqr_create_sharded); every instance behaves exactly
+ * like one reference `Solver`.
  *
  * Conventions: every function returns 0 on success, <0 on error (never
  * throws); ilqr_last_error() gives the message. The caller owns all host
@@ -91,6 +92,15 @@ int ilqr_default_options(ilqr_options* opt);
 /* Solver(...) — src/solver.jl:11-46. Fails loudly (ILQR_ERR_NO_DEVICE) when no
  * HIP device is present: there is no CPU fallback. */
 int ilqr_create(const ilqr_problem_desc* desc, ilqr_handle** out);
+/* The same Solver with its batch spread over several GPUs of the node — the reference's caller holds ONE Solver and calls
+ * solve! (src/solver.jl:28-46, src/solve.jl:137-143); a Julia host has no process launcher. The instances are split into
+ * contiguous ranges of ceil(batch / n_devices), range i on devices[i] (desc->device is ignored; an ordinal may repeat). Inside
+ * the library every range is a handle of its own with its own workspace and stream on its device; launches are asynchronous
+ * on all of them, blocking copies run on one host thread per device. Every entry point below takes the returned handle
+ * unchanged: host arrays stay instance-major over the WHOLE batch and are scattered / gathered over the ranges. No data
+ * crosses devices (the instances are independent). Not available on it: ilqr_initialize_rollout_device and ilqr_get_stream
+ * (one device's pointers / stream); ilqr_timing_get reports the slowest device. */
+int ilqr_create_sharded(const ilqr_problem_desc* desc, const int32_t* devices, int32_t n_devices, ilqr_handle** out);
 int ilqr_destroy(ilqr_handle* h);
 int ilqr_set_options(ilqr_handle* h, const ilqr_options* opt);   /* solver.options */
 int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw,

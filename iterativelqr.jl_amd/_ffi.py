@@ -42,6 +42,7 @@ SYMBOLS = {
     "ilqr_device_count": (C.c_int, []),
     "ilqr_default_options": (C.c_int, [C.POINTER(Options)]),
     "ilqr_create": (C.c_int, [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),
+    "ilqr_create_sharded": (C.c_int, [C.POINTER(ProblemDesc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
     "ilqr_destroy": (C.c_int, [C.c_void_p]),
     "ilqr_set_options": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "ilqr_get_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 7),

@@ -85,7 +85,9 @@ class Solver:
     """
 
     def __init__(self, dynamics=None, costs=None, constraints=None, *, model=None, horizon=None, batch=1,
-                 options=None, device=0, name="user"):
+                 options=None, device=0, devices=None, name="user"):
+        """devices: list of HIP ordinals — the batch is split into contiguous ranges over them (ilqr_create_sharded: one handle,
+        every GPU of the node); device: a single ordinal (ilqr_create)."""
         L = _ffi.lib()
         model_library = None
         self._selectors = None
@@ -106,7 +108,12 @@ class Solver:
         desc = _ffi.ProblemDesc(model.encode(), model_library.encode() if model_library else None,
                                 self.T, self.B, device, 1 if constrained else 0)
         h = C.c_void_p()
-        _ffi.check(L.ilqr_create(C.byref(desc), C.byref(h)))
+        self.devices = None if devices is None else [int(d) for d in devices]
+        if self.devices is None:
+            _ffi.check(L.ilqr_create(C.byref(desc), C.byref(h)))
+        else:
+            arr = (C.c_int32 * len(self.devices))(*self.devices)
+            _ffi.check(L.ilqr_create_sharded(C.byref(desc), arr, len(self.devices), C.byref(h)))
         self._h = h
         d = [C.c_int32() for _ in range(7)]
         _ffi.check(L.ilqr_get_dims(self._h, *[C.byref(v) for v in d]))

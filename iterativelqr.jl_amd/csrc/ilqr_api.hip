@@ -13,6 +13,7 @@
 #include <fcntl.h>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -91,6 +92,10 @@ struct ilqr_handle {
     bool P_dirty;         // P, p hold pre-reset values (only the backward-pass STAGE kernel writes them): zeroed lazily
     std::vector<BufferDesc> buffers;
     std::vector<BufferDesc> qbuffers;
+    // ilqr_create_sharded: this handle owns no device memory itself but one sub-handle per entry of the device list, each with
+    // its own contiguous range of instances [lo[i], lo[i] + shards[i]->B), workspace and stream on its device
+    std::vector<ilqr_handle*> shards;
+    std::vector<int> lo;
 };
 
 namespace {
@@ -196,6 +201,27 @@ int copy_in(ilqr_handle* h, const BufferDesc* bd, const double* in) {
     }
     return ILQR_OK;
 }
+
+// Sharded handles: run f(sub-handle, first instance of its range) for every shard. Launch-type calls are asynchronous and go
+// one after the other from the calling thread; calls that move data (blocking copies) run on one host thread per device.
+template <class F>
+int each_shard(ilqr_handle* h, F f, bool threaded = false) {
+    const size_t G = h->shards.size();
+    if (!threaded || G == 1) {
+        for (size_t i = 0; i < G; ++i) { const int rc = f(h->shards[i], (size_t)h->lo[i]); if (rc != ILQR_OK) return rc; }
+        return ILQR_OK;
+    }
+    std::vector<int> rcs(G, ILQR_OK);
+    std::vector<std::string> msgs(G);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < G; ++i)
+        th.emplace_back([&, i] { rcs[i] = f(h->shards[i], (size_t)h->lo[i]); if (rcs[i] != ILQR_OK) msgs[i] = g_err; });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < G; ++i)
+        if (rcs[i] != ILQR_OK) return fail(rcs[i], "device " + std::to_string(h->shards[i]->device) + ": " + msgs[i]);
+    return ILQR_OK;
+}
+#define SHARDED(h) ((h) && !(h)->shards.empty())
 
 }  // namespace
 
@@ -384,8 +410,43 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     return ILQR_OK;
 }
 
+// Solver(...) over a device list — SURVEY §8(b)/(e): one reference-style handle whose batch is split into contiguous ranges of
+// ceil(B / G) instances, range i on devices[i] (a device may be listed more than once). Every other entry point accepts the
+// handle and scatters / gathers instance-major host arrays over the ranges.
+int ilqr_create_sharded(const ilqr_problem_desc* d, const int32_t* devices, int32_t n_devices, ilqr_handle** out) {
+    if (!d || !out || !d->model || !devices) return fail(ILQR_ERR_INVALID, "null descriptor/model/device list");
+    if (n_devices < 1) return fail(ILQR_ERR_INVALID, "empty device list");
+    if (d->horizon < 2 || d->batch < 1) return fail(ILQR_ERR_INVALID, "horizon must be >= 2 and batch >= 1");
+    if (n_devices > d->batch) return fail(ILQR_ERR_INVALID, "more devices than instances");
+    ilqr_handle* h = new ilqr_handle();
+    h->vt = nullptr; h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr; h->trace = nullptr; h->qv = nullptr;
+    h->B = d->batch; h->device = devices[0]; h->constrained = d->constrained ? 1 : 0; h->trace_cap = 0; h->variant = 0;
+    const int per = (d->batch + n_devices - 1) / n_devices;
+    for (int i = 0, lo = 0; i < n_devices && lo < d->batch; ++i, lo += per) {
+        ilqr_problem_desc sd = *d;
+        sd.device = devices[i];
+        sd.batch = (d->batch - lo) < per ? (d->batch - lo) : per;
+        ilqr_handle* sub = nullptr;
+        const int rc = ilqr_create(&sd, &sub);
+        if (rc != ILQR_OK) { const std::string msg = g_err; ilqr_destroy(h); return fail(rc, msg); }
+        h->shards.push_back(sub);
+        h->lo.push_back(lo);
+    }
+    const ilqr_handle* s0 = h->shards[0];
+    h->vt = s0->vt; h->L = s0->L; h->QL = s0->QL; h->opt = s0->opt; h->lds_bytes = s0->lds_bytes; h->lds_fits = s0->lds_fits; h->num_simds = s0->num_simds;
+    h->full_stale = false; h->P_dirty = false;
+    fill_buffers(h);
+    *out = h;
+    return ILQR_OK;
+}
+
 int ilqr_destroy(ilqr_handle* h) {
     if (!h) return ILQR_OK;
+    if (!h->shards.empty() || h->vt == nullptr) {
+        for (ilqr_handle* s : h->shards) ilqr_destroy(s);
+        delete h;
+        return ILQR_OK;
+    }
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& p : h->timing) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -401,6 +462,7 @@ int ilqr_destroy(ilqr_handle* h) {
 
 int ilqr_set_options(ilqr_handle* h, const ilqr_options* opt) {
     if (!h || !opt) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) { h->opt = *opt; return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_options(s, opt); }); }
     h->opt = *opt;
     return ILQR_OK;
 }
@@ -420,6 +482,7 @@ int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw, i
 
 int ilqr_reset(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_reset(s); });
     HIP_TRY(hipSetDevice(h->device));
     if (ilqr::is_large_model(h->vt->nx, h->vt->nu) && h->vt->nw == 0) {
         // HBM-resident models: zero the trajectories, gradients, gains, duals, scalars and the compact Jacobian / Hessian rows
@@ -446,21 +509,25 @@ int ilqr_reset(ilqr_handle* h) {
 
 int ilqr_initialize_controls(ilqr_handle* h, const double* u) {
     if (!h || !u) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_initialize_controls(s, u + lo * (size_t)(h->L.T - 1) * h->L.nu); }, true);
     return copy_in(h, find_buffer(h, "nominal_actions"), u);
 }
 int ilqr_initialize_states(ilqr_handle* h, const double* x) {
     if (!h || !x) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_initialize_states(s, x + lo * (size_t)h->L.T * h->L.nx); }, true);
     return copy_in(h, find_buffer(h, "nominal_states"), x);
 }
 
 int ilqr_set_parameters(ilqr_handle* h, const double* w) {
     if (!h || !w) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_set_parameters(s, w + lo * (size_t)h->L.T * h->L.nw); }, true);
     if (h->vt->nw == 0) return fail(ILQR_ERR_INVALID, "this model has no parameters (num_parameter == 0)");
     return copy_in(h, find_buffer(h, "parameters"), w);
 }
 
 int ilqr_initialize_rollout_device(ilqr_handle* h, const double* d_x1, const double* d_u) {
     if (!h || !d_x1 || !d_u) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return fail(ILQR_ERR_INVALID, "device pointers belong to one device: call ilqr_initialize_rollout (host pointers) on a sharded handle");
     HIP_TRY(hipSetDevice(h->device));
     ilqr::KArgs a = make_args(h);
     a.x1 = d_x1; a.u_in = d_u;
@@ -470,6 +537,8 @@ int ilqr_initialize_rollout_device(ilqr_handle* h, const double* d_x1, const dou
 
 int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u) {
     if (!h || !x1 || !u) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) {
+        return ilqr_initialize_rollout(s, x1 + lo * (size_t)h->L.nx, u + lo * (size_t)(h->L.T - 1) * h->L.nu); }, true);
     HIP_TRY(hipSetDevice(h->device));
     const size_t bx = (size_t)h->B * h->vt->nx * 8, bu = (size_t)h->B * (h->L.T - 1) * h->vt->nu * 8;
     if (!h->d_x1) HIP_TRY(hipMalloc((void**)&h->d_x1, bx));
@@ -484,6 +553,7 @@ int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u) {
 
 int ilqr_solve(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_solve(s); });      // asynchronous on every device's stream
     HIP_TRY(hipSetDevice(h->device));
     ilqr::KArgs a = make_args(h);
     a.qv = nullptr;
@@ -523,6 +593,7 @@ int ilqr_run_stage(ilqr_handle* h, int32_t stage) { return ilqr_run_stage_param(
 
 int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t flag) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_run_stage_param(s, stage, param, flag); }, true);
     HIP_TRY(hipSetDevice(h->device));
     { const int rc = settle_reset(h); if (rc != ILQR_OK) return rc; }
     if (!h->lds_fits) return fail(ILQR_ERR_LDS, "stage kernels are LDS-resident: this horizon only runs through ilqr_solve (packed kernel)");
@@ -541,6 +612,7 @@ int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t fl
 
 int ilqr_synchronize(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_synchronize(s); });
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return ILQR_OK;
@@ -548,6 +620,8 @@ int ilqr_synchronize(ilqr_handle* h) {
 
 int ilqr_get_trajectory(ilqr_handle* h, double* x, double* u) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) {
+        return ilqr_get_trajectory(s, x ? x + lo * (size_t)h->L.T * h->L.nx : nullptr, u ? u + lo * (size_t)(h->L.T - 1) * h->L.nu : nullptr); }, true);
     int rc = ILQR_OK;
     if (x) rc = copy_out(h, find_buffer(h, "nominal_states"), x);
     if (rc == ILQR_OK && u) rc = copy_out(h, find_buffer(h, "nominal_actions"), u);
@@ -556,6 +630,9 @@ int ilqr_get_trajectory(ilqr_handle* h, double* x, double* u) {
 
 int ilqr_get_policy(ilqr_handle* h, double* K, double* k) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) {
+        const size_t N = (size_t)(h->L.T - 1);
+        return ilqr_get_policy(s, K ? K + lo * N * h->L.nu * h->L.nx : nullptr, k ? k + lo * N * h->L.nu : nullptr); }, true);
     int rc = ILQR_OK;
     if (K) rc = copy_out(h, find_buffer(h, "K"), K);
     if (rc == ILQR_OK && k) rc = copy_out(h, find_buffer(h, "k"), k);
@@ -564,6 +641,7 @@ int ilqr_get_policy(ilqr_handle* h, double* K, double* k) {
 
 int ilqr_get_stats(ilqr_handle* h, ilqr_stats* st) {
     if (!h || !st) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_get_stats(s, st + lo); }, true);
     std::vector<double> s((size_t)h->B * ilqr::S_COUNT);
     int rc = copy_out(h, find_buffer(h, "_scalars"), s.data());
     if (rc != ILQR_OK) return rc;
@@ -588,6 +666,7 @@ int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len) {
 }
 int ilqr_enable_action_value_buffers(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_enable_action_value_buffers(s); });
     if (h->qv) return ILQR_OK;
     HIP_TRY(hipSetDevice(h->device));
     const size_t bytes = (size_t)h->B * (size_t)h->QL.stride * 8;
@@ -613,6 +692,12 @@ int ilqr_scalar_slot(const char* name) {
 
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out) {
     if (!h || !name || !out) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) {
+        size_t len = 0;
+        const int rc = ilqr_buffer_len(h, name, &len);
+        if (rc != ILQR_OK) return rc;
+        return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_get_buffer(s, name, out + lo * len); }, true);
+    }
     if (const BufferDesc* qd = find_qbuffer(h, name)) {
         if (!h->qv) return fail(ILQR_ERR_INVALID, "action-value buffers are off: call ilqr_enable_action_value_buffers first");
         if (qd->len == 0) return ILQR_OK;
@@ -628,12 +713,19 @@ int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out) {
 }
 int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
     if (!h || !name || !in) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) {
+        size_t len = 0;
+        const int rc = ilqr_buffer_len(h, name, &len);
+        if (rc != ILQR_OK) return rc;
+        return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_set_buffer(s, name, in + lo * len); }, true);
+    }
     const BufferDesc* bd = find_buffer(h, name);
     if (!bd) return fail(ILQR_ERR_INVALID, std::string("unknown buffer '") + name + "'");
     return copy_in(h, bd, in);
 }
 
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_kernel_variant(s, variant); });
     if (!h || variant < 0 || variant > 3) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency), 2 (throughput) or 3 (packed)");
     if (variant == 3 && h->vt->launch_solve_packed == nullptr)
         return fail(ILQR_ERR_INVALID, "the packed variant exists for small models (nx, nu <= 4) only");
@@ -647,6 +739,7 @@ int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
 
 int ilqr_enable_trace(ilqr_handle* h, int32_t capacity) {
     if (!h || capacity < 0) return fail(ILQR_ERR_INVALID, "bad argument");
+    if (SHARDED(h)) { h->trace_cap = capacity; return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_enable_trace(s, capacity); }); }
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->trace) { HIP_TRY(hipFree(h->trace)); h->trace = nullptr; }
@@ -661,6 +754,7 @@ int ilqr_enable_trace(ilqr_handle* h, int32_t capacity) {
 
 int ilqr_get_trace(ilqr_handle* h, double* out) {
     if (!h || !out) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_get_trace(s, out + lo * (size_t)h->trace_cap * ilqr::TRACE_W); }, true);
     if (!h->trace) return fail(ILQR_ERR_INVALID, "trace not enabled");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -670,12 +764,14 @@ int ilqr_get_trace(ilqr_handle* h, double* out) {
 
 int ilqr_get_stream(ilqr_handle* h, void** s) {
     if (!h || !s) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return fail(ILQR_ERR_INVALID, "a sharded handle has one stream per device: synchronise with ilqr_synchronize");
     *s = (void*)h->stream;
     return ILQR_OK;
 }
 
 int ilqr_timing_reset(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_timing_reset(s); });
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto& p : h->timing) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -685,6 +781,18 @@ int ilqr_timing_reset(ilqr_handle* h) {
 
 int ilqr_timing_get(ilqr_handle* h, double* ms_avg, int32_t* launches) {
     if (!h || !ms_avg) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) {          // the devices run side by side: the slowest shard's kernel time
+        double worst = 0.0; int32_t nl = 0;
+        const int rc = each_shard(h, [&](ilqr_handle* s, size_t) {
+            double ms = 0.0; int32_t n_ = 0;
+            const int r = ilqr_timing_get(s, &ms, &n_);
+            if (ms > worst) worst = ms;
+            nl = n_;
+            return r; });
+        *ms_avg = worst;
+        if (launches) *launches = nl;
+        return rc;
+    }
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     double total = 0.0;

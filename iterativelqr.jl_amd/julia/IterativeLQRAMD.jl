@@ -67,20 +67,29 @@ mutable struct Solver
 end
 
 """
-    Solver(model; horizon, batch, constrained=true, options=Options(), device=0, model_library="")
+    Solver(model; horizon, batch, constrained=true, options=Options(), device=0, devices=Int[], model_library="")
 
 Batched counterpart of `Solver(dynamics, costs, constraints)` (src/solver.jl:28-46).
 `model` names a built-in ("acrobot", "car", "particle", ...) or a model compiled by
 the code generator (iterativelqr.jl_amd/codegen.py) whose module is `model_library`.
+`devices = [0, 1, ..., 7]` spreads the batch over the GPUs of the node (contiguous ranges of
+ceil(batch / length(devices)) instances, `ilqr_create_sharded`); every other call is unchanged.
 """
 function Solver(model::AbstractString; horizon::Integer, batch::Integer, constrained::Bool=true,
-                options::Options=Options(), device::Integer=0, model_library::AbstractString="")
+                options::Options=Options(), device::Integer=0, devices::AbstractVector{<:Integer}=Int[],
+                model_library::AbstractString="")
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve model model_library begin
         desc = ProblemDesc(Base.unsafe_convert(Cstring, model),
                            isempty(model_library) ? Cstring(C_NULL) : Base.unsafe_convert(Cstring, model_library),
                            Int32(horizon), Int32(batch), Int32(device), Int32(constrained))
-        check(ccall((:ilqr_create, LIB[]), Cint, (Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), desc, h))
+        if isempty(devices)
+            check(ccall((:ilqr_create, LIB[]), Cint, (Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), desc, h))
+        else
+            devs = Int32.(collect(devices))
+            check(ccall((:ilqr_create_sharded, LIB[]), Cint, (Ref{ProblemDesc}, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}),
+                        desc, devs, Int32(length(devs)), h))
+        end
     end
     d = [Ref{Int32}(0) for _ in 1:7]
     check(ccall((:ilqr_get_dims, LIB[]), Cint,
@@ -201,6 +210,17 @@ function Constraint(Symbolics, f::Function, num_state::Int, num_action::Int; ind
     Constraint(body, length(c), num_state, num_action, num_parameter, indices_inequality)
 end
 
+# The reference's own signatures — Dynamics(f, nx, nu; num_parameter), Cost(f, nx, nu; num_parameter),
+# Constraint(f, nx, nu; indices_inequality, num_parameter) (src/dynamics.jl:16, src/costs.jl:17, src/constraints.jl:17) —
+# with Symbolics taken from the session (`using Symbolics` before the first call, as a user of the reference has anyway)
+function symbolics_module()
+    isdefined(Main, :Symbolics) || error("IterativeLQRAMD: `using Symbolics` first (the constructors trace the user function symbolically, as the reference does)")
+    return getfield(Main, :Symbolics)
+end
+Dynamics(f::Function, num_state::Int, num_action::Int; kwargs...) = Dynamics(symbolics_module(), f, num_state, num_action; kwargs...)
+Cost(f::Function, num_state::Int, num_action::Int; kwargs...) = Cost(symbolics_module(), f, num_state, num_action; kwargs...)
+Constraint(f::Function, num_state::Int, num_action::Int; kwargs...) = Constraint(symbolics_module(), f, num_state, num_action; kwargs...)
+
 struct ModelSource
     name::Cstring; nx::Int32; nu::Int32; nw::Int32; nc_stage::Int32; nc_term::Int32
     ineq_stage::UInt64; ineq_term::UInt64; source::Cstring
@@ -215,7 +235,18 @@ ineq_mask(idx) = reduce(|, (UInt64(1) << (i - 1) for i in idx); init = UInt64(0)
 the Python host, lowering.py), `costs[end]` / `constraints[end]` the terminal ones.
 """
 function Solver(dynamics::Vector{Dynamics}, costs::Vector{Cost}, constraints::Vector{Constraint};
-                batch::Integer, options::Options = Options(), name::AbstractString = "user", device::Integer = 0)
+                batch::Integer, options::Options = Options(), name::AbstractString = "user", device::Integer = 0,
+                devices::AbstractVector{<:Integer} = Int[], constrained::Bool = true)
+    # The device kernels are compiled for ONE stage template. Distinct per-step objects (README.md:26 of the reference) are
+    # lowered onto it by the Python host only (lowering.py); here they are refused instead of silently solving with [1].
+    length(costs) == length(dynamics) + 1 && length(constraints) == length(costs) ||
+        error("Solver: expected T-1 dynamics, T costs and T constraints (src/solver.jl:28-46)")
+    all(x -> x.body == dynamics[1].body, dynamics) ||
+        error("Solver: per-step Dynamics objects differ; this wrapper takes one stage template (use the Python host's lowering)")
+    all(x -> x.body == costs[1].body, costs[1:end-1]) ||
+        error("Solver: per-step stage Cost objects differ; this wrapper takes one stage template (use the Python host's lowering)")
+    all(x -> x.body == constraints[1].body && x.indices_inequality == constraints[1].indices_inequality, constraints[1:end-1]) ||
+        error("Solver: per-step stage Constraint objects differ; this wrapper takes one stage template (use the Python host's lowering)")
     d, cs, ct = dynamics[1], constraints[1], constraints[end]
     source = d.body * costs[1].body * costs[end].body * cs.body * ct.body
     regname = Vector{UInt8}(undef, 128); path = Vector{UInt8}(undef, 1024)
@@ -226,8 +257,14 @@ function Solver(dynamics::Vector{Dynamics}, costs::Vector{Cost}, constraints::Ve
         check(ccall((:ilqr_compile_model, LIB[]), Cint, (Ref{ModelSource}, Ptr{UInt8}, Csize_t, Ptr{UInt8}, Csize_t),
                     ms, regname, length(regname), path, length(path)))
     end
-    Solver(unsafe_string(pointer(regname)); horizon = length(costs), batch = batch, constrained = true, options = options,
-           device = device, model_library = unsafe_string(pointer(path)))
+    Solver(unsafe_string(pointer(regname)); horizon = length(costs), batch = batch, constrained = constrained, options = options,
+           device = device, devices = devices, model_library = unsafe_string(pointer(path)))
+end
+
+# Solver(dynamics, costs) — src/solver.jl:11-26: no constraints, plain iLQR
+function Solver(dynamics::Vector{Dynamics}, costs::Vector{Cost}; kwargs...)
+    T = length(costs)
+    return Solver(dynamics, costs, [Constraint() for _ in 1:T]; constrained = false, kwargs...)
 end
 
 # solve!(solver; augmented_lagrangian_callback! = cb) — src/solve.jl:88,125: the outer AL loop stepped from the host, one launch

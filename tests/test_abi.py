@@ -57,6 +57,14 @@ def test_no_cpu_fallback(pkg):
     assert L.ilqr_create(C.byref(desc), C.byref(h)) < 0
     assert b"unknown model" in L.ilqr_last_error()
     assert L.ilqr_solve(None) < 0 and L.ilqr_get_stats(None, None) < 0
+    # the sharded constructor refuses the same way (and validates its device list first)
+    with pytest.raises(pkg._ffi.IlqrError, match="no HIP device"):
+        pkg.Solver(model="acrobot", horizon=101, batch=4, devices=[0, 0])
+    good = pkg._ffi.ProblemDesc(b"acrobot", None, 11, 2, 0, 1)
+    devs = (C.c_int32 * 3)(0, 0, 0)
+    assert L.ilqr_create_sharded(C.byref(good), devs, 0, C.byref(h)) < 0 and b"empty device list" in L.ilqr_last_error()
+    assert L.ilqr_create_sharded(C.byref(good), devs, 3, C.byref(h)) < 0 and b"more devices than instances" in L.ilqr_last_error()
+    assert L.ilqr_create_sharded(C.byref(good), None, 1, C.byref(h)) < 0
 
 
 class _ModelSource(C.Structure):

@@ -1093,3 +1093,37 @@ def test_cooperative_rollout_with_a_parameter_inside_a_trig_argument(pkg):
             assert st["iterations"][b] == s_.iterations and st["rollouts"][b] == s_.rollouts, (variant, b, st["iterations"][b], s_.iterations)
             assert np.abs(x[b] - np.stack(s_.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s_.nominal_actions[:-1])).max() < 1e-8
         sol.close()
+
+
+@pytest.mark.parametrize("config,B,devices", [("acrobot51", 64, [0, 0]), ("car", 96, [0, 0]), ("particle", 7, [0, 0, 0]), ("synth32", 5, [0, 0])])
+def test_sharded_handle_equals_single_handle(pkg, config, B, devices):
+    """ilqr_create_sharded (one Solver spanning several GPUs, as the reference's caller holds one Solver,
+    src/solver.jl:28-46): the batch split into contiguous ranges over a device list — here sub-handles on the one GPU of the
+    box — must reproduce the single handle BITWISE through every accessor (instances are independent; no data crosses ranges)."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+    opt = dict(verbose=0, max_iterations=12) if config == "acrobot51" else dict(verbose=0)
+    one = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(**opt))
+    many = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(**opt), devices=devices)
+    assert (many.nx, many.nu, many.B, many.T) == (one.nx, one.nu, B, T)
+    for s in (one, many):
+        s.enable_trace_(16)
+        s.initialize_rollout_(x1, ub); s.solve_()
+    for a, b in zip(one.get_trajectory() + one.get_policy(), many.get_trajectory() + many.get_policy()):
+        assert np.array_equal(a, b, equal_nan=True)
+    sa, sb = one.stats(), many.stats()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    assert np.array_equal(one.trace(), many.trace(), equal_nan=True)
+    for name in ("violations", "constraint_dual", "gradient_state", "K"):
+        assert np.array_equal(one.buffer(name), many.buffer(name), equal_nan=True), name
+    # setters scatter: a warm start through the sharded handle equals the same through the single one
+    x, u = one.get_trajectory()
+    for s in (one, many):
+        s.reset_(); s.initialize_controls_(u * 0.9); s.initialize_states_(x); s.solve_()
+    assert np.array_equal(one.get_trajectory()[0], many.get_trajectory()[0], equal_nan=True)
+    # stage entry points and the host-stepped loop run on every range
+    for s in (one, many):
+        s.reset_(); s.initialize_rollout_(x1, ub); s.run_stage_("cost_nominal"); s.run_stage_("gradients"); s.run_stage_("backward_pass")
+    assert np.array_equal(one.buffer("P"), many.buffer("P"), equal_nan=True)
+    assert many.timing()[1] >= 1 and many.timing()[0] > 0.0
+    one.close(); many.close()
