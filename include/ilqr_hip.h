@@ -194,13 +194,12 @@ int ilqr_enable_action_value_buffers(ilqr_handle* h);
  * "inner_done", "j_prev", "inner_it". -1 if unknown. */
 int ilqr_scalar_slot(const char* name);
 
-/* Kernel variant of ilqr_solve: 0 = auto (default: the latency kernel — two waves per instance, all iteration
- * state in LDS — while the batch fits the chip (one instance per SIMD); the throughput kernel — one wave per
- * instance, two instances per SIMD, Jacobians in HBM/L2 — up to two instances per SIMD; beyond that the packed
- * kernel — FOUR instances per wave on the four blocks of v_mfma_f64_4x4x4, workspace streamed from HBM/L2, no LDS
- * and therefore no horizon limit; nx, nu <= 4), 1 = latency, 2 = throughput, 3 = packed. All run the same
- * arithmetic up to the association of a few sums. Horizons whose LDS-resident set exceeds the 160 KiB of a CU run
- * on the packed kernel only (ILQR_ERR_LDS for models without one). */
+/* Kernel variant of ilqr_solve (small models, nx, nu <= 4; large models have one kernel family): 0 = auto — the latency kernel
+ * (two waves per instance, all iteration state in LDS) while the batch fits the chip at one instance per SIMD (batch <= 4 x CUs),
+ * the packed kernel beyond that and for horizons whose LDS-resident set exceeds the 160 KiB of a CU; 1 = latency; 2 = throughput
+ * (one wave per instance, Jacobians in HBM / L2; superseded by the packed kernel, kept for A/B runs); 3 = packed — FOUR
+ * instances per wave on the four blocks of v_mfma_f64_4x4x4, workspace streamed from HBM / L2 through a 13 KB LDS chunk buffer
+ * per wave, no horizon limit. All run the same arithmetic up to the association of a few sums. */
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);
 
 /* Per-iteration record of what the reference prints when `verbose` (src/solve.jl:40-45): for every

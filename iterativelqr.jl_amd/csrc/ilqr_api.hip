@@ -279,19 +279,28 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
     const std::string csrc = env_csrc ? env_csrc : libdir + "/../csrc";
     const char* env_hipcc = std::getenv("ILQR_HIPCC");
     const std::string hipcc = env_hipcc ? env_hipcc : "/opt/rocm/bin/hipcc";
-    // tag = FNV-1a over everything that ends up in the module: source, dimensions, ABI version
+    // tag = FNV-1a over everything that ends up in the module: source, dimensions, ABI version and the hash of the kernel
+    // headers + compiler flags this library was built from (ILQR_BUILD_HASH, computed by the Makefile): a kernel fix without an
+    // ABI bump must not be served a module compiled against the old kernels
     unsigned long long hsh = 1469598103934665603ull;
     auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; ++i) { hsh ^= ((const unsigned char*)p)[i]; hsh *= 1099511628211ull; } };
     mix(src->source, std::strlen(src->source)); mix(src->name, std::strlen(src->name));
     const long long dims[8] = {src->nx, src->nu, src->nw, src->nc_stage, src->nc_term, (long long)src->ineq_stage, (long long)src->ineq_term,
                                ILQR_MODEL_ABI_VERSION * 1000 + (long long)sizeof(ilqr::KArgs)};
     mix(dims, sizeof(dims));
+#ifdef ILQR_BUILD_HASH
+    mix(ILQR_BUILD_HASH, std::strlen(ILQR_BUILD_HASH));
+#endif
     char tag[32];
     std::snprintf(tag, sizeof(tag), "%016llx", hsh);
     const std::string uname = std::string(src->name) + "_c" + tag;
     const std::string dir = libdir + "/models";
     mkdir(dir.c_str(), 0755);
-    const std::string so = dir + "/libilqr_model_" + uname + ".so", hip = dir + "/model_" + uname + ".hip", log = dir + "/model_" + uname + ".log";
+    // source and log are written under process-unique names: ranks compiling the same model at the same time must not truncate
+    // each other's input under a running hipcc (the module itself is moved into place atomically)
+    const std::string pid = std::to_string((long)getpid());
+    const std::string so = dir + "/libilqr_model_" + uname + ".so", hip = dir + "/model_" + uname + "." + pid + ".hip",
+                      log = dir + "/model_" + uname + "." + pid + ".log";
     if (uname.size() + 1 > name_len || so.size() + 1 > path_len) return fail(ILQR_ERR_INVALID, "output buffers too small");
     struct stat st;
     if (stat(so.c_str(), &st) != 0) {
@@ -320,7 +329,7 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
                      (unsigned long long)src->ineq_stage, (unsigned long long)src->ineq_term, uname.c_str(), uname.c_str());
         std::fclose(f);
         // hipcc as a child process (no shell): same flags as the built-in models
-        const std::string tmp = so + ".tmp" + std::to_string((long)getpid());
+        const std::string tmp = so + ".tmp" + pid;
         const std::string inc = "-I" + csrc, lflag = "-L" + libdir, rpath = "-Wl,-rpath," + libdir;
         std::vector<const char*> argv = {hipcc.c_str(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
                                          "-amdgpu-mfma-vgpr-form", "-Wno-unused-parameter", inc.c_str(), hip.c_str(), "-o", tmp.c_str(),
@@ -347,6 +356,8 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
             return fail(ILQR_ERR_MODEL, msg);
         }
         if (std::rename(tmp.c_str(), so.c_str()) != 0) return fail(ILQR_ERR_MODEL, "cannot move the model module into place");
+        std::remove(hip.c_str());
+        std::remove(log.c_str());
     }
     if (!dlopen(so.c_str(), RTLD_NOW | RTLD_GLOBAL)) return fail(ILQR_ERR_MODEL, std::string("dlopen failed: ") + dlerror());
     if (!find_model(uname.c_str())) return fail(ILQR_ERR_MODEL, "the compiled module did not register '" + uname + "' (ABI mismatch?)");
@@ -574,7 +585,9 @@ int ilqr_solve(ilqr_handle* h) {
                       (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
     if (!packed && !h->lds_fits) return drop(fail(ILQR_ERR_LDS, "this horizon only runs on the packed kernel"));
     if (packed) {
-        if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);      // phase-timing hook, see ilqr_device_packed.hpp
+#ifdef ILQR_PK_DEBUG_HOOK      // phase-timing hook of tools/packed_phases.py (see ilqr_device_packed.hpp); never compiled into the product library
+        if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);
+#endif
         if (h->vt->launch_solve_packed(&a, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (packed variant) launch failed"));
     } else if (slim) {
         if (h->vt->launch_solve_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)

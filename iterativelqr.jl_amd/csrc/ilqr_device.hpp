@@ -1462,7 +1462,7 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
             I.iterations += 1;                                        // (:39)
             if (I.trace != nullptr && I.trace_len < I.trace_cap && I.lane == 0) {     // verbose record (:40-45)
                 double* r = I.trace + (size_t)I.trace_len * TRACE_W;
-                r[0] = (double)(al_outer ? o : 0); r[1] = (double)it; r[2] = I.objective; r[3] = I.gradient_norm;
+                r[0] = (double)(al_outer ? o : I.outer_iterations); r[1] = (double)it; r[2] = I.objective; r[3] = I.gradient_norm;
                 r[4] = I.max_violation; r[5] = I.step_size; r[6] = (double)I.status; r[7] = (double)I.rollouts;
             }
             I.trace_len += 1;
@@ -1492,7 +1492,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x & 63; I.wave = threadIdx.x >> 6;
     I.lds = smem; I.gbase = g; I.fv_off = 0; I.hc_off = 0;
     I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
-    I.trace_cap = a.trace_cap; I.trace_len = 0;
+    I.trace_cap = a.trace_cap; I.trace_len = 0;      // (the stage kernel continues from the stored count, see there)
     I.Q = a.qv ? a.qv + (size_t)b * (size_t)a.QL.stride : nullptr; I.QL = a.QL;
     I.delta = I.scal[S_DELTA]; I.delta_next = 0.0; I.delta_next_ok = 0;
     if constexpr (is_large<M>::value) {
@@ -1595,6 +1595,10 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, 2) void stage_kernel(KArgs
     // host-stepped AL loop (solve! with augmented_lagrangian_callback!, src/solve.jl:88,125): instances that
     // already met the constraint tolerance sit out the remaining outer iterations
     const bool done = I.scal[S_DONE] != 0.0 && a.stage > ILQR_STAGE_AL_BEGIN;      // AL_BEGIN itself re-arms a finished instance
+    // per-iteration trace across the launches of a host-stepped solve (augmented_lagrangian_callback! path): AL_BEGIN and a
+    // stand-alone ILQR_SOLVE start a new record, every later stage appends to it
+    const bool trace_restart = a.stage == ILQR_STAGE_AL_BEGIN || a.stage == ILQR_STAGE_ILQR_SOLVE;
+    I.trace_len = trace_restart ? 0 : (int)I.scal[S_TRACE_LEN];
     if (!done) switch (a.stage) {
         case ILQR_STAGE_COST_NOMINAL: cost_bang<M>(I, false, con); break;
         case ILQR_STAGE_GRADIENTS: gradients<M>(I, con); break;
@@ -1685,6 +1689,8 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, 2) void stage_kernel(KArgs
         } break;
         default: break;
     }
+    if (I.lane == 0 && I.wave == 0 && (trace_restart || (!done && I.trace != nullptr)))
+        I.scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
     inst_writeback<M>(I, a, smem, b);
 }
 

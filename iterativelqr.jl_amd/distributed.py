@@ -57,19 +57,36 @@ def launch_ranks(script, argv, nproc, share_device=False, stub=False, timeout=No
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = b""
+    # rank 0's pipe is drained by a thread while ALL children are polled: a rank that dies at start-up (no GPU, import error)
+    # must end the job at once — the others would sit in init_process_group / a barrier until the collective timeout
+    import threading
+    import time
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
+    deadline = None if timeout is None else time.time() + timeout
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for p in procs:
-            p.wait(timeout=timeout)
-            rc = rc or p.returncode
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed:
+                rc = failed[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if deadline is not None and time.time() > deadline:
+                rc = 124
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:           # exactly the children started here, by PID
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=5)
+    out0 = b"".join(c for c in chunks if c)
     return rc, out0.decode()
 
 

@@ -61,3 +61,16 @@ def test_driver_style_torchrun_launch():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks"]["group_world_size"] == 2 and "torchrun" in out["ranks"]["launcher"]
+
+
+def test_a_rank_that_dies_at_start_up_ends_the_job_at_once(tmp_path):
+    """launch_ranks polls every child: rank 1 exiting non-zero must not leave rank 0 waiting in a barrier until a timeout."""
+    import time
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
+    script = tmp_path / "ranks.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\nprint('rank0 up', flush=True)\ntime.sleep(120)\n")
+    t0 = time.time()
+    rc, out = pkg.distributed.launch_ranks(str(script), [], 2, stub=True, timeout=100)
+    assert rc == 3 and time.time() - t0 < 20
+    assert "rank0 up" in out or out == ""

@@ -528,13 +528,24 @@ def test_host_stepped_al_loop_with_callback(pkg):
     model, T, x1, ub = pkg.workloads.make_inputs("car_obs", B)
     w = pkg.workloads.make_parameters("car_obs", B)
     fused = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    fused.enable_trace_(128)
     fused.set_parameters_(w); fused.initialize_rollout_(x1, ub); fused.solve_()
     xf, uf = fused.get_trajectory(); sf = fused.stats()
     calls = []
     stepped = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    stepped.enable_trace_(128)
     stepped.set_parameters_(w); stepped.initialize_rollout_(x1, ub)
     stepped.solve_(augmented_lagrangian_callback_=lambda s: calls.append(1))
     xs, us = stepped.get_trajectory(); ss = stepped.stats()
+    # the per-iteration record survives the launches of the stepped loop: as many rows as the fused solve wrote, same
+    # (outer, inner, step size, status) columns
+    tl_f, tl_s = fused.scalar("trace_len"), stepped.scalar("trace_len")
+    assert (tl_f == sf["iterations"]).all() and (tl_s == ss["iterations"]).all()
+    tf, ts = fused.trace(), stepped.trace()
+    for b in range(B):
+        if sf["iterations"][b] == ss["iterations"][b]:
+            k = int(tl_f[b])
+            assert np.array_equal(tf[b, :k][:, [0, 1, 5, 6]], ts[b, :k][:, [0, 1, 5, 6]]), b
     # the stepped loop runs the same device functions from another kernel: same results up to the
     # compiler's FMA-contraction choices in the two inlining contexts
     same = (sf["iterations"] == ss["iterations"]) & (sf["rollouts"] == ss["rollouts"])

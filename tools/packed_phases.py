@@ -1,4 +1,6 @@
-"""Per-phase time of the packed kernel in fixed-work mode (ILQR_PK_DEBUG bit 0: every instance takes every phase for
+"""Needs a library built with the hook:  make -C iterativelqr.jl_amd/csrc LIBDIR=../lib_dbg EXTRA_API=-DILQR_PK_DEBUG_HOOK  and
+ILQR_LIB pointing at it (the product library ignores ILQR_PK_DEBUG).
+Per-phase time of the packed kernel in fixed-work mode (ILQR_PK_DEBUG bit 0: every instance takes every phase for
 max_iterations cycles, nothing is accepted): kernel ms per cycle with one phase left out at a time."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
