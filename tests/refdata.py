@@ -7,7 +7,14 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "ref_*.npz")))
+# ref_<case>_julia.npz — the same schema produced by the REAL package (tests/golden/make_julia_fixtures.jl + julia_to_npz.py) —
+# takes precedence over the restatement's ref_<case>.npz wherever it exists (none can be produced in this image: no Julia)
+CASES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "ref_*.npz")) if not p.endswith("_julia.npz"))
+
+
+def source_of(case):
+    """"julia" if the reference itself produced this case's numbers, "restatement" otherwise."""
+    return "julia" if os.path.exists(os.path.join(GOLDEN, "ref_%s_julia.npz" % case)) else "restatement"
 
 # fixture key -> reference field name used by orc_buffer / ilqr_get_buffer
 FIELD = {"fx": "jacobian_state", "fu": "jacobian_action", "gx": "gradient_state", "gu": "gradient_action",
@@ -19,7 +26,10 @@ MODEL_OF = {"particle": "particle", "car": "car", "car_goal": "car_goal", "acrob
 
 
 def load(case):
-    d = dict(np.load(os.path.join(GOLDEN, "ref_%s.npz" % case)))
+    path = os.path.join(GOLDEN, "ref_%s_julia.npz" % case)
+    if not os.path.exists(path):
+        path = os.path.join(GOLDEN, "ref_%s.npz" % case)
+    d = dict(np.load(path))
     d["model"] = "car_goal" if case.startswith("car_goal") else MODEL_OF[case.split("_")[0]]
     d["T"] = int(d["horizon"][0])
     return d

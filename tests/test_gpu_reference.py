@@ -166,3 +166,40 @@ def test_hip_whole_solve_matches_reference_fixture(pkg, case):
         assert dK <= 5e-7, (case, variant, dK)
         assert np.abs(k[0] - d["k"]).max() <= 1e-6 * max(1.0, np.abs(d["k"]).max())
         sol.close()
+
+
+@pytest.mark.parametrize("family,B", [("acrobot", 7), ("car", 5), ("particle", 6), ("car_goal", 5)])
+def test_packed_kernel_with_several_fixture_instances_in_one_handle(pkg, family, B):
+    """The fixtures' instances side by side in ONE handle on the packed kernel (four instances per wave: a full wave plus a
+    ragged one, neighbours in different phases of their state machines): every instance must reproduce its own fixture —
+    trace exact, trajectories and gains within the whole-solve tolerance — exactly as it does alone."""
+    cases = [c for c in CASES if c.startswith(family + "_i") or (family == "particle" and c == "particle_sin")]
+    assert len(cases) >= 2
+    order = [cases[i % len(cases)] for i in [0, 1, 2, 1, 0, 2, 1][:B]]
+    ds = [load(c) for c in order]
+    T, model = ds[0]["T"], ds[0]["model"]
+    assert all(d["T"] == T and d["model"] == model for d in ds)
+    cap = max(d["trace"].shape[0] for d in ds) + 8
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.set_kernel_variant_("packed")
+    sol.enable_trace_(cap)
+    sol.initialize_rollout_(np.stack([d["x1"] for d in ds]), np.stack([d["ubar"] for d in ds]))
+    sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    tl = sol.scalar("trace_len").astype(int); tr = sol.trace()
+    for b, d in enumerate(ds):
+        ref = d["trace"]
+        assert tl[b] == ref.shape[0], (order[b], b, tl[b], ref.shape[0])
+        assert np.array_equal(tr[b, :tl[b]][:, [0, 1, 5, 6, 7]], ref[:, [0, 1, 5, 6, 7]]), (order[b], b)
+        assert np.allclose(tr[b, :tl[b], 2], ref[:, 2], rtol=1e-8, atol=1e-12)
+        got = (st["iterations"][b], st["outer_iterations"][b], st["status"][b], st["rollouts"][b], st["potrf_info"][b])
+        assert tuple(int(v) for v in got) == tuple(int(v) for v in d["stats"][4:9]), (order[b], b)
+        assert np.abs(x[b] - d["x"]).max() <= 1e-7 and np.abs(u[b] - d["u"]).max() <= 1e-7, (order[b], b)
+        Kd = K[b].transpose(0, 2, 1)
+        assert np.abs(Kd - d["K"]).max() <= 5e-7 * max(1.0, np.abs(d["K"]).max()), (order[b], b)
+    # equal fixtures in different lanes of different waves give bitwise equal results
+    for b in range(B):
+        for c in range(b + 1, B):
+            if order[b] == order[c]:
+                assert np.array_equal(x[b], x[c]) and np.array_equal(K[b], K[c]), (b, c)
+    sol.close()

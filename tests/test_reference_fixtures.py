@@ -16,6 +16,7 @@ import sys
 import numpy as np
 import pytest
 
+import refdata
 from refdata import CASES, FIELD, colmajor, load, npoints, rel
 
 STAGE_TOL = 1e-11
@@ -176,3 +177,39 @@ def test_reference_fingerprints_in_fixtures():
     g = load("particle_sin")["trace"]
     g1 = g[g[:, 0] == 1][:, 3]
     assert np.allclose(g1 * np.arange(1, g1.size + 1), g1[0], rtol=1e-6)                # Q1 fingerprint: ‖∇L‖∞ ∝ 1/k
+
+
+def test_julia_fixture_route_round_trips(tmp_path):
+    """The route to a reference-produced pin (tests/golden/make_julia_fixtures.jl runs the REAL package; no Julia here): its
+    input dump and its output converter are exercised by writing an existing fixture in the Julia script's on-disk format
+    (column-major arrays + manifest) and converting it back — every key must come back bit for bit, and refdata must then
+    prefer the *_julia file."""
+    import sys
+    sys.path.insert(0, refdata.GOLDEN)
+    import dump_fixture_inputs
+    import julia_to_npz
+    ind = dump_fixture_inputs.main(str(tmp_path / "julia_in"))
+    case = "car_i1"
+    d = dict(np.load(os.path.join(refdata.GOLDEN, "ref_%s.npz" % case)))
+    lines = open(os.path.join(ind, case + ".txt")).read().split("\n")
+    assert lines[0] == "car" and int(lines[1]) == 51 and int(lines[2]) == 3
+    assert np.array_equal(np.fromfile(os.path.join(ind, case + ".u.f64")).reshape(50, 2), d["ubar"])
+    src = tmp_path / "julia_out" / case
+    src.mkdir(parents=True)
+    with open(src / "manifest.txt", "w") as man:
+        for key, a in d.items():
+            a = np.asarray(a, dtype=np.float64)
+            if a.ndim == 3:
+                jl = a.transpose(1, 2, 0)              # [t][row][col] -> Julia (rows, cols, T)
+            elif a.ndim == 2:
+                jl = a.T                               # [t][i] -> Julia (n, T)
+            else:
+                jl = a
+            jl.ravel(order="F").astype("<f8").tofile(src / (key + ".f64"))
+            man.write("%s %s\n" % (key, " ".join(str(v) for v in jl.shape)))
+    assert julia_to_npz.main(str(tmp_path / "julia_out"), str(tmp_path)) == [case]
+    back = dict(np.load(tmp_path / ("ref_%s_julia.npz" % case)))
+    assert set(back) == set(d)
+    for key in d:
+        assert back[key].shape == d[key].shape and np.array_equal(back[key], np.asarray(d[key], dtype=back[key].dtype)), key
+    assert refdata.source_of(case) == "restatement"     # nothing of the kind is committed: the image has no Julia
