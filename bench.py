@@ -335,23 +335,26 @@ def worker(args):
                 roof["traffic_over_algorithmic"] = tr["traffic_bytes_per_launch"] / abytes
             else:
                 roof["traffic_unmeasured_reason"] = why
-        try:     # instruction-issue model of the critical path (tools/issue_model.py, from the ISA of this build)
-            im = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json"))).get("%s" % args.config)
-            if im and kernel_ms > 0 and args.variant in ("auto", "latency") and B <= 1024:
-                rollouts_per_iter = float(st["rollouts"].sum()) / max(1.0, it_sum)
-                per_iter_clk = (T - 1) * (im["rollout_step_occupancy_clk"] * rollouts_per_iter + im["riccati_step_occupancy_clk"]) \
-                    + im["per_iteration_other_clk"]
-                slots_iter = (T - 1) * (im["rollout_step_instr"] * rollouts_per_iter + im["riccati_step_instr"])
-                floor_ms = it_max * per_iter_clk / (im["clock_ghz"] * 1e6)
-                roof["actual_bound"] = ("instruction issue of ONE wave: the slowest instance's critical wave issues one instruction per 5-6 clk "
-                                        "whatever its class (tools/probes/probe_issue.hip), so its serial loops last as long as their "
-                                        "instruction lists; predicted_floor_ms prices this build's lists at those rates")
-                roof["issue_model"] = dict(im, iterations_max=it_max, rollouts_per_iteration=rollouts_per_iter,
-                                           issue_slots_per_iteration=slots_iter,
-                                           measured_clk_per_issue_slot=kernel_ms * im["clock_ghz"] * 1e6 / (it_max * slots_iter),
-                                           predicted_floor_ms=floor_ms, achieved_over_floor=kernel_ms / floor_ms)
-        except (OSError, ValueError, KeyError):
-            pass
+        # instruction-issue model of the critical path: the per-step instruction lists of the serial loops, read off the assembly
+        # the library's own compilation kept (csrc/Makefile -> lib/issue_model.json, stamped with the device-source hash)
+        im, why_not = pkg._ffi.issue_model(model)
+        if im is None:
+            roof["issue_model_unavailable"] = why_not
+        elif kernel_ms > 0 and args.variant in ("auto", "latency") and B <= 1024 and sol.nx <= 4 and sol.nu <= 4:
+            rollouts_per_iter = float(st["rollouts"].sum()) / max(1.0, it_sum)
+            per_iter_clk = (T - 1) * (im["rollout_step_occupancy_clk"] * rollouts_per_iter + im["riccati_step_occupancy_clk"]) \
+                + im["per_iteration_other_clk"]
+            slots_iter = (T - 1) * (im["rollout_step_instr"] * rollouts_per_iter + im["riccati_step_instr"])
+            floor_ms = it_max * per_iter_clk / (im["clock_ghz"] * 1e6)
+            roof["bound"] = "issue"
+            roof["roofline_kind"] = "hbm (SURVEY §8(d): achieved / peak / frac are the modelled HBM figure the survey asks for)"
+            roof["actual_bound"] = ("instruction issue of ONE wave: the slowest instance's critical wave issues one instruction per 5-6 clk "
+                                    "whatever its class (tools/probes/probe_issue.hip), so its serial loops last as long as their "
+                                    "instruction lists; predicted_floor_ms prices this build's lists at those rates")
+            roof["issue_model"] = dict(im, iterations_max=it_max, rollouts_per_iteration=rollouts_per_iter,
+                                       issue_slots_per_iteration=slots_iter,
+                                       measured_clk_per_issue_slot=kernel_ms * im["clock_ghz"] * 1e6 / (it_max * slots_iter),
+                                       predicted_floor_ms=floor_ms, achieved_over_floor=kernel_ms / floor_ms)
         out["roofline"] = roof
 
         if world == 1:

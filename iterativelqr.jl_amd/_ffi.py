@@ -91,6 +91,38 @@ def build(force=False):
     return LIB_PATH
 
 
+def device_source_hash():
+    """sha256 over the device sources a build of the library is made from (names and contents, sorted) — the stamp
+    tools/issue_model.py puts on lib/issue_model.json at build time (the same function there; tests/test_abi.py compares them)."""
+    import hashlib
+    root = os.path.dirname(_HERE)
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))] +
+                   [os.path.join(CSRC, "models", f) for f in os.listdir(os.path.join(CSRC, "models")) if f.endswith(".h")] +
+                   [os.path.join(INCLUDE, "ilqr_hip.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def issue_model(config):
+    """The per-loop instruction lists of the library's own compilation (lib/issue_model.json, written by csrc/Makefile), or
+    (None, reason) when there is none for this model or it was made from other sources than the ones in the tree."""
+    import json
+    path = os.path.join(os.path.dirname(LIB_PATH), "issue_model.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError) as e:
+        return None, "no issue model next to the library (%s)" % e
+    stamp = d.get("_build", {}).get("source_hash")
+    if stamp != device_source_hash():
+        return None, "stale: built from sources %s, the tree is %s — rebuild (make -C iterativelqr.jl_amd/csrc)" % (stamp, device_source_hash())
+    if config not in d:
+        return None, "no serial-loop model for %r" % config
+    return dict(d[config], source_hash=stamp, built_from=d["_build"].get("from")), None
+
+
 def lib():
     """Load libilqr_hip.so; the product path has no fallback if it is missing."""
     global _lib

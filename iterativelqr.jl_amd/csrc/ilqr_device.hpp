@@ -127,13 +127,10 @@ __device__ __forceinline__ void load_w(const double* W, int t, double (&w)[cdim<
 #define ILQR_PROF_END(I, slot) do {} while (0)
 #endif
 enum { PROF_COST = 0, PROF_GRAD, PROF_BACKWARD, PROF_DELTA, PROF_ROLLOUT, PROF_OTHER, PROF_N };
-// -DILQR_ISA_MARKERS (analysis builds only, tools/issue_model.py): comment markers at the head of every timestep body of the
-// serial loops, so that the loops can be found and their per-step instruction counts read off the assembly
-#ifdef ILQR_ISA_MARKERS
+// Comment markers at the head of every timestep body of the serial loops: tools/issue_model.py finds the loops in the assembly
+// the build keeps (-save-temps, csrc/Makefile) and reads their per-step instruction counts off it. An empty asm statement: it
+// emits no instruction (same-box A/B of the library with and without the markers: profiles/r03_ab_markers.txt).
 #define ILQR_ISA_MARK(name, role) asm volatile("; ILQR_MARK " name " %0" ::"i"(role))
-#else
-#define ILQR_ISA_MARK(name, role) do {} while (0)
-#endif
 
 // Per-instance context. LDS pointers first, then HBM pointers, then the
 // wave-uniform SolverData scalars (src/data/solver.jl:4-18) kept in registers.

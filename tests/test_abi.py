@@ -109,3 +109,20 @@ def test_compile_model_from_c_source_without_python_codegen(pkg):
     assert L.ilqr_compile_model(C.byref(bad), name2, 128, path, 1024) < 0 and b"hipcc failed" in L.ilqr_last_error()
     big = _ModelSource(b"abi_big", 9, 1, 0, 0, 0, 0, 0, b"")
     assert L.ilqr_compile_model(C.byref(big), name2, 128, path, 1024) < 0
+
+
+def test_issue_model_is_a_product_of_the_build_and_goes_stale_with_the_sources(pkg, tmp_path, monkeypatch):
+    """csrc/Makefile writes lib/issue_model.json from the assembly of the library's own compilation, stamped with the hash of
+    the device sources; the loader refuses it once the sources differ (bench.py then reports why instead of comparing the
+    measurement with another build's instruction lists)."""
+    import importlib.util
+    im, why = pkg._ffi.issue_model("acrobot")
+    assert im is not None, why
+    assert im["rollout_step_instr"] > 50 and im["riccati_step_instr"] > 30 and "save-temps" in im["built_from"]
+    spec = importlib.util.spec_from_file_location("issue_model_tool", os.path.join(ROOT, "tools", "issue_model.py"))
+    tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+    assert tool.device_source_hash() == pkg._ffi.device_source_hash() == im["source_hash"]
+    assert pkg._ffi.issue_model("no_such_model")[0] is None
+    monkeypatch.setattr(pkg._ffi, "device_source_hash", lambda: "0" * 16)      # as if a kernel header had been edited
+    im2, why2 = pkg._ffi.issue_model("acrobot")
+    assert im2 is None and "stale" in why2

@@ -1,14 +1,19 @@
 """Instruction-issue model of the latency kernel's critical path, from the ISA of THIS build.
 
-    python tools/issue_model.py [config ...]      # writes profiles/issue_model.json, prints the loop table
+    python tools/issue_model.py --asm FILE.s --out issue_model.json [--flags "..."]    # what csrc/Makefile runs on the assembly
+                                                                                        # the library's own compilation kept
+    python tools/issue_model.py [config ...]      # stand-alone: compiles to assembly itself, prints the loop table
+
+The build writes lib/issue_model.json stamped with a hash of the device sources; bench.py recomputes that hash and drops a
+stale model instead of comparing the measurement with another build's instruction lists.
 
 What bounds solve_kernel<Model_acrobot> at batch 1024 is not HBM (counter traffic well under 1 % of peak) but the serial
 instruction stream of each instance's slowest wave. tools/probes/probe_issue.hip (profiles/r02_probe_issue.txt) measures what
 ONE wave can issue on gfx950: one instruction every ~5.1-6 shader clocks whatever its class (fp64 / integer VALU, DPP,
 v_readlane, scalar ALU, s_nop) and whether or not it depends on the previous one; a 4x4x4 f64 MFMA every ~17 clk; an LDS write
 every ~13 clk; LDS reads ~7-10 clk. So the step of a serial loop lasts as long as its instruction list, and instruction-level
-parallelism inside the wave buys nothing. This script compiles csrc/builtin_models.hip to assembly, finds the serial time
-loops of solve_kernel<Model_X> through comment markers (-DILQR_ISA_MARKERS) and LLVM's loop annotations, and counts the
+parallelism inside the wave buys nothing. This script reads the assembly of csrc/builtin_models.hip, finds the serial time
+loops of solve_kernel<Model_X> through the comment markers the kernels carry (ILQR_ISA_MARK) and LLVM's loop annotations, and counts the
 instructions ISSUED per timestep on each wave by class (s_nop N counts N+1 idle states). bench.py turns them into the issue
 time of the slowest instance's critical wave (roofline.issue_model.predicted_floor_ms, achieved_over_floor)."""
 import json
@@ -30,13 +35,26 @@ OCC = {"valu_f64": 5.5, "mfma": 17.0, "valu_other": 5.1, "dpp_perm": 5.5, "lds":
 CLOCK_GHZ = 2.38            # sustained shader clock with 1024 such workgroups resident (probe_clock.hip)
 
 
+def device_source_hash():
+    """sha256 over the device sources a build of the library is made from (names and contents, sorted)."""
+    import hashlib
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))] +
+                   [os.path.join(CSRC, "models", f) for f in os.listdir(os.path.join(CSRC, "models")) if f.endswith(".h")] +
+                   [os.path.join(ROOT, "include", "ilqr_hip.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def assembly():
     out = "/tmp/ilqr_builtin_models.s"
     src = os.path.join(CSRC, "builtin_models.hip")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(CSRC, "models", f) for f in os.listdir(os.path.join(CSRC, "models"))]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                               "--cuda-device-only", "-DILQR_ISA_MARKERS", "-S", "-I", CSRC, src, "-o", out], stderr=subprocess.DEVNULL)
+                               "--cuda-device-only", "-S", "-I", CSRC, src, "-o", out], stderr=subprocess.DEVNULL)
     return open(out).read().splitlines()
 
 
@@ -181,7 +199,7 @@ def model_for(config, lines):
         "occupancy_clk_per_instruction": OCC, "clock_ghz": CLOCK_GHZ,
         "per_iteration_other_clk": {"acrobot": 13400.0, "car": 11000.0}.get(config, 14000.0),
         "note": "issue slots per timestep = (instructions + s_nop idle states of the loop holding the step marker, cold child loops "
-                "excluded) / step copies in that loop body (-DILQR_ISA_MARKERS analysis build of the same sources). *_occupancy_clk = "
+                "excluded) / step copies in that loop body (assembly kept by the library's own compilation). *_occupancy_clk = "
                 "the issue time of that instruction list at the single-wave rates of tools/probes/probe_issue.hip "
                 "(occupancy_clk_per_instruction; s_nop N = 5 + N). A lone wave issues one instruction per 5-6 clk whether or not it "
                 "depends on the previous one, so this IS the speed limit of the serial loops; what the measured time adds on top "
@@ -192,11 +210,18 @@ def model_for(config, lines):
 
 
 def main():
-    lines = assembly()
+    argv = sys.argv[1:]
+    opt = {}
+    while argv and argv[0] in ("--asm", "--out", "--flags"):
+        opt[argv[0][2:]] = argv[1]
+        argv = argv[2:]
+    lines = open(opt["asm"]).read().splitlines() if "asm" in opt else assembly()
     out = {}
-    for config in (sys.argv[1:] or ["acrobot", "car"]):
+    for config in (argv or ["acrobot", "car"]):
         m, table = model_for(config, lines)
         out[config] = m
+        if "asm" in opt:
+            continue
         print("== %s: serial loops of the solve kernel (per loop body)" % config)
         for t in table:
             print("  %-32s steps/body %d  total %4d  f64 %4d  mfma %3d  valu %3d  dpp/perm %3d  lds %3d  vmem %3d  salu %3d  wait %2d  nop-states %3d"
@@ -204,7 +229,9 @@ def main():
                      t["waitcnt"], t["nop_states"]))
         print("  -> wave 0 per timestep: rollout %.0f issue slots = %.0f clk of SIMD occupancy, Riccati matrix chain %.0f issue slots = %.0f clk"
               % (m["rollout_step_instr"], m["rollout_step_occupancy_clk"], m["riccati_step_instr"], m["riccati_step_occupancy_clk"]))
-    json.dump(out, open(os.path.join(ROOT, "profiles", "issue_model.json"), "w"), indent=1)
+    out["_build"] = {"source_hash": device_source_hash(), "flags": opt.get("flags", ""),
+                     "from": "assembly kept by the library's own compilation (-save-temps)" if "asm" in opt else "stand-alone compile of the same sources"}
+    json.dump(out, open(opt.get("out", os.path.join(ROOT, "profiles", "issue_model.json")), "w"), indent=1)
 
 
 if __name__ == "__main__":
