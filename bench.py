@@ -79,6 +79,8 @@ def parse_args(argv=None):
                     help="optional mode, NOT the reference's behaviour and not the headline: one Armijo step size per inner iteration "
                          "for the whole (multi-GPU) batch, decided on the summed merit — one all-reduce (RCCL over xGMI) of three "
                          "doubles per line-search trial, line search stepped from the host (Solver.solve_shared_step_)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the two short secondary passes (distinct shards per rank; two batches in flight) reported as extra keys")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -170,8 +172,10 @@ class _StubSolver:
 
 
 # ------------------------------------------------------------------------------------------------ one rank
-def worker(args):
-    stub = os.environ.get("ILQR_BENCH_STUB") == "1"
+def worker(args, solver_factory=None):
+    """One rank. solver_factory(rank, model, T, B, x1, ub) -> solver-like object replaces the GPU solver (tests only: the CPU
+    tests of the N > 1 path run this very function over gloo with a sleeping stub or with a CPU solve of the rank's shard)."""
+    stub = os.environ.get("ILQR_BENCH_STUB") == "1" or solver_factory is not None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -214,7 +218,7 @@ def worker(args):
     lo, _ = pkg.distributed.shard_range(rank, B)
     model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if args.distinct_shards else 0))
     if stub:
-        sols = [_StubSolver(rank, B)]
+        sols = [solver_factory(rank, model, T, B, x1, ub) if solver_factory is not None else _StubSolver(rank, B)]
         d_x1 = d_u = None
     else:
         d_x1 = torch.from_numpy(x1).to(dev)
@@ -269,6 +273,66 @@ def worker(args):
     kernel_ms, launches = sol.timing()
     st = sol.stats()
     it_sum, it_max = float(st["iterations"].sum()), float(st["iterations"].max())
+
+    # ---- secondary figures of the same run (extra keys of the JSON line, never `value`): rank r on ITS OWN shard
+    # [rB, (r+1)B) of one big synthetic batch (BASELINE config 4's situation: the step then lasts as long as the unluckiest
+    # shard's slowest instance), and two batches in flight per GPU (the next batch fills SIMDs freed by early finishers)
+    secondary = {}
+    if not args.shared_step and not args.no_secondary and solver_factory is None:
+        k2 = max(1, min(3, args.steps))
+
+        def timed(step_fn, handles):
+            for s_ in handles:
+                s_.synchronize()
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(k2):
+                step_fn()
+            for s_ in handles:
+                s_.synchronize()
+            if not stub:
+                torch.cuda.synchronize()
+            mine = time.perf_counter() - t_
+            barrier()
+            return pkg.distributed.max_over_ranks(mine, dist, cdev)
+
+        if not args.distinct_shards:
+            m2, T2, x1b, ubb = pkg.workloads.make_inputs(args.config, B, offset=lo)
+            if stub:
+                d2 = (None, None)
+            else:
+                d2 = (torch.from_numpy(x1b).to(dev), torch.from_numpy(ubb).to(dev))
+
+            def step_distinct():
+                sol.reset_()
+                sol.initialize_rollout_device_(d2[0].data_ptr() if d2[0] is not None else 0, d2[1].data_ptr() if d2[1] is not None else 0)
+                sol.solve_(sync=False)
+            el = timed(step_distinct, [sol])
+            itmax = pkg.distributed.gather_over_ranks([float(sol.stats()["iterations"].max())], dist, cdev)
+            secondary["distinct_shards"] = {"value": world * B * k2 / el, "unit": "trajectories/s", "ms_per_step": 1e3 * el / k2, "steps": k2,
+                                            "iterations_max_per_rank": [r[0] for r in itmax],
+                                            "note": "rank r solves instances [r*B, (r+1)*B): the data-dependent iteration counts of the shards enter the figure"}
+        if len(sols) == 1 and not stub:
+            extra = pkg.Solver(model=model, horizon=T, batch=B, device=gpu,
+                               options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
+            pair = [sol, extra]
+            for s_ in pair:
+                s_.set_kernel_variant_(os.environ.get("ILQR_INFLIGHT_VARIANT", "throughput") if args.variant == "auto" and sol.nx <= 4 and sol.nu <= 4 else args.variant)
+            cnt2 = [0]
+
+            def step_pair():
+                s_ = pair[cnt2[0] % 2]
+                cnt2[0] += 1
+                s_.reset_()
+                s_.initialize_rollout_device_(d_x1.data_ptr(), d_u.data_ptr())
+                s_.solve_(sync=False)
+            for _ in range(2):
+                step_pair()
+            el = timed(lambda: (step_pair(), step_pair()), pair)
+            secondary["inflight_2"] = {"value": world * B * 2 * k2 / el, "unit": "trajectories/s", "ms_per_batch": 1e3 * el / (2 * k2),
+                                       "note": "two solver handles per GPU on separate streams, alternating batches"}
+            extra.close()
+            sol.set_kernel_variant_(args.variant)
     per_rank = pkg.distributed.gather_over_ranks([1e3 * my_elapsed / args.steps, kernel_ms, it_sum, it_max], dist, cdev)
     if rank != 0:
         for s_ in sols:
@@ -306,6 +370,8 @@ def worker(args):
                         "converged_frac": float((st["max_violation"] <= 5e-3).mean()),
                         "trajectory_iterations_per_s": float(sum(r[2] for r in per_rank) * args.steps / elapsed)},
     }
+    if secondary:
+        out["secondary"] = secondary
     if not stub:
         n_, m_ = sol.nx, sol.nu
         io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))
