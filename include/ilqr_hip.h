@@ -191,7 +191,7 @@ int ilqr_enable_action_value_buffers(ilqr_handle* h);
  * "iterations","gradient_norm","outer_iterations","potrf_info","rollouts","done" (host-stepped AL loop: instance met
  * the constraint tolerance), "delta_grad_product" (∇Lᵀ·Δz of the last forward_pass!, src/forward_pass.jl:20),
  * "trace_len" (rows the last solve wrote to the trace), "count" (length of "_scalars"); shared-step mode: "obj_prev",
- * "inner_done", "j_prev", "inner_it". -1 if unknown. */
+ * "inner_done", "j_prev", "inner_it"; "resume" (hand-over bookkeeping, 0 after a solve). -1 if unknown. */
 int ilqr_scalar_slot(const char* name);
 
 /* Kernel variant of ilqr_solve (small models, nx, nu <= 4; large models have one kernel family): 0 = auto — the latency kernel
@@ -201,6 +201,15 @@ int ilqr_scalar_slot(const char* name);
  * instances per wave on the four blocks of v_mfma_f64_4x4x4, workspace streamed from HBM / L2 through a 13 KB LDS chunk buffer
  * per wave, no horizon limit. All run the same arithmetic up to the association of a few sums. */
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);
+/* Straggler hand-over of the packed kernel (no counterpart in the reference, which is one trajectory per Solver): a batched
+ * launch lasts as long as its slowest instance, and in the packed kernel a straggler keeps a whole wave at ~120 us per
+ * iteration. An instance that is still unconverged when it ENTERS outer iteration `outer` of constrained_ilqr_solve!
+ * (src/solve.jl:105) leaves the packed kernel at that boundary — duals, penalties and nominal trajectory are complete in its
+ * workspace block — and a second launch on the same stream finishes exactly those instances with the latency kernel (two
+ * waves per instance, state in LDS: ~65 us per iteration). The rule looks at the instance alone: results never depend on the
+ * other instances of the batch; a handed-over instance follows the latency kernel's arithmetic from that boundary on (the two
+ * kernels agree to rounding, both parity-tested). outer = -1: auto = max_dual_updates / 2 + 1 (default); 0: off; >= 2: as given. */
+int ilqr_set_handover(ilqr_handle* h, int32_t outer);
 
 /* Per-iteration record of what the reference prints when `verbose` (src/solve.jl:40-45): for every
  * instance up to `capacity` rows of 8 doubles {outer, inner, objective, gradient_norm, max_violation,

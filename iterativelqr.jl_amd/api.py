@@ -280,6 +280,10 @@ class Solver:
         v = {"auto": 0, "latency": 1, "throughput": 2, "packed": 3}.get(variant, variant)
         _ffi.check(_ffi.lib().ilqr_set_kernel_variant(self._h, int(v)))
 
+    def set_handover_(self, outer):
+        """Straggler hand-over of the packed kernel (see ilqr_set_handover): -1 auto, 0 off, k >= 2 = instances entering outer iteration k."""
+        _ffi.check(_ffi.lib().ilqr_set_handover(self._h, int(outer)))
+
     def enable_trace_(self, capacity):
         """Record per-iteration rows (what `verbose` prints in the reference) during solve_."""
         self._trace_cap = int(capacity)

@@ -81,6 +81,7 @@ struct ilqr_handle {
     double* d_u;   // staging for host-pointer initialize_rollout
     double* trace;
     int trace_cap;
+    int handover;         // straggler hand-over of the packed kernel: -1 auto, 0 off, k > 1 = instances entering outer iteration k
     int variant;          // 0 auto, 1 latency kernel (all-LDS, 2 waves per instance), 2 throughput kernel (slim), 3 packed kernel (4 instances per wave, no LDS)
     bool lds_fits;        // the LDS-resident kernels can hold this horizon (otherwise only the packed kernel runs it)
     int num_simds;
@@ -107,6 +108,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.trace = h->trace; a.trace_cap = h->trace_cap;
     a.qv = h->qv; a.QL = h->QL;
     a.stage_param = 0.0; a.stage_flag = 0;
+    a.handover_outer = 0; a.resume = 0;
     return a;
 }
 
@@ -388,7 +390,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu, vt->hess_nnz) * 8
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
-    h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024;
+    h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024; h->handover = -1;
     h->qv = nullptr; h->QL = ilqr::make_qlayout(vt->nx, vt->nu, d->horizon); h->full_stale = false; h->P_dirty = false;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
@@ -585,10 +587,22 @@ int ilqr_solve(ilqr_handle* h) {
                       (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
     if (!packed && !h->lds_fits) return drop(fail(ILQR_ERR_LDS, "this horizon only runs on the packed kernel"));
     if (packed) {
+        // straggler hand-over: instances still unconverged when they enter outer iteration k leave the packed kernel at that
+        // boundary and are finished by the latency kernel (two waves per instance, LDS-resident state: about half the time per
+        // iteration when few instances are left). The rule looks at the instance alone, so a result never depends on which
+        // other instances share the batch. auto: k = max_dual_updates / 2 + 1 (6 with the reference's default of 10).
+        int ho = h->handover < 0 ? h->opt.max_dual_updates / 2 + 1 : h->handover;
+        if (!h->constrained || !h->lds_fits || ho < 2 || ho > h->opt.max_dual_updates) ho = 0;
+        a.handover_outer = ho;
 #ifdef ILQR_PK_DEBUG_HOOK      // phase-timing hook of tools/packed_phases.py (see ilqr_device_packed.hpp); never compiled into the product library
         if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);
 #endif
         if (h->vt->launch_solve_packed(&a, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (packed variant) launch failed"));
+        if (ho > 0) {
+            ilqr::KArgs r = a;
+            r.resume = 1; r.stage = 0;
+            if (h->vt->launch_solve(&r, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (hand-over resume) launch failed"));
+        }
     } else if (slim) {
         if (h->vt->launch_solve_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
             return drop(fail(ILQR_ERR_HIP, "solve (throughput variant) launch failed"));
@@ -696,6 +710,7 @@ int ilqr_scalar_slot(const char* name) {
         {"states_eq_nominal", ilqr::S_STATES_EQ_NOMINAL}, {"profile", ilqr::S_PROF}, {"done", ilqr::S_DONE},
         {"delta_grad_product", ilqr::S_DELTA}, {"trace_len", ilqr::S_TRACE_LEN}, {"count", ilqr::S_COUNT},
         {"obj_prev", ilqr::S_OBJ_PREV}, {"inner_done", ilqr::S_INNER_DONE}, {"j_prev", ilqr::S_J_PREV}, {"inner_it", ilqr::S_INNER_IT},
+        {"resume", ilqr::S_RESUME},
     };
     if (!name) return -1;
     for (auto& s_ : slots)
@@ -747,6 +762,13 @@ int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
     if (variant == 2 && h->vt->launch_solve_slim == nullptr)
         return fail(ILQR_ERR_INVALID, "the throughput variant exists for small models (nx, nu <= 4) only");
     h->variant = variant;
+    return ILQR_OK;
+}
+
+int ilqr_set_handover(ilqr_handle* h, int32_t outer) {
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_handover(s, outer); });
+    if (!h || outer < -1 || outer == 1) return fail(ILQR_ERR_INVALID, "hand-over: -1 (auto), 0 (off) or the outer iteration (>= 2) from which stragglers leave the packed kernel");
+    h->handover = outer;
     return ILQR_OK;
 }
 

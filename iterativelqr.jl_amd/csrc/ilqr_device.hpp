@@ -50,6 +50,11 @@ struct KArgs {
     QLayout QL;
     double stage_param;  // stage kernel only: step size of ILQR_STAGE_SS_TRIAL / SS_FINISH
     int stage_flag;      //                    first trial / accepted
+    // Straggler hand-over (small models, batches on the packed kernel): an instance that enters outer iteration
+    // handover_outer (> 1; 0 = never) leaves the packed kernel at that boundary; a second launch of the latency kernel with
+    // resume = 1 picks up exactly the instances so marked (S_RESUME) and finishes them with two waves and LDS-resident state each.
+    int handover_outer;
+    int resume;
 };
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
@@ -1426,8 +1431,8 @@ __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
 //   al_outer = true : AL outer loop (Solver with constraints)
 //   al_outer = false: a single ilqr_solve! (plain Objective, or the stage test)
 template <class M, bool STORE_VALUE>
-__device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constrained, bool al_outer) {
-    if (al_outer) {
+__device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constrained, bool al_outer, int o_start = 1) {
+    if (al_outer && o_start == 1) {
         // reset!(solver.data) (:93, src/data/solver.jl:49-59); λ ← 0, ρ ← ρ0 (:96-103)
         I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
         for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
@@ -1440,7 +1445,7 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
         I.outer_iterations = 0;
     }
     const int outer_max = al_outer ? opt.max_dual_updates : 1;
-    for (int o = 1; o <= outer_max; ++o) {                            // src/solve.jl:105
+    for (int o = o_start; o <= outer_max; ++o) {                      // src/solve.jl:105 (o_start > 1: resumed after a hand-over)
         if (al_outer) I.outer_iterations = o;
         // ---------------- ilqr_solve! (src/solve.jl:1-54)
         reset_model_objective<M>(I, false);                           // (:9-10)
@@ -1552,15 +1557,24 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
+    int o_start = 1;
+    if (a.resume) {                       // second launch after the packed kernel: only the instances it handed over
+        o_start = (int)(a.ws + (size_t)b * (size_t)a.L.stride)[a.L.scal + S_RESUME];
+        if (o_start < 2) return;
+    }
     Inst<M> I;
     inst_setup<M>(I, a, smem, b);
-    I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0;
+    if (o_start == 1) { I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0; }
+    else I.trace_len = (int)I.scal[S_TRACE_LEN];
     {
         ILQR_PROF_BEGIN();
-        solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0);
+        solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0, o_start);
         ILQR_PROF_END(I, PROF_OTHER);   // total; phases are subtracted on the host
     }
-    if (I.lane == 0 && I.wave == 0) I.scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
+    if (I.lane == 0 && I.wave == 0) {
+        I.scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
+        I.scal[S_RESUME] = 0.0;
+    }
     inst_writeback<M>(I, a, smem, b);
 }
 
@@ -1757,7 +1771,7 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 5   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+#define ILQR_MODEL_ABI_VERSION 6   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against

@@ -682,6 +682,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
         I.outer = 1;
     }
     I.state = live ? ST_INIT : ST_DONE;
+    int resume = 0;
     __syncthreads();
     const int outer_max = al_outer ? opt.max_dual_updates : 1;
     if (outer_max < 1) I.state = ST_DONE;
@@ -718,7 +719,13 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                     }
                 }
                 if (conv || (upd && I.outer >= outer_max)) I.state = ST_DONE;
-                else if (upd) { I.outer += 1; I.state = ST_INIT; }
+                else if (upd) {
+                    I.outer += 1;
+                    // straggler hand-over: this instance's workspace block is complete at the boundary (duals and penalties
+                    // updated, nominal trajectory in place); it leaves for the latency kernel's resume launch
+                    if (a.handover_outer > 1 && I.outer >= a.handover_outer) { I.state = ST_DONE; resume = I.outer; }
+                    else I.state = ST_INIT;
+                }
                 __syncthreads();
             }
             const bool at_init = I.state == ST_INIT;
@@ -828,6 +835,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
         scal[S_ROLLOUTS] = (double)I.rollouts; scal[S_STATES_EQ_NOMINAL] = (double)I.states_eq_nominal;
         scal[S_DELTA] = I.delta;
         scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
+        scal[S_RESUME] = (double)resume;
     }
 }
 

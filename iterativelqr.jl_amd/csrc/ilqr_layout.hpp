@@ -21,7 +21,10 @@ enum {
     S_TRACE_LEN = 19,   // rows of the per-iteration trace written by the last solve
     // host-stepped shared-step mode only (ILQR_STAGE_SS_*): loop state of ilqr_solve! that otherwise lives in registers
     S_OBJ_PREV = 20, S_INNER_DONE = 21, S_J_PREV = 22, S_INNER_IT = 23,
-    S_COUNT = 24
+    // straggler hand-over: the packed kernel left this instance at the START of outer iteration S_RESUME (>= 2) for the latency
+    // kernel to finish (0 = nothing to resume)
+    S_RESUME = 24,
+    S_COUNT = 26
 };
 
 // Riccati hand-over between the two waves of a small-model instance: chunks of RING_STEPS timesteps, double-buffered

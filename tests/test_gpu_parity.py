@@ -1138,3 +1138,41 @@ def test_sharded_handle_equals_single_handle(pkg, config, B, devices):
     assert np.array_equal(one.buffer("P"), many.buffer("P"), equal_nan=True)
     assert many.timing()[1] >= 1 and many.timing()[0] > 0.0
     one.close(); many.close()
+
+
+@pytest.mark.parametrize("config,B,outer", [("acrobot51", 45, 2), ("acrobot51", 45, 4), ("car", 37, 2), ("particle", 9, 2)])
+def test_straggler_handover_from_the_packed_to_the_latency_kernel(pkg, oracle, config, B, outer):
+    """ilqr_set_handover: instances that enter outer iteration `outer` leave the packed kernel at that boundary and are finished
+    by the latency kernel (here forced early, so that most instances change kernels mid-solve). The outcome must be the one of
+    the packed kernel alone — same control flow, trace rows and results (the two kernels run the same arithmetic) — and it must
+    not depend on which other instances share the batch."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+
+    def run(handover, sel=slice(None), variant="packed"):
+        nb = len(range(*sel.indices(B)))
+        s = pkg.Solver(model=model, horizon=T, batch=nb, options=pkg.Options(verbose=0))
+        s.set_kernel_variant_(variant); s.set_handover_(handover); s.enable_trace_(600)
+        s.initialize_rollout_(x1[sel], ub[sel]); s.solve_()
+        out = dict(x=s.get_trajectory()[0], u=s.get_trajectory()[1], K=s.get_policy()[0], st=s.stats(), tl=s.scalar("trace_len"),
+                   tr=s.trace(), resume=s.scalar("resume"), lam=s.buffer("constraint_dual"))
+        s.close()
+        return out
+    off, on = run(0), run(outer)
+    moved = off["st"]["outer_iterations"] >= outer
+    assert moved.any() and (on["resume"] == 0).all()
+    for k in ("iterations", "outer_iterations", "rollouts", "status", "potrf_info"):
+        assert np.array_equal(off["st"][k], on["st"][k]), k
+    assert np.array_equal(off["tl"], on["tl"]) and (on["tl"] == on["st"]["iterations"]).all()       # one trace across both launches
+    assert np.array_equal(off["tr"][:, :, [0, 1, 5, 6, 7]], on["tr"][:, :, [0, 1, 5, 6, 7]])
+    for k in ("x", "u", "K", "lam"):
+        assert np.abs(off[k] - on[k]).max() <= 1e-9 * max(1.0, np.abs(off[k]).max()), k
+    assert np.array_equal(off["x"][~moved], on["x"][~moved])                                          # instances that never left: bitwise
+    # batch independence: a sub-batch with the hand-over on gives bitwise what the instances got inside the larger batch
+    sub = slice(3, 3 + min(B - 3, 7))
+    part = run(outer, sub)
+    assert np.array_equal(part["x"], on["x"][sub]) and np.array_equal(part["K"], on["K"][sub])
+    # and the oracle agrees as with every other kernel
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=8)
+    same = (on["st"]["iterations"] == ref["stats"]["iterations"]) & (on["st"]["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.95
+    assert np.abs(on["x"] - ref["x"])[same].max() < 1e-7
