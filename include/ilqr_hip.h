@@ -240,7 +240,8 @@ int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launch
  * The library wraps the source (csrc/ilqr_model_adapter.hpp), compiles it for gfx950 with hipcc as a child process (cached
  * by a hash of the source; ILQR_HIPCC / ILQR_CSRC_DIR override the tool and the kernel headers), loads the module and
  * returns the name to put into ilqr_problem_desc.model and the module path for ilqr_problem_desc.model_library.
- * Small models only (nx, nu <= 4); larger ones go through the symbolic generator. */
+ * nx <= 64, nu <= 16. Models with nx > 4 or nu > 4 run on the large path with every Jacobian / Hessian entry treated as
+ * state-dependent / non-zero (callables carry no structure; the symbolic generator is the way to constant and sparse tables). */
 typedef struct {
     const char* name;        /* C identifier */
     int32_t nx, nu, nw;      /* num_state, num_action, num_parameter */

@@ -265,10 +265,9 @@ int ilqr_model_count(void) { return (int)registry().size(); }
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len) {
     if (!src || !src->name || !src->source || !registered_name || !library_path)
         return fail(ILQR_ERR_INVALID, "null argument");
-    if (src->nx < 1 || src->nx > 4 || src->nu < 1 || src->nu > 4 || src->nw < 0 || src->nc_stage < 0 || src->nc_stage > 64 ||
+    if (src->nx < 1 || src->nx > 64 || src->nu < 1 || src->nu > 16 || src->nw < 0 || src->nc_stage < 0 || src->nc_stage > 64 ||
         src->nc_term < 0 || src->nc_term > 64)
-        return fail(ILQR_ERR_INVALID, "ilqr_compile_model: 1 <= nx, nu <= 4, at most 64 constraint rows per stage (larger models go "
-                                      "through the symbolic generator, iterativelqr.jl_amd/codegen.py)");
+        return fail(ILQR_ERR_INVALID, "ilqr_compile_model: 1 <= nx <= 64, 1 <= nu <= 16, at most 64 constraint rows per stage");
     for (const char* c = src->name; *c; ++c)
         if (!((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_'))
             return fail(ILQR_ERR_INVALID, "model name must be a C identifier");
@@ -325,9 +324,10 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
             if (have) std::fprintf(f, "    ILQR_MODEL_FN void %s(double* o, const double* x, const double* u, const double* w) { user_%s::%s(o, x, u, w); }\n", cnames[i], tag, cnames[i]);
             else std::fprintf(f, "    ILQR_MODEL_FN void %s(double*, const double*, const double*, const double*) {}\n", cnames[i]);
         }
-        std::fprintf(f, "};\nstruct Model_%s : ilqr::AdaptedModel<Fns_%s, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull> {\n"
+        // nx > 4 or nu > 4: the compact forms of the large path, dense (black-box callables carry no structure)
+        std::fprintf(f, "};\nstruct Model_%s : ilqr::%s<Fns_%s, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull> {\n"
                         "    static constexpr const char* NAME = \"%s\";\n};\nILQR_DEFINE_MODEL(Model_%s)\n",
-                     uname.c_str(), tag, src->nx, src->nu, src->nw, src->nc_stage, src->nc_term,
+                     uname.c_str(), (src->nx > 4 || src->nu > 4) ? "AdaptedLargeModel" : "AdaptedModel", tag, src->nx, src->nu, src->nw, src->nc_stage, src->nc_term,
                      (unsigned long long)src->ineq_stage, (unsigned long long)src->ineq_term, uname.c_str(), uname.c_str());
         std::fclose(f);
         // hipcc as a child process (no shell): same flags as the built-in models

@@ -12,7 +12,10 @@
 // — each `ILQR_MODEL_FN void name(double* out, const double* x, const double* u, const double* w)` — into a struct F of
 // static forwarders and instantiates AdaptedModel<F, ...>, which the solve / stage / packed kernels take like a generated
 // model. No wave-cooperative rollout form exists for such code: every lane evaluates the dynamics (correct, not the fastest),
-// the Gauss-Newton AL terms are the dense products of src/gradients.jl:54-80. Small models only (nx, nu <= 4).
+// the Gauss-Newton AL terms are the dense products of src/gradients.jl:54-80.
+// Models with nx > 4 or nu > 4 (up to nx = 64, nu = 16) get AdaptedLargeModel: the compact forms the large path streams
+// (ilqr_device_large.hpp), with every Jacobian entry treated as state-dependent and every Hessian entry as structurally
+// non-zero — black-box callables carry no structure; the symbolic generator (codegen.py) is the way to constant / sparse tables.
 #pragma once
 
 #include "ilqr_device.hpp"
@@ -25,7 +28,7 @@ template <class F, int NX_, int NU_, int NW_, int NCS_, int NCT_, unsigned long 
 struct AdaptedModel {
     static constexpr int NX = NX_, NU = NU_, NW = NW_, NCS = NCS_, NCT = NCT_;
     static constexpr unsigned long long INEQ_S = INEQ_S_, INEQ_T = INEQ_T_;
-    static_assert(NX >= 1 && NX <= 4 && NU >= 1 && NU <= 4, "ilqr_compile_model: small models only (nx, nu <= 4)");
+    static_assert(NX >= 1 && NX <= 64 && NU >= 1 && NU <= 16, "ilqr_compile_model: nx <= 64, nu <= 16");
     static_assert(NCS <= 64 && NCT <= 64, "at most 64 constraint rows per stage");
     static constexpr int W = cdim<NW>::v, CS = cdim<NCS>::v, CT = cdim<NCT>::v;
 
@@ -206,6 +209,129 @@ struct AdaptedModel {
                     for (int i = 0; i < NCT; ++i) acc += cx[i2 * NCT + i] * (ir[i] * cx[j * NCT + i]);
                     gxx[j * NX + i2] += acc;
                 }
+        }
+    }
+};
+
+// Index tables of the dense compact forms: Jacobian entry q is entry q of [fx | fu]; the Hessian row is [gxx sorted by the
+// 16x16 tile an entry falls in | guu | gux], each in column-major order inside its matrix.
+template <int NX, int NU>
+struct DenseTables {
+    static constexpr int TN = (NX + 15) / 16, NXX = NX * NX, NUU = NU * NU, NUX = NU * NX, HS = NXX + NUU + NUX, JV = NX * NX + NX * NU;
+    struct Tab { int hess_idx[HS]; int tile_start[TN * TN + 1]; int jac_idx[JV]; };
+    static constexpr Tab make() {
+        Tab t{};
+        int q = 0;
+        for (int tile = 0; tile < TN * TN; ++tile) {
+            t.tile_start[tile] = q;
+            for (int idx = 0; idx < NXX; ++idx) {
+                const int col = idx / NX, row = idx % NX;
+                if ((row / 16) * TN + col / 16 == tile) t.hess_idx[q++] = idx;
+            }
+        }
+        t.tile_start[TN * TN] = q;
+        for (int i = 0; i < NUU; ++i) t.hess_idx[q++] = i;
+        for (int i = 0; i < NUX; ++i) t.hess_idx[q++] = i;
+        for (int i = 0; i < JV; ++i) t.jac_idx[i] = i;
+        return t;
+    }
+    static constexpr Tab tab = make();
+};
+
+template <class F, int NX_, int NU_, int NW_, int NCS_, int NCT_, unsigned long long INEQ_S_, unsigned long long INEQ_T_>
+struct AdaptedLargeModel : AdaptedModel<F, NX_, NU_, NW_, NCS_, NCT_, INEQ_S_, INEQ_T_> {
+    typedef AdaptedModel<F, NX_, NU_, NW_, NCS_, NCT_, INEQ_S_, INEQ_T_> Base;
+    typedef DenseTables<NX_, NU_> DT;
+    static constexpr int NX = NX_, NU = NU_, NW = NW_, NCS = NCS_, NCT = NCT_;
+    static constexpr int W = cdim<NW>::v, CS = cdim<NCS>::v, CT = cdim<NCT>::v;
+    static_assert(NX > 4 || NU > 4, "the compact forms are the large path's");
+    // ---- Jacobians: all entries state-dependent, no constant part
+    static constexpr int JAC_NVAR = DT::JV;
+    static constexpr double JAC_CONST_FX[1][NX * NX] = {};
+    static constexpr double JAC_CONST_FU[1][NX * NU] = {};
+    static constexpr const int (&JAC_VAR_IDX)[DT::JV] = DT::tab.jac_idx;
+    __device__ __forceinline__ static void dyn_jac_var(const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&v)[DT::JV]) {
+#pragma unroll
+        for (int i = 0; i < DT::JV; ++i) v[i] = 0.0;
+        F::dynamics_jacobian_state(v, x, u, w);
+        F::dynamics_jacobian_action(v + NX * NX, x, u, w);
+    }
+    // ---- dynamics row form: no affine part known, the whole f is the "remainder", evaluated by every lane
+    static constexpr double DYN_AFF[NX][NX + NU + 1] = {};
+    static constexpr bool DYN_HAS_REM = true, DYN_REM_ELEMENTWISE = false;
+    template <class BC = WaveBC>
+    __device__ __forceinline__ static void dyn_rem_wave(const int, const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&r)[NX]) {
+        Base::dyn(x, u, w, r);
+    }
+    __device__ __forceinline__ static double dyn_rem_own(const double, const double (&)[NU], const double (&)[W]) { return 0.0; }
+    // ---- Hessians: dense compact row
+    static constexpr int HESS_NXX = DT::NXX, HESS_NUU = DT::NUU, HESS_NUX = DT::NUX;
+    static constexpr const int (&HESS_IDX)[DT::HS] = DT::tab.hess_idx;
+    static constexpr const int (&HESS_XX_TILE_START)[DT::TN * DT::TN + 1] = DT::tab.tile_start;
+    __device__ __forceinline__ static void cost_s_hess_c(const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double* __restrict__ hs) {
+        double hxx[NX * NX], huu[NU * NU], hux[NU * NX];
+        Base::cost_s_hess(x, u, w, hxx, huu, hux);
+        for (int q = 0; q < DT::NXX; ++q) hs[q] += hxx[DT::tab.hess_idx[q]];
+        for (int q = 0; q < DT::NUU; ++q) hs[DT::NXX + q] += huu[q];
+        for (int q = 0; q < DT::NUX; ++q) hs[DT::NXX + DT::NUU + q] += hux[q];
+    }
+    __device__ __forceinline__ static void cost_t_hess_c(const double (&x)[NX], const double (&w)[W], double* __restrict__ hs) {
+        double hxx[NX * NX];
+        Base::cost_t_hess(x, w, hxx);
+        for (int q = 0; q < DT::NXX; ++q) hs[q] += hxx[DT::tab.hess_idx[q]];
+    }
+    // Gauss-Newton AL terms (src/gradients.jl:54-80) on the compact row
+    __device__ __forceinline__ static void al_s_c(const double (&x)[NX], const double (&u)[NU], const double (&w)[W], const double (&ct)[CS],
+                                                  const double (&ir)[CS], double (&gx)[NX], double (&gu)[NU], double* __restrict__ hs) {
+        if constexpr (NCS > 0) {
+            double cx[NCS * NX], cu[NCS * NU];
+            Base::con_s_jac(x, u, w, cx, cu);
+            for (int j = 0; j < NX; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < NCS; ++i) acc += cx[j * NCS + i] * ct[i];
+                gx[j] += acc;
+            }
+            for (int j = 0; j < NU; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < NCS; ++i) acc += cu[j * NCS + i] * ct[i];
+                gu[j] += acc;
+            }
+            for (int q = 0; q < DT::NXX; ++q) {
+                const int idx = DT::tab.hess_idx[q], j = idx / NX, i2 = idx % NX;
+                double acc = 0.0;
+                for (int i = 0; i < NCS; ++i) acc += cx[i2 * NCS + i] * (ir[i] * cx[j * NCS + i]);
+                hs[q] += acc;
+            }
+            for (int idx = 0; idx < DT::NUU; ++idx) {
+                const int j = idx / NU, i2 = idx % NU;
+                double acc = 0.0;
+                for (int i = 0; i < NCS; ++i) acc += cu[i2 * NCS + i] * (ir[i] * cu[j * NCS + i]);
+                hs[DT::NXX + idx] += acc;
+            }
+            for (int idx = 0; idx < DT::NUX; ++idx) {
+                const int j = idx / NU, i2 = idx % NU;
+                double acc = 0.0;
+                for (int i = 0; i < NCS; ++i) acc += cu[i2 * NCS + i] * (ir[i] * cx[j * NCS + i]);
+                hs[DT::NXX + DT::NUU + idx] += acc;
+            }
+        }
+    }
+    __device__ __forceinline__ static void al_t_c(const double (&x)[NX], const double (&w)[W], const double (&ct)[CT], const double (&ir)[CT],
+                                                  double (&gx)[NX], double* __restrict__ hs) {
+        if constexpr (NCT > 0) {
+            double cx[NCT * NX];
+            Base::con_t_jac(x, w, cx);
+            for (int j = 0; j < NX; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < NCT; ++i) acc += cx[j * NCT + i] * ct[i];
+                gx[j] += acc;
+            }
+            for (int q = 0; q < DT::NXX; ++q) {
+                const int idx = DT::tab.hess_idx[q], j = idx / NX, i2 = idx % NX;
+                double acc = 0.0;
+                for (int i = 0; i < NCT; ++i) acc += cx[i2 * NCT + i] * (ir[i] * cx[j * NCT + i]);
+                hs[q] += acc;
+            }
         }
     }
 };

@@ -1176,3 +1176,48 @@ def test_straggler_handover_from_the_packed_to_the_latency_kernel(pkg, oracle, c
     same = (on["st"]["iterations"] == ref["stats"]["iterations"]) & (on["st"]["rollouts"] == ref["stats"]["rollouts"])
     assert same.mean() >= 0.95
     assert np.abs(on["x"] - ref["x"])[same].max() < 1e-7
+
+
+def test_c_callables_define_a_large_path_model(pkg, oracle, tmp_path):
+    """ilqr_compile_model beyond nx, nu <= 4 (src/dynamics.jl:55-60, src/costs.jl:1-15, src/constraints.jl:54-64 accept any
+    size): the synth12 callables of examples/synth12_model.c as C source -> AdaptedLargeModel (compact forms, every entry
+    treated as state-dependent / non-zero) -> the four-wave large kernels; against the oracle's own synth12 and against the
+    model the symbolic generator makes from the same functions. Then the plain-C host of examples/synth12_compile.c."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "examples", "synth12_model.c"), "rb").read()
+
+    class Src(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+    L = pkg._ffi.lib()
+    ms = Src(b"synth12_t", 12, 5, 0, 10, 3, (1 << 10) - 1, 0, text)
+    name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
+    assert L.ilqr_compile_model(C.byref(ms), name, 128, path, 1024) == 0, L.ilqr_last_error().decode()
+    T, B = 41, 24
+    rng = np.random.default_rng(12)
+    x1 = 0.5 * rng.standard_normal((B, 12)); ub = 0.1 * rng.standard_normal((B, T - 1, 5))
+    kw = dict(max_iterations=15, max_dual_updates=3)
+    sol = pkg.Solver(model=name.value.decode(), horizon=T, batch=B, options=pkg.Options(verbose=0, **kw))
+    assert (sol.nx, sol.nu, sol.nc_stage, sol.nc_term) == (12, 5, 10, 3)
+    sol.initialize_rollout_(x1, ub)
+    assert np.abs(sol.buffer("nominal_states").reshape(B, T, 12)[0] - oracle.Problem("synth12", T).rollout(x1[0], ub[0])).max() < 1e-12
+    sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    ref = oracle.solve_batch("synth12", T, x1, ub, options=oracle.default_options(**kw), nthreads=4)
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.95, same.mean()
+    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
+    assert np.abs(K - ref["K"])[same].max() <= 5e-7 * np.abs(ref["K"]).max()
+    # the mirror of the compact rows: full Jacobians / Hessians read back like the reference's buffers
+    fx = sol.buffer("jacobian_state").reshape(B, T - 1, 12, 12)
+    assert np.abs(fx).max() > 0 and np.isfinite(sol.buffer("hessian_state_state")).all()
+    sol.close()
+    exe = str(tmp_path / "synth12_compile")
+    lib = os.path.join(root, "iterativelqr.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "synth12_compile.c"),
+                           "-o", exe, "-L" + lib, "-lilqr_hip", "-Wl,-rpath," + lib, "-lm"])
+    out = subprocess.run([exe, os.path.join(root, "examples", "synth12_model.c")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0, out.stdout.decode()[-2000:]
+    assert b"max |dx| = 0.000e+00" in out.stdout
