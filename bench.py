@@ -415,6 +415,22 @@ def worker(args, solver_factory=None):
                 roof["traffic_over_algorithmic"] = tr["traffic_bytes_per_launch"] / abytes
             else:
                 roof["traffic_unmeasured_reason"] = why
+        if sol.nx > 4 or sol.nu > 4:
+            # large path: the Riccati step's tile products on v_mfma_f64_16x16x4_f64 (zero-padded 16x16 tiles), one backward pass per
+            # inner iteration plus one per ilqr_solve! call; peak = MI355X fp64 matrix rate (78.6 TFLOP/s spec; the instruction issues
+            # once per 71.5 clk per SIMD, tools/probes/probe_mfma16.hip: 70 TFLOP/s at 2.4 GHz)
+            NPt, m4 = (sol.nx + 15) // 16, (sol.nu + 3) // 4
+            n4 = (sol.nx + 3) // 4
+            mfma_per_step = NPt * n4 + NPt * NPt * n4 + NPt * n4 + n4 + NPt * NPt * n4 + NPt * NPt * 4 * m4
+            passes = float((st["iterations"] + st["outer_iterations"]).sum())
+            flops = passes * (T - 1) * mfma_per_step * 2048.0
+            roof["mfma"] = {"achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": 78.6, "unit": "TFLOP/s",
+                            "frac": flops / (kernel_ms * 1e-3) / 1e12 / 78.6 if kernel_ms > 0 else 0.0,
+                            "mfma_per_riccati_step": mfma_per_step, "backward_passes": passes,
+                            "note": "v_mfma_f64_16x16x4_f64 flops incl. tile padding / kernel time; the matrix pipe is shared by the two instances of a CU"}
+            roof["actual_bound"] = ("per-timestep latency of the Riccati step: four MFMA-tile windows around the serial potrf / potrs chain "
+                                    "(about 8 k clk per timestep for one instance alone, of which 2.2 k are MFMA pipe time per SIMD); "
+                                    "the launch lasts as long as its slowest instance")
         # instruction-issue model of the critical path: the per-step instruction lists of the serial loops, read off the assembly
         # the library's own compilation kept (csrc/Makefile -> lib/issue_model.json, stamped with the device-source hash)
         im, why_not = pkg._ffi.issue_model(model)

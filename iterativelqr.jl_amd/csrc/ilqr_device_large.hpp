@@ -427,6 +427,9 @@ __device__ __forceinline__ void potrs_U_lds(const double* U, const double (&R)[m
 // TN = 2 (17 <= nx <= 32, e.g. synth32) is scheduled by hand so that no wave has more than one tile in A or in B:
 //   A: w0 ûx0, w1 ûx1, w2 T(0,0), w3 T(0,1)   B: w0 Qux0, w1 Qux1 (+ Qu), w2 Quu, w3 T(1,0)
 //   C: w1 Qx, Qxx(0,0); w2 Qxx(0,1); w3 T(1,1), Qxx(1,0), Qxx(1,1)   D: w1 P0, P3; w2 P1; w3 P2
+// (the ninth tile of windows A + B has no free slot and lands in C on wave 3, whose three tiles are about as long as the chain.
+// Forming that tile twice — on waves 1 and 3, two tiles each in C — was measured: the chain no longer waits 0.45 k clk per
+// timestep, but the eight extra MFMAs cost more when both instances of a CU are active: 3.83 -> 3.94 ms on BASELINE C5.)
 // Other sizes: critical tiles alternate over waves 0, 1; T tiles over waves 2, 3 (half in A, half in B); Qxx / P over waves 1..3.
 enum { RIC_UH = 1 << 5, RIC_T = 2 << 5, RIC_QUX = 3 << 5, RIC_QUU = 4 << 5, RIC_END = 0xff };   // task byte: kind << 5 | tile index
 template <int TN>

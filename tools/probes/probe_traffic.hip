@@ -48,6 +48,17 @@ __global__ void rmw8_strided(double* p, int steps) {
             for (int e = 0; e < 16; ++e) base[(size_t)t * 16 + e] += 0.2;
     }
 }
+// ONE 8-byte entry per 128-byte tile (entry 10): the accumulated-Hessian update of a model whose stage cost touches a single
+// entry per matrix — what granule does WRITE_SIZE / FETCH_SIZE count for a lone 8-byte read-modify-write?
+__global__ void rmw8_sparse(double* p, int steps) {
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    double* base = p + wave * (size_t)steps * 16;
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < steps) base[(size_t)t * 16 + 10] += 0.2;
+    }
+}
 __global__ void write8_rows16(double* p, int steps) {
     const size_t row = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4;      // four rows per wave, each its own block
     const int l = threadIdx.x & 15;
@@ -68,11 +79,13 @@ int main() {
         flush(); hipLaunchKernelGGL(read8_tile128, dim3((unsigned)(waves / 4)), dim3(256), 0, 0, a, out, steps);
         flush(); hipLaunchKernelGGL(write8_coalesced, dim3(8192), dim3(256), 0, 0, a, n8);
         flush(); hipLaunchKernelGGL(rmw8_strided, dim3((unsigned)(waves / 4)), dim3(256), 0, 0, a, steps);
+        flush(); hipLaunchKernelGGL(rmw8_sparse, dim3((unsigned)(waves / 4)), dim3(256), 0, 0, a, steps);
         flush(); hipLaunchKernelGGL(write8_rows16, dim3((unsigned)(rows / 16)), dim3(256), 0, 0, a, steps);
         hipDeviceSynchronize();
     }
     // kernel, true bytes read, true bytes written (per launch)
     printf("TRUE read16_coalesced %zu 0\nTRUE read8_coalesced %zu 0\nTRUE read8_tile128 %zu 0\nTRUE write8_coalesced 0 %zu\n"
-           "TRUE rmw8_strided %zu %zu\nTRUE write8_rows16 0 %zu\n", BYTES, BYTES, BYTES, BYTES, BYTES, BYTES, BYTES);
+           "TRUE rmw8_strided %zu %zu\nTRUE write8_rows16 0 %zu\nTRUE rmw8_sparse %zu %zu\n", BYTES, BYTES, BYTES, BYTES, BYTES, BYTES, BYTES,
+           BYTES / 16, BYTES / 16);
     return 0;
 }
