@@ -245,7 +245,7 @@ def worker(args, solver_factory=None):
         s_.set_kernel_variant_(args.variant)
     if len(sols) > 1 and args.variant == "auto":   # several batches in flight: which kernel fills the SIMDs freed by early finishers best
         for s_ in sols:
-            s_.set_kernel_variant_(os.environ.get("ILQR_INFLIGHT_VARIANT", "throughput"))
+            s_.set_kernel_variant_(os.environ.get("ILQR_INFLIGHT_VARIANT", "latency"))
     counter = [0]
 
     def step():
@@ -331,7 +331,7 @@ def worker(args, solver_factory=None):
                                options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
             pair = [sol, extra]
             for s_ in pair:
-                s_.set_kernel_variant_(os.environ.get("ILQR_INFLIGHT_VARIANT", "throughput") if args.variant == "auto" and sol.nx <= 4 and sol.nu <= 4 else args.variant)
+                s_.set_kernel_variant_(args.variant)       # (same kernel as the headline: the second batch's workgroups take the LDS of early finishers)
             cnt2 = [0]
 
             def step_pair():
@@ -346,7 +346,6 @@ def worker(args, solver_factory=None):
             secondary["inflight_2"] = {"value": world * B * 2 * k2 / el, "unit": "trajectories/s", "ms_per_batch": 1e3 * el / (2 * k2),
                                        "note": "two solver handles per GPU on separate streams, alternating batches"}
             extra.close()
-            sol.set_kernel_variant_(args.variant)
     per_rank = pkg.distributed.gather_over_ranks([1e3 * my_elapsed / args.steps, kernel_ms, it_sum, it_max], dist, cdev)
     if rank != 0:
         for s_ in sols:
