@@ -13,8 +13,8 @@
 // Riccati step (src/backward_pass.jl:42-90): 132 v_mfma_f64_16x16x4_f64 tiles for n = 32, m = 8 around the serial
 // potrf / potrs chain, scheduled over the four waves in four windows (one workgroup barrier each):
 //     A   waves 0,1: ûx = fuᵀP′ (the tiles the chain waits for)          waves 2,3: first half of T = fxᵀP′
-//     B   waves 0,1: Qux = ûx fx, Quu = ûx fu; wave 1: Qu = fuᵀp′ + gu   waves 2,3: rest of T
-//     C   wave 0: + guu, gux; potrf; potrs → K, k (the serial chain)      waves 1-3: Qx = fxᵀp′ + gx; Qxx = T fx + gxx into P′'s place
+//     B   waves 0,1: Qux = ûx fx, Quu = ûx fu                            waves 2,3: rest of T
+//     C   wave 0: + guu, gux; potrf; potrs → K, k (the serial chain)      waves 1-3: Qu (flag to wave 0), Qx; Qxx = T fx + gxx
 //     D   wave 0: ûxt = Quu K; p, ∇L                                      waves 1-3: P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx; all: patch fx, fu
 // Every tile is one generic call (tile_mm) with run-time tile coordinates; operand fragments are read from zero-padded LDS
 // matrices with odd leading dimensions (transposition = stride pattern, no bounds checks), the MFMAs of a tile issue back to back.
@@ -532,6 +532,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         sp[i] = v;
         if (STORE_VALUE) A.p[N * n + i] = v;
     }
+    if (tid == 0) sOut[5] = -1.0;                                          // "Qu of step t is ready" flag (wave 2 -> wave 0)
     // where this thread's entries go (offsets into S; -1 = none)
     int poff[EJ];
 #pragma unroll
@@ -657,20 +658,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         ILQR_SUB_MARK(I, 0);
         // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | T
         run_tiles(list_b);
-        if (wave == 1) {
-            // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum
-            constexpr int JP = (n + 3) / 4;
-            const int i = li < m ? li : m - 1;
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < JP; ++q) {
-                const int l = lk * JP + q;
-                if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
-            }
-            acc = sum_quarters(acc);
-            if (lane < m) sQu[lane] = acc + (STAGE ? sG[n + lane] : (double)A.gu[t * m + lane]);
-        }
-        __syncthreads();                                                  // (B2) Qux, Quu, Qu, T complete
+        __syncthreads();                                                  // (B2) Qux, Quu, T complete
         ILQR_SUB_MARK(I, 1);
         // ------------------------------------------------ window C: the serial chain | Qx, Qxx
         if (wave == 0) {
@@ -700,6 +688,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             }
             wave_lds_fence();
             ILQR_SUB_MARK(I, 2);
+            // Qu comes from wave 2, formed at the head of this window (it is needed only here, ~1.7 k clk in): a flag in LDS instead
+            // of a workgroup barrier — LDS serves a wave's requests in order, so whoever sees the flag sees Qu
+            while (__hip_atomic_load(&sOut[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
             // potrs('U'): column j of [Qux | Qu] per lane (Qu is column NP of the LDS matrix, k of K's)   (:70-75)
             // (nx = 64 leaves no lane for k: a second pass on lane 0)
 #pragma unroll
@@ -723,6 +714,23 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             }
             ILQR_SUB_MARK(I, 3);
         } else {
+            if (wave == 2) {
+                // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum; handed to the chain
+                // (wave 0) through the flag
+                constexpr int JP = (n + 3) / 4;
+                const int i = li < m ? li : m - 1;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < JP; ++q) {
+                    const int l = lk * JP + q;
+                    if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
+                }
+                acc = sum_quarters(acc);
+                if (lane < m) sQu[lane] = acc + (STAGE ? sG[n + lane] : (double)A.gu[t * m + lane]);
+                wave_lds_fence();
+                if (lane == 0) __hip_atomic_store(&sOut[5], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (STORE_VALUE && Qv != nullptr && lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
+            }
             if (wave == 1) {
                 // Qx = fxᵀp′ + gx (:44-46): state i on lanes i and i + 32 (half of the sum each) when n <= 32
                 if constexpr (n <= 32) {
@@ -744,7 +752,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                     if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
                 }
                 if (STORE_VALUE && Qv != nullptr && lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
-                if (STORE_VALUE && Qv != nullptr && lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
             }
             run_tiles(list_c);                                  // what is left of T (this wave's own Qxx rows need it)
             // Qxx = T fx + gxx (:53-54), written where P′ was (generic schedule: nobody reads P′ after window B) or to its own buffer
