@@ -373,6 +373,64 @@ __device__ __forceinline__ bool potrf_U_rows(double (&a)[m], double (&R)[m], int
     potrf_U_rows_step<m, 0>(a, R, col, bad);
     return bad;
 }
+template <int m, int NR, int I, int L>
+__device__ __forceinline__ void back_terms(const double (&a)[m], const double (&b)[NR][m], double (&w)[NR]) {
+    if constexpr (L < m) {
+        const double u = row_bcast<L>(a[I]);                                 // U(I,L) from the lanes that hold column L
+#pragma unroll
+        for (int q = 0; q < NR; ++q) w[q] -= u * b[q][L];
+        back_terms<m, NR, I, L + 1>(a, b, w);
+    }
+}
+// potrf('U') and potrs('U') in one sequence, the factor never leaving the registers: column c = lane & 15 of Quu on every lane
+// (a, as in potrf_U_rows) and NR right-hand sides per lane (b). The entries U(l,J), l < J, that pivot step J broadcasts for the
+// factorisation are exactly the ones row J of the forward substitution multiplies with, so that row rides along with its pivot
+// step (and fills the issue slots its dependent chain leaves empty); the back substitution re-broadcasts them (one DPP move
+// each). Same arithmetic, operation for operation, as potrf_U_rows + potrs_U_lds; the diagonal of the factor is not formed
+// (nobody reads it: the solves use R = 1 / diag). Returns whether a pivot was not positive (the caller then repeats the step
+// on the careful path).
+template <int m, int NR, int J = 0>
+__device__ __forceinline__ void chol_solve_rows_fwd(double (&a)[m], double (&R)[m], double (&b)[NR][m], bool& bad) {
+    if constexpr (J < m) {
+        double v = a[J], w[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) w[q] = b[q][J];
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+            const double u = row_bcast<J>(a[l]);                             // U(l,J), the same on every lane
+            v -= u * a[l];                                                   // A(J,c) - sum_l U(l,J) U(l,c)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) w[q] -= u * b[q][l];                // row J of U^T y = b
+        }
+        const double ajj = row_bcast<J>(v);
+        bad = bad || !(ajj > 0.0);
+        const double r = rsqrt_fast(ajj);
+        a[J] = v * r;
+        R[J] = r;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) b[q][J] = w[q] * r;
+        chol_solve_rows_fwd<m, NR, J + 1>(a, R, b, bad);
+    }
+}
+template <int m, int NR, int I>
+__device__ __forceinline__ void chol_solve_rows_back(const double (&a)[m], const double (&R)[m], double (&b)[NR][m]) {
+    if constexpr (I >= 0) {
+        double w[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) w[q] = b[q][I];
+        back_terms<m, NR, I, I + 1>(a, b, w);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) b[q][I] = w[q] * R[I];
+        chol_solve_rows_back<m, NR, I - 1>(a, R, b);
+    }
+}
+template <int m, int NR>
+__device__ __forceinline__ bool chol_solve_rows(double (&a)[m], double (&R)[m], double (&b)[NR][m]) {
+    bool bad = false;
+    chol_solve_rows_fwd<m, NR, 0>(a, R, b, bad);
+    chol_solve_rows_back<m, NR, m - 1>(a, R, b);
+    return bad;
+}
 // potrf('U') with column c of the matrix on lane c (a[i] = A(i, c), i <= c): dpotf2 order, element for element the arithmetic of
 // potrf_U (ilqr_device.hpp) — there every lane repeats the whole factorisation (m^3/3 FMAs on the serial chain), here a lane
 // updates its own column and the entries of column j it needs arrive by v_readlane: 3 instructions per (pivot, row) pair
@@ -671,42 +729,53 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 for (int e = lane; e < m * n; e += 64) Qv[QL.Qux + (size_t)t * m * n + e] = sQux[(e / m) * ldm + e % m];
                 for (int e = lane; e < m * m; e += 64) Qv[QL.Quu + (size_t)t * m * m + e] = sQuu[(e / m) * ldm + e % m];
             }
-            // potrf('U'), column c of Quu on lanes c, c + 16, ... (info ignored, :68-69); the factor goes to LDS for the solves
-            double Ua[m], Ur[m];
+            // potrf('U') (info ignored, :68-69) and potrs('U') on [Qux | Qu] (:70-75) fused: column c of Quu on lanes c, c + 16, ...,
+            // column j of [Qux | Qu] per lane (Qu is column NP of the LDS matrix, k of K's; nx = 64 leaves no lane for k: lane 0 carries
+            // it as a second right-hand side)
+            constexpr int NR = n < 64 ? 1 : 2;
+            double Ua[m], Ur[m], b[NR][m];
             const int ucol = li < m ? li : m - 1;
 #pragma unroll
             for (int i = 0; i < m; ++i) Ua[i] = sQuu[ucol * ldm + i];
-            if (__builtin_expect(potrf_U_rows<m>(Ua, Ur, li), 0)) {
+            // Qu comes from wave 2, formed at the head of this window: a flag in LDS instead of a workgroup barrier — LDS serves a
+            // wave's requests in order, so whoever sees the flag sees Qu
+            while (__hip_atomic_load(&sOut[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
+            const int col0 = n < 64 ? (lane < n ? lane : NP) : lane;
+#pragma unroll
+            for (int i = 0; i < m; ++i) b[0][i] = sQux[col0 * ldm + i];
+            if constexpr (NR == 2) {
+#pragma unroll
+                for (int i = 0; i < m; ++i) b[1][i] = sQux[NP * ldm + i];
+            }
+            ILQR_SUB_MARK(I, 2);
+            if (__builtin_expect(chol_solve_rows<m, NR>(Ua, Ur, b), 0)) {
+                // a pivot was not positive (rare: diverged instances): what dpotf2 leaves behind, then the solves against it
 #pragma unroll
                 for (int i = 0; i < m; ++i) Ua[i] = sQuu[ucol * ldm + i];
                 const int info = potrf_U_lanes<m>(Ua, Ur, lane);
                 if (info != 0 && potrf_info == 0) potrf_info = info;
-            }
-            if (lane < m) {
+                if (lane < m) {
 #pragma unroll
-                for (int i = 0; i < m; ++i) sU[lane * m + i] = Ua[i];
-            }
-            wave_lds_fence();
-            ILQR_SUB_MARK(I, 2);
-            // Qu comes from wave 2, formed at the head of this window (it is needed only here, ~1.7 k clk in): a flag in LDS instead
-            // of a workgroup barrier — LDS serves a wave's requests in order, so whoever sees the flag sees Qu
-            while (__hip_atomic_load(&sOut[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
-            // potrs('U'): column j of [Qux | Qu] per lane (Qu is column NP of the LDS matrix, k of K's)   (:70-75)
-            // (nx = 64 leaves no lane for k: a second pass on lane 0)
+                    for (int i = 0; i < m; ++i) sU[lane * m + i] = Ua[i];
+                }
+                wave_lds_fence();
 #pragma unroll
-            for (int pass = 0; pass < (n < 64 ? 1 : 2); ++pass) {
-                const bool mine = n < 64 ? lane <= n : (pass == 0 || lane == 0);
+                for (int q = 0; q < NR; ++q) {
+                    const int col = q == 0 ? col0 : NP;
+#pragma unroll
+                    for (int i = 0; i < m; ++i) b[q][i] = sQux[col * ldm + i];
+                    potrs_U_lds<m>(sU, Ur, b[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const bool mine = q == 0 ? (n < 64 ? lane <= n : true) : lane == 0;
                 if (mine) {
-                    const int j = (n < 64 || pass == 0) ? lane : n;
-                    const int col = j < n ? j : NP;
-                    double b[m];
-#pragma unroll
-                    for (int i = 0; i < m; ++i) b[i] = sQux[col * ldm + i];
-                    potrs_U_lds<m>(sU, Ur, b);            // inverted diagonal from the factorisation: no divisions here
-                    gdbl* dst = j < n ? A.K + (size_t)t * m * n + j * m : A.k + t * m;
+                    const int col = q == 0 ? col0 : NP;
+                    gdbl* dst = col != NP ? A.K + (size_t)t * m * n + col * m : A.k + t * m;
 #pragma unroll
                     for (int i = 0; i < m; ++i) {
-                        const double v = b[i] * -1.0;
+                        const double v = b[q][i] * -1.0;
                         sK[col * ldm + i] = v;
                         dst[i] = v;
                     }

@@ -54,7 +54,19 @@ __device__ __forceinline__ void sqrt_rsqrt_fast(double a, double& d, double& r) 
     d = fma(fma(-g, g, a), h, g);
     r = h + h;
 }
+// r alone (bitwise the r of sqrt_rsqrt_fast: 2 fma(h, e, h) = fma(2h, e, 2h)), one instruction shorter on the dependent chain and
+// without the four that only serve d — for the factorisations that never read the diagonal of the factor
+__device__ __forceinline__ double rsqrt_fast(double a) {
+    const double r0 = __builtin_amdgcn_rsq(a);
+    double g = a * r0, h = 0.5 * r0;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    const double h2 = h + h;
+    return fma(h2, e, h2);
+}
 #else
+ILQR_HD double rsqrt_fast(double a) { return 1.0 / sqrt(a); }
 ILQR_HD void sqrt_rsqrt_fast(double a, double& d, double& r) { d = sqrt(a); r = 1.0 / d; }
 ILQR_HD double fma3(double a, double b, double c) { return fma(a, b, c); }
 #define ILQR_OPAQUE(v) do {} while (0)
