@@ -120,14 +120,25 @@ __device__ __forceinline__ void load_w(const double* W, int t, double (&w)[cdim<
 #define ILQR_PROF_END(I, slot) do {} while (0)
 #define ILQR_SUB_BEGIN() long long sub_t0_ = clock64()
 #define ILQR_SUB_MARK(I, slot) do { const long long t1_ = clock64(); (I).prof[slot] += (double)(t1_ - sub_t0_); sub_t0_ = t1_; } while (0)
+#if defined(ILQR_SUB_SET) && ILQR_SUB_SET == 2      // the alternative set of mark sites (work / wait of the first two windows)
+#define ILQR_SUB_MARK1(I, slot) do {} while (0)
+#define ILQR_SUB_MARK2(I, slot) ILQR_SUB_MARK(I, slot)
+#else
+#define ILQR_SUB_MARK1(I, slot) ILQR_SUB_MARK(I, slot)
+#define ILQR_SUB_MARK2(I, slot) do {} while (0)
+#endif
 #elif defined(ILQR_PROFILE)
 #define ILQR_PROF_BEGIN() const long long prof_t0_ = clock64()
 #define ILQR_PROF_END(I, slot) (I).prof[slot] += (double)(clock64() - prof_t0_)
 #define ILQR_SUB_BEGIN() do {} while (0)
 #define ILQR_SUB_MARK(I, slot) do {} while (0)
+#define ILQR_SUB_MARK1(I, slot) do {} while (0)
+#define ILQR_SUB_MARK2(I, slot) do {} while (0)
 #else
 #define ILQR_SUB_BEGIN() do {} while (0)
 #define ILQR_SUB_MARK(I, slot) do {} while (0)
+#define ILQR_SUB_MARK1(I, slot) do {} while (0)
+#define ILQR_SUB_MARK2(I, slot) do {} while (0)
 #define ILQR_PROF_BEGIN() do {} while (0)
 #define ILQR_PROF_END(I, slot) do {} while (0)
 #endif

@@ -373,6 +373,14 @@ __device__ __forceinline__ bool potrf_U_rows(double (&a)[m], double (&R)[m], int
     potrf_U_rows_step<m, 0>(a, R, col, bad);
     return bad;
 }
+// out[i] = v of lane i of the 16-lane row, for every i < m (four identical rows: the same on every lane)
+template <int m, int I = 0>
+__device__ __forceinline__ void bcast_all(double v, double (&out)[m]) {
+    if constexpr (I < m) {
+        out[I] = row_bcast<I>(v);
+        bcast_all<m, I + 1>(v, out);
+    }
+}
 template <int m, int NR, int I, int L>
 __device__ __forceinline__ void back_terms(const double (&a)[m], const double (&b)[NR][m], double (&w)[NR]) {
     if constexpr (L < m) {
@@ -492,7 +500,7 @@ __device__ __forceinline__ void potrs_U_lds(const double* U, const double (&R)[m
 enum { RIC_UH = 1 << 5, RIC_T = 2 << 5, RIC_QUX = 3 << 5, RIC_QUU = 4 << 5, RIC_END = 0xff };   // task byte: kind << 5 | tile index
 template <int TN>
 struct RicSchedule {
-    static constexpr int NQ = TN * TN, MAXL = 8, SLOTS = (NQ + 2) / 3;       // a task list is one 64-bit word: eight task bytes
+    static constexpr int NQ = TN * TN, MAXL = 8, SLOTS = (NQ + 2) / 3, RIC_WAIT_T = 0x40;       // a task list is one 64-bit word: eight task bytes
     struct Tab {
         int a[4][MAXL], b[4][MAXL], ct[4][MAXL], qxx[4][SLOTS], p[4][SLOTS];
         unsigned long long wa[4], wb[4], wc[4];                               // the lists packed, RIC_END-terminated
@@ -508,8 +516,9 @@ struct RicSchedule {
             t.a[0][na[0]++] = RIC_UH + 0; t.a[1][na[1]++] = RIC_UH + 1; t.a[2][na[2]++] = RIC_T + 0; t.a[3][na[3]++] = RIC_T + 1;
             t.b[0][nb[0]++] = RIC_QUX + 0; t.b[1][nb[1]++] = RIC_QUX + 1; t.b[2][nb[2]++] = RIC_QUU; t.b[3][nb[3]++] = RIC_T + 2;
             t.ct[3][nc[3]++] = RIC_T + 3;
-            t.qxx[1][nq[1]++] = 0; t.qxx[2][nq[2]++] = 1; t.qxx[3][nq[3]++] = 2; t.qxx[3][nq[3]++] = 3;
-            t.p[1][np[1]++] = 0; t.p[1][np[1]++] = 3; t.p[2][np[2]++] = 1; t.p[3][np[3]++] = 2;
+            // Qxx(1,.) needs T(1,1), formed in this same window by wave 3: tile 2 on wave 1 waits for wave 3's flag (RIC_WAIT_T)
+            t.qxx[1][nq[1]++] = 0; t.qxx[1][nq[1]++] = 2 | RIC_WAIT_T; t.qxx[2][nq[2]++] = 1; t.qxx[3][nq[3]++] = 3;
+            t.p[0][np[0]++] = 3; t.p[1][np[1]++] = 0; t.p[2][np[2]++] = 1; t.p[3][np[3]++] = 2;
         } else {
             for (int c = 0; c < TN; ++c) { const int w = c % 2; t.a[w][na[w]++] = RIC_UH + c; }
             for (int v = 2; v < 4; ++v) {
@@ -521,7 +530,7 @@ struct RicSchedule {
             }
             for (int i = 0; i <= TN; ++i) { const int w = i % 2; t.b[w][nb[w]++] = i < TN ? RIC_QUX + i : RIC_QUU; }
             for (int q = 0; q < NQ; ++q) { const int w = 1 + (q + 1) % 3; t.qxx[w][nq[w]++] = q; }
-            for (int q = 0; q < NQ; ++q) { const int w = 1 + q % 3; t.p[w][np[w]++] = q; }
+            for (int q = 0; q < NQ; ++q) { const int w = (q + 1) % 4; t.p[w][np[w]++] = q; }      // wave 0 last: it also stores p, Lx, Lu
         }
         for (int w = 0; w < 4; ++w) {
             t.wa[w] = 0; t.wb[w] = 0; t.wc[w] = 0;
@@ -536,6 +545,23 @@ struct RicSchedule {
     static constexpr Tab tab = make();
     static_assert(NQ <= 16, "tile index fits five bits; at most eight tasks per list (TN <= 4)");
 };
+
+// compile-time loop and a switch on the (uniform) wave index that hands the index over as a constant: the Riccati step's static
+// schedule is compiled into four straight-line instruction streams, one per wave, with every tile coordinate an immediate
+template <int V> struct IntC { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IntC<I>{}); static_for<I + 1, N>(f); }
+}
+template <class F>
+__device__ __forceinline__ void wave_switch(int wave, F&& f) {
+    switch (wave) {
+        case 0: f(IntC<0>{}); break;
+        case 1: f(IntC<1>{}); break;
+        case 2: f(IntC<2>{}); break;
+        default: f(IntC<3>{}); break;
+    }
+}
 
 struct RiccatiOut {
     double gradient_norm; int potrf_info;
@@ -590,7 +616,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         sp[i] = v;
         if (STORE_VALUE) A.p[N * n + i] = v;
     }
-    if (tid == 0) sOut[5] = -1.0;                                          // "Qu of step t is ready" flag (wave 2 -> wave 0)
+    // flags of window C, each holding the step whose datum is ready: [5] Qu (wave 2 -> wave 0), [6] Qx (wave 1 -> wave 0),
+    // [7] what is left of T (wave 3 -> the wave whose Qxx tile waits for it)
+    if (tid < 3) sOut[5 + tid] = -1.0;
     // where this thread's entries go (offsets into S; -1 = none)
     int poff[EJ];
 #pragma unroll
@@ -618,7 +646,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     int xcnt[SLOTS], xbeg[SLOTS], xoff[SLOTS][EXT];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const int q = RS::tab.qxx[wave][s];
+        const int q = RS::tab.qxx[wave][s] < 0 ? -1 : (RS::tab.qxx[wave][s] & ~RS::RIC_WAIT_T);
         const bool have = q >= 0;
         xbeg[s] = have ? M::HESS_XX_TILE_START[have ? q : 0] : 0;
         xcnt[s] = have ? M::HESS_XX_TILE_START[(have ? q : 0) + 1] - xbeg[s] : 0;
@@ -672,17 +700,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     };
     if (STAGE && N > 0) { stage_load(N - 1, rval); stage_store(rval); }
     double gmax = 0.0;
-    // this wave's part of the static schedule, read once
-    auto uniform64 = [](unsigned long long v) {
-        return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
-    };
-    const unsigned long long list_a = uniform64(RS::tab.wa[wave]), list_b = uniform64(RS::tab.wb[wave]), list_c = uniform64(RS::tab.wc[wave]);
-    int qxx_tile[SLOTS], p_tile[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        qxx_tile[s] = __builtin_amdgcn_readfirstlane(RS::tab.qxx[wave][s]);
-        p_tile[s] = __builtin_amdgcn_readfirstlane(RS::tab.p[wave][s]);
-    }
     __syncthreads();
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
         ILQR_SUB_BEGIN();
@@ -692,34 +709,42 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
         for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)tn * JVP + (tid - 64) + NS * j] : 0.0;
         // ------------------------------------------------ window A: ûx = fuᵀP′ (:57) | T = fxᵀP′ (:52)
-        auto run_tiles = [&](unsigned long long lst) {                    // the task bytes of this wave, in a scalar register pair
-            for (; (lst & 0xff) != RIC_END; lst = (lst >> 8) | (0xffull << 56)) {
-                const int task = (int)(lst & 0xff), kind = task & 0xe0, idx = task & 0x1f;
-                if (kind == RIC_UH) {
-                    const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFu, sP + ld * 16 * idx, li, lk);
-                    tile_store<ldm>(sUh, acc, 0, 16 * idx, li, lk);
-                } else if (kind == RIC_T) {
-                    const int a = idx / TN, c = idx % TN;
-                    const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
-                    tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
-                } else if (kind == RIC_QUX) {
-                    const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
-                    tile_store<ldm>(sQux, acc, 0, 16 * idx, li, lk);
-                } else {
-                    const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
-                    tile_store<ldm>(sQuu, acc, 0, 0, li, lk);
+        auto run_tiles = [&](auto Wc, auto WINc) {                        // window WIN's tasks of wave W, all compile-time
+            constexpr int W = decltype(Wc)::value, WIN = decltype(WINc)::value;
+            static_for<0, RS::MAXL>([&](auto Ic) {
+                constexpr int task = WIN == 0 ? RS::tab.a[W][decltype(Ic)::value] : WIN == 1 ? RS::tab.b[W][decltype(Ic)::value] : RS::tab.ct[W][decltype(Ic)::value];
+                if constexpr (task >= 0) {
+                    constexpr int kind = task & 0xe0, idx = task & 0x1f;
+                    if constexpr (kind == RIC_UH) {
+                        const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFu, sP + ld * 16 * idx, li, lk);
+                        tile_store<ldm>(sUh, acc, 0, 16 * idx, li, lk);
+                    } else if constexpr (kind == RIC_T) {
+                        constexpr int a = idx / TN, c = idx % TN;
+                        const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
+                        tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
+                    } else if constexpr (kind == RIC_QUX) {
+                        const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
+                        tile_store<ldm>(sQux, acc, 0, 16 * idx, li, lk);
+                    } else {
+                        const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
+                        tile_store<ldm>(sQuu, acc, 0, 0, li, lk);
+                    }
                 }
-            }
+            });
         };
-        run_tiles(list_a);
+        wave_switch(wave, [&](auto Wc) { run_tiles(Wc, IntC<0>{}); });
+        ILQR_SUB_MARK2(I, 0);
         __syncthreads();                                                  // (B1) ûx complete
-        ILQR_SUB_MARK(I, 0);
+        ILQR_SUB_MARK1(I, 0); ILQR_SUB_MARK2(I, 1);
         // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | T
-        run_tiles(list_b);
+        wave_switch(wave, [&](auto Wc) { run_tiles(Wc, IntC<1>{}); });
+        ILQR_SUB_MARK2(I, 2);
         __syncthreads();                                                  // (B2) Qux, Quu, T complete
-        ILQR_SUB_MARK(I, 1);
-        // ------------------------------------------------ window C: the serial chain | Qx, Qxx
+        ILQR_SUB_MARK1(I, 1); ILQR_SUB_MARK2(I, 3);
+        // ------------------------------------------------ window C: the serial chain and p, ∇L | Qx, Qu, Qxx
+        double pn = 0.0;
         if (wave == 0) {
+            double Lxv, Luv;
             // Quu += guu, Qux += gux (:59, :64): the structurally non-zero entries only
 #pragma unroll
             for (int j = 0; j < EU; ++j)
@@ -747,7 +772,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
                 for (int i = 0; i < m; ++i) b[1][i] = sQux[NP * ldm + i];
             }
-            ILQR_SUB_MARK(I, 2);
+            ILQR_SUB_MARK1(I, 2);
             if (__builtin_expect(chol_solve_rows<m, NR>(Ua, Ur, b), 0)) {
                 // a pivot was not positive (rare: diverged instances): what dpotf2 leaves behind, then the solves against it
 #pragma unroll
@@ -769,21 +794,59 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             }
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
+#pragma unroll
+                for (int i = 0; i < m; ++i) b[q][i] *= -1.0;                // K, k (:72-75)
                 const bool mine = q == 0 ? (n < 64 ? lane <= n : true) : lane == 0;
                 if (mine) {
                     const int col = q == 0 ? col0 : NP;
                     gdbl* dst = col != NP ? A.K + (size_t)t * m * n + col * m : A.k + t * m;
 #pragma unroll
                     for (int i = 0; i < m; ++i) {
-                        const double v = b[q][i] * -1.0;
-                        sK[col * ldm + i] = v;
-                        dst[i] = v;
+                        sK[col * ldm + i] = b[q][i];
+                        dst[i] = b[q][i];
                     }
                 }
             }
-            ILQR_SUB_MARK(I, 3);
-        } else {
-            if (wave == 2) {
+            // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx (:86-89) with ux_tmp^T k = (Quu K)^T k formed as K^T (Quu^T k), and the Lagrangian
+            // gradient (src/solve.jl:73-81), here rather than in window D: column j of K is still in lane j's registers and k in those
+            // of lane nx (lane 0's second right-hand side when nx = 64); the m-vector Quu^T k takes m FMAs with column c of Quu per lane.
+            {
+                double kk[m], Qk[m];
+#pragma unroll
+                for (int l = 0; l < m; ++l) kk[l] = lane_bcast(b[NR - 1][l], n < 64 ? n : 0);
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < m; ++r) acc += sQuu[ucol * ldm + r] * kk[r];
+                bcast_all<m>(acc, Qk);                                      // Qk[l] = (Quu^T k)[l], the same on every lane
+                while (__hip_atomic_load(&sOut[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
+                const int j = lane < n ? lane : 0;
+                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) {
+                    a1 += b[0][l] * Qk[l];
+                    a2 += b[0][l] * sQu[l];
+                    a3 += sQux[j * ldm + l] * kk[l];
+                }
+                const double qx = sQx[j];
+                pn = ((a1 + a2) + a3) + qx;
+                Lxv = qx - pn;
+                if (lane < n) gmax = nanmax(gmax, fabs(Lxv));
+                if (lane < m) {
+                    Luv = sQu[lane];
+                    gmax = nanmax(gmax, fabs(Luv));
+                }
+                // stored here, a window ahead of the loop edge: the counter of outstanding memory operations is waited to zero at the
+                // top of a step (the fetches of waves 1..3 share the code), and a store issued just before it would be waited for there
+                if (lane < n) {
+                    A.Lx[t * n + lane] = Lxv;
+                    if (STORE_VALUE) A.p[t * n + lane] = pn;
+                }
+                if (lane < m) A.Lu[t * m + lane] = Luv;
+            }
+            ILQR_SUB_MARK1(I, 3);
+        } else wave_switch(wave, [&](auto Wc) {
+            constexpr int W = decltype(Wc)::value;
+            if constexpr (W == 2) {
                 // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum; handed to the chain
                 // (wave 0) through the flag
                 constexpr int JP = (n + 3) / 4;
@@ -800,7 +863,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 if (lane == 0) __hip_atomic_store(&sOut[5], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (STORE_VALUE && Qv != nullptr && lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
             }
-            if (wave == 1) {
+            if constexpr (W == 1) {
                 // Qx = fxᵀp′ + gx (:44-46): state i on lanes i and i + 32 (half of the sum each) when n <= 32
                 if constexpr (n <= 32) {
                     constexpr int JP = (n + 1) / 2;
@@ -820,23 +883,31 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                     for (int l = 0; l < n; ++l) acc += sFx[i * ld + l] * sp[l];
                     if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
                 }
+                wave_lds_fence();
+                if (lane == 0) __hip_atomic_store(&sOut[6], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (STORE_VALUE && Qv != nullptr && lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
             }
-            run_tiles(list_c);                                  // what is left of T (this wave's own Qxx rows need it)
+            if constexpr (W > 0 && RS::tab.ct[W][0] >= 0) {     // what is left of T; a Qxx tile on another wave may wait for it
+                run_tiles(Wc, IntC<2>{});
+                wave_lds_fence();
+                if (lane == 0) __hip_atomic_store(&sOut[7], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             // Qxx = T fx + gxx (:53-54), written where P′ was (generic schedule: nobody reads P′ after window B) or to its own buffer
             // (TN = 2: a tile of T is still being formed from P′ in this window); the wave that stored a tile adds its gxx entries
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int q = qxx_tile[s];
-                if (q >= 0) {
-                    const int a = q / TN, c = q % TN;
+            if constexpr (W > 0) static_for<0, SLOTS>([&](auto Sc) {
+                constexpr int s = decltype(Sc)::value, e = RS::tab.qxx[W][s];
+                if constexpr (e >= 0) {
+                    constexpr int q = e & ~RS::RIC_WAIT_T, a = q / TN, c = q % TN;
+                    if constexpr ((e & RS::RIC_WAIT_T) != 0)
+                        while (__hip_atomic_load(&sOut[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
                     const double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
                     tile_store<ld>(sQ, acc, 16 * a, 16 * c, li, lk);
-                    if (xcnt[s] > 0) {
+                    constexpr int xb = M::HESS_XX_TILE_START[q], xc = M::HESS_XX_TILE_START[q + 1] - xb;
+                    if constexpr (xc > 0) {
                         wave_lds_fence();
 #pragma unroll
-                        for (int x = 0; x < EXT; ++x)
-                            if (xoff[s][x] >= 0) S[xoff[s][x]] += STAGE ? sH[xbeg[s] + lane + 64 * x] : (double)A.hc[(size_t)t * HSP + xbeg[s] + lane + 64 * x];
+                        for (int x = 0; x < (xc + 63) / 64; ++x)
+                            if (xoff[s][x] >= 0) S[xoff[s][x]] += STAGE ? sH[xb + lane + 64 * x] : (double)A.hc[(size_t)t * HSP + xb + lane + 64 * x];
                     }
                     if (STORE_VALUE && Qv != nullptr) {
                         wave_lds_fence();
@@ -847,20 +918,18 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         }
                     }
                 }
-            }
-        }
+            });
+        });
         __syncthreads();                                                  // (B3) K, k, Qx in LDS; T, fx, fu no longer needed
-        ILQR_SUB_MARK(I, 4);
+        ILQR_SUB_MARK1(I, 4); ILQR_SUB_MARK2(I, 4);
         // ------------------------------------------------ window D: P (:79-84) | p, ∇L (:86-89, src/solve.jl:73-81); next step's Jacobian entries
-        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order, on waves 1..3 (wave 0 has the
-        // vector chain); ux_tmp = Quu K (:79) comes out of its MFMAs in exactly the layout the next MFMA's B operand wants
+        // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order, on one tile per wave when nx <= 32; ux_tmp = Quu K (:79) comes out of its MFMAs in exactly the layout the next MFMA's B operand wants
         // (k = lane>>4 + 4 reg, j = lane&15). All fragments of a tile are read first, then its eight MFMAs issue back to back.
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int q = p_tile[s];
-            if (q >= 0) {
+        wave_switch(wave, [&](auto Wc) { static_for<0, SLOTS>([&](auto Sc) {
+            constexpr int q = RS::tab.p[decltype(Wc)::value][decltype(Sc)::value];
+            if constexpr (q >= 0) {
                 constexpr int KS = m4 / 4;
-                const int a = q / TN, c = q % TN;
+                constexpr int a = q / TN, c = q % TN;
                 const double* pKa = sK + ldm * (16 * a + li) + lk;                     // A(i,k) = K[k][16a + i]
                 const double* pKc = sK + ldm * (16 * c + li) + lk;                     // B(k,j) = K[k][16c + j]
                 const double* pQa = sQux + ldm * (16 * a + li) + lk;                   // A(i,k) = Qux[k][16a + i]
@@ -893,39 +962,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                     }
                 }
             }
-        }
-        // p = ux_tmp^T k + K^T Qu + Qux^T k + Qx (:86-89) with ux_tmp^T k = (Quu K)^T k formed as K^T (Quu^T k): the m-vector Quu^T k
-        // costs m FMAs on m lanes where the tiles of ux_tmp cost four MFMAs and two LDS round trips on wave 0's chain;
-        // Lagrangian gradient (src/solve.jl:73-81): values first ...
-        double pn = 0.0, Lxv = 0.0, Luv = 0.0;
-        if (wave == 0) {
-            double* sQk = sUxt;                                           // Quu^T k
-            if (lane < m) {
-                double acc = 0.0;
-#pragma unroll
-                for (int r = 0; r < m; ++r) acc += sQuu[lane * ldm + r] * sk[r];
-                sQk[lane] = acc;
-            }
-            wave_lds_fence();
-            if (lane < n) {
-                double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-                for (int l = 0; l < m; ++l) {
-                    const double Kl = sK[lane * ldm + l];
-                    a1 += Kl * sQk[l];
-                    a2 += Kl * sQu[l];
-                    a3 += sQux[lane * ldm + l] * sk[l];
-                }
-                pn = ((a1 + a2) + a3) + sQx[lane];
-                Lxv = sQx[lane] - pn;
-                gmax = nanmax(gmax, fabs(Lxv));
-            }
-            if (lane < m) {
-                Luv = sQu[lane];
-                gmax = nanmax(gmax, fabs(Luv));
-            }
-        }
-        // ... then, by all threads alike, the next step's operands into LDS (waits for the loads requested at the top of the step;
+        }); });
+        // the next step's operands into LDS, by the threads that requested them (waits for the loads requested at the top of the step;
         // placed here so that the acknowledgements of wave 0's K, k stores are not waited for as well) ...
         // (unconditional: at t = 0 it rewrites step 0's own values, and the loads must be consumed on every path through the loop —
         // a path that skipped them would leave them pending at the loop edge and every iteration would start by waiting)
@@ -933,17 +971,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         for (int j = 0; j < EJ; ++j)
             if (poff[j] >= 0) S[poff[j]] = pval[j];
         if (STAGE) stage_store(rval);
-        // ... and the stores last
-        if (wave == 0) {
-            if (lane < n) {
-                A.Lx[t * n + lane] = Lxv;
-                if (STORE_VALUE) A.p[t * n + lane] = pn;
-                sp[lane] = pn;                                            // p' of the next step
-            }
-            if (lane < m) A.Lu[t * m + lane] = Luv;
-        }
+        if (wave == 0 && lane < n) sp[lane] = pn;                         // p' of the next step (its readers of this step are past B3)
         __syncthreads();                                                  // (B0) P′, p′, patched fx, fu visible
-        ILQR_SUB_MARK(I, 5);
+        ILQR_SUB_MARK1(I, 5); ILQR_SUB_MARK2(I, 5);
     }
     // the serial chain lived on wave 0: hand its scalars to all waves (identical control flow afterwards)
     const double gn = wave_max(gmax);
