@@ -40,8 +40,8 @@ struct LargeDims {
     static constexpr int HXX = M::HESS_NXX, HUU = M::HESS_NUU, HUX = M::HESS_NUX, HS = HXX + HUU + HUX, HSP = pad2(HS > 0 ? HS : 1);
     // LDS carve (doubles); must match large_lds_doubles() of ilqr_layout.hpp
     static constexpr int oFx = 0, oFu = oFx + NP * ld, oP = oFu + MP * ld, oT = oP + NP * ld, oUh = oT + NP * ld,
-                         oQux = oUh + NP * ldm, oK = oQux + (NP + 1) * ldm, oUxt = oK + (NP + 1) * ldm, oQuu = oUxt + NP * ldm,
-                         oChol = oQuu + MP * ldm, oVec = oChol + LARGE_CHOL, oLay = oVec + 2 * NP + 8,      // Qux, K: one more column for Qu, k
+                         oQux = oUh + NP * ldm, oK = oQux + (NP + 1) * ldm, oGux = oK + (NP + 1) * ldm, oQuu = oGux + NP * ldm,
+                         oGuu = oQuu + MP * ldm, oChol = oGuu + MP * ldm, oVec = oChol + LARGE_CHOL, oLay = oVec + 2 * NP + 8,      // Qux, K: one more column for Qu, k
                          oQxx = oLay + LAYOUT_LDS_DOUBLES, QXB = TN == 2 ? NP * ld : 0,                      // Qxx's own buffer (TN = 2 schedule)
                          oStg = oQxx + QXB, STG = large_stage_doubles(n, m, HS), total = oStg + STG;
     static constexpr bool STAGE = STG > 0;                  // next step's compact Hessian row and cost gradients staged in LDS
@@ -60,6 +60,15 @@ __device__ __forceinline__ void tile_store(double* D, double4_t acc, int I0, int
     double* p = D + (J0 + li) * LDD + I0 + lk;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[4 * r] = acc[r];
+}
+
+template <int LDD>
+__device__ __forceinline__ double4_t tile_load(const double* D, int I0, int J0, int li, int lk) {
+    const double* p = D + (J0 + li) * LDD + I0 + lk;
+    double4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = p[4 * r];
+    return v;
 }
 
 // One 16x16 output tile on v_mfma_f64_16x16x4_f64: acc += sum_{k<KD} A(i,k) B(k,j), A(i,k) at Ab[AI*i + AK*k], B(k,j) at
@@ -513,11 +522,13 @@ struct RicSchedule {
             for (int i = 0; i < SLOTS; ++i) { t.qxx[w][i] = -1; t.p[w][i] = -1; }
         }
         if (TN == 2) {
+            // A: ûx | T(0,.)   B: Qux, Quu | (wave 3: Qu, Qx)   C: chain | T(1,.), Qxx   D: P
             t.a[0][na[0]++] = RIC_UH + 0; t.a[1][na[1]++] = RIC_UH + 1; t.a[2][na[2]++] = RIC_T + 0; t.a[3][na[3]++] = RIC_T + 1;
-            t.b[0][nb[0]++] = RIC_QUX + 0; t.b[1][nb[1]++] = RIC_QUX + 1; t.b[2][nb[2]++] = RIC_QUU; t.b[3][nb[3]++] = RIC_T + 2;
-            t.ct[3][nc[3]++] = RIC_T + 3;
-            // Qxx(1,.) needs T(1,1), formed in this same window by wave 3: tile 2 on wave 1 waits for wave 3's flag (RIC_WAIT_T)
-            t.qxx[1][nq[1]++] = 0; t.qxx[1][nq[1]++] = 2 | RIC_WAIT_T; t.qxx[2][nq[2]++] = 1; t.qxx[3][nq[3]++] = 3;
+            t.b[0][nb[0]++] = RIC_QUX + 0; t.b[1][nb[1]++] = RIC_QUX + 1; t.b[2][nb[2]++] = RIC_QUU;
+            t.ct[2][nc[2]++] = RIC_T + 2; t.ct[3][nc[3]++] = RIC_T + 3;
+            // Qxx(1,.) needs T(1,0) and T(1,1), formed in this same window by waves 2 and 3: those tiles wait for the flags of the
+            // OTHER waves that form T here (RIC_WAIT_T)
+            t.qxx[1][nq[1]++] = 0; t.qxx[1][nq[1]++] = 2 | RIC_WAIT_T; t.qxx[2][nq[2]++] = 1; t.qxx[3][nq[3]++] = 3 | RIC_WAIT_T;
             t.p[0][np[0]++] = 3; t.p[1][np[1]++] = 0; t.p[2][np[2]++] = 1; t.p[3][np[3]++] = 2;
         } else {
             for (int c = 0; c < TN; ++c) { const int w = c % 2; t.a[w][na[w]++] = RIC_UH + c; }
@@ -595,7 +606,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     const int N = A.N, li = lane & 15, lk = lane >> 4;
     double* S = lds_dyn;
     double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *sP = S + LD::oP, *sT = S + LD::oT, *sUh = S + LD::oUh, *sQux = S + LD::oQux,
-           *sK = S + LD::oK, *sUxt = S + LD::oUxt, *sQuu = S + LD::oQuu;
+           *sK = S + LD::oK, *sGux = S + LD::oGux, *sQuu = S + LD::oQuu, *sGuu = S + LD::oGuu;
     double *sp = S + LD::oVec, *sQx = sp + NP, *sOut = sQx + NP;
     double *sQu = sQux + NP * ldm, *sk = sK + NP * ldm;              // Qu and k ride along as column NP of Qux and K
     double* sU = S + LD::oChol;                                            // the Cholesky factor, column c at sU + c m
@@ -616,8 +627,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         sp[i] = v;
         if (STORE_VALUE) A.p[N * n + i] = v;
     }
-    // flags of window C, each holding the step whose datum is ready: [5] Qu (wave 2 -> wave 0), [6] Qx (wave 1 -> wave 0),
-    // [7] what is left of T (wave 3 -> the wave whose Qxx tile waits for it)
+    // flags of window C, each holding the step whose datum is ready: [4 + w] = what wave w forms of T in that window
     if (tid < 3) sOut[5 + tid] = -1.0;
     // where this thread's entries go (offsets into S; -1 = none)
     int poff[EJ];
@@ -691,12 +701,26 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             R[j] = (tid >= 64 && e < HSP + NG) ? (double)A.hc[off] : 0.0;
         }
     };
+    // where a staged element goes: the gxx entries and the gradients into the staging row; the guu / gux entries into dense
+    // matrices Guu, Gux (zero elsewhere, for good: the same positions are rewritten every step) that the waves forming Quu / Qux
+    // add to their tiles before storing them — the chain never touches them
+    int soff[ER];
+#pragma unroll
+    for (int j = 0; j < ER; ++j) {
+        const int e = (tid - 64) + NS * j;
+        soff[j] = -1;
+        if (tid >= 64 && e < HSP + NG) {
+            soff[j] = LD::oStg + e;
+            if (e >= HXX && e < HXX + HUU + HUX) {
+                const int idx = M::HESS_IDX[e];
+                soff[j] = (e < HXX + HUU ? LD::oGuu : LD::oGux) + (idx / m) * ldm + idx % m;
+            }
+        }
+    }
     auto stage_store = [&](const double (&R)[ER]) {
 #pragma unroll
-        for (int j = 0; j < ER; ++j) {
-            const int e = (tid - 64) + NS * j;
-            if (tid >= 64 && e < HSP + NG) sH[e] = R[j];
-        }
+        for (int j = 0; j < ER; ++j)
+            if (soff[j] >= 0) S[soff[j]] = R[j];
     };
     if (STAGE && N > 0) { stage_load(N - 1, rval); stage_store(rval); }
     double gmax = 0.0;
@@ -722,11 +746,13 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         constexpr int a = idx / TN, c = idx % TN;
                         const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
                         tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
-                    } else if constexpr (kind == RIC_QUX) {
-                        const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
+                    } else if constexpr (kind == RIC_QUX) {                  // Qux = ûx fx + gux (:63-64)
+                        double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
+                        if constexpr (STAGE) acc += tile_load<ldm>(sGux, 0, 16 * idx, li, lk);
                         tile_store<ldm>(sQux, acc, 0, 16 * idx, li, lk);
-                    } else {
-                        const double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
+                    } else {                                                 // Quu = ûx fu + guu (:58-59)
+                        double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
+                        if constexpr (STAGE) acc += tile_load<ldm>(sGuu, 0, 0, li, lk);
                         tile_store<ldm>(sQuu, acc, 0, 0, li, lk);
                     }
                 }
@@ -738,6 +764,45 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         ILQR_SUB_MARK1(I, 0); ILQR_SUB_MARK2(I, 1);
         // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | T
         wave_switch(wave, [&](auto Wc) { run_tiles(Wc, IntC<1>{}); });
+        // wave 3 (no tile in this window when nx <= 32): the two matrix-vector products of the step
+        if (wave == 3) {
+            {
+                // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum
+                constexpr int JP = (n + 3) / 4;
+                const int i = li < m ? li : m - 1;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < JP; ++q) {
+                    const int l = lk * JP + q;
+                    if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
+                }
+                acc = sum_quarters(acc);
+                if (lane < m) sQu[lane] = acc + (STAGE ? sG[n + lane] : (double)A.gu[t * m + lane]);
+                if (STORE_VALUE && Qv != nullptr && lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
+            }
+            {
+                // Qx = fxᵀp′ + gx (:44-46): state i on lanes i and i + 32 (half of the sum each) when n <= 32
+                if constexpr (n <= 32) {
+                    constexpr int JP = (n + 1) / 2;
+                    const int i = (lane & 31) < n ? (lane & 31) : n - 1, h = lane >> 5;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < JP; ++q) {
+                        const int l = h * JP + q;
+                        if ((n % 2 == 0) || l < n) acc += sFx[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
+                    }
+                    acc = sum_halves(acc);
+                    if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
+                } else {
+                    const int i = lane < n ? lane : n - 1;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int l = 0; l < n; ++l) acc += sFx[i * ld + l] * sp[l];
+                    if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
+                }
+                if (STORE_VALUE && Qv != nullptr && lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
+            }
+        }
         ILQR_SUB_MARK2(I, 2);
         __syncthreads();                                                  // (B2) Qux, Quu, T complete
         ILQR_SUB_MARK1(I, 1); ILQR_SUB_MARK2(I, 3);
@@ -746,10 +811,13 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         if (wave == 0) {
             double Lxv, Luv;
             // Quu += guu, Qux += gux (:59, :64): the structurally non-zero entries only
+            // (with the staging row the producing waves have added them already)
+            if constexpr (!STAGE) {
 #pragma unroll
-            for (int j = 0; j < EU; ++j)
-                if (uoff[j] >= 0) S[uoff[j]] += STAGE ? sH[HXX + lane + 64 * j] : (double)A.hc[(size_t)t * HSP + HXX + lane + 64 * j];
-            wave_lds_fence();
+                for (int j = 0; j < EU; ++j)
+                    if (uoff[j] >= 0) S[uoff[j]] += (double)A.hc[(size_t)t * HSP + HXX + lane + 64 * j];
+                wave_lds_fence();
+            }
             if (STORE_VALUE && Qv != nullptr) {                           // policy.action_value.* (src/data/policy.jl:58-64)
                 for (int e = lane; e < m * n; e += 64) Qv[QL.Qux + (size_t)t * m * n + e] = sQux[(e / m) * ldm + e % m];
                 for (int e = lane; e < m * m; e += 64) Qv[QL.Quu + (size_t)t * m * m + e] = sQuu[(e / m) * ldm + e % m];
@@ -762,15 +830,14 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             const int ucol = li < m ? li : m - 1;
 #pragma unroll
             for (int i = 0; i < m; ++i) Ua[i] = sQuu[ucol * ldm + i];
-            // Qu comes from wave 2, formed at the head of this window: a flag in LDS instead of a workgroup barrier — LDS serves a
-            // wave's requests in order, so whoever sees the flag sees Qu
-            while (__hip_atomic_load(&sOut[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
             const int col0 = n < 64 ? (lane < n ? lane : NP) : lane;
+            // K = -Quu^-1 Qux, k = -Quu^-1 Qu (:72-75): the solves run on the NEGATED right-hand sides (exact; the sign rides on the
+            // first instruction that reads them)
 #pragma unroll
-            for (int i = 0; i < m; ++i) b[0][i] = sQux[col0 * ldm + i];
+            for (int i = 0; i < m; ++i) b[0][i] = -sQux[col0 * ldm + i];
             if constexpr (NR == 2) {
 #pragma unroll
-                for (int i = 0; i < m; ++i) b[1][i] = sQux[NP * ldm + i];
+                for (int i = 0; i < m; ++i) b[1][i] = -sQux[NP * ldm + i];
             }
             ILQR_SUB_MARK1(I, 2);
             if (__builtin_expect(chol_solve_rows<m, NR>(Ua, Ur, b), 0)) {
@@ -788,14 +855,12 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 for (int q = 0; q < NR; ++q) {
                     const int col = q == 0 ? col0 : NP;
 #pragma unroll
-                    for (int i = 0; i < m; ++i) b[q][i] = sQux[col * ldm + i];
+                    for (int i = 0; i < m; ++i) b[q][i] = -sQux[col * ldm + i];
                     potrs_U_lds<m>(sU, Ur, b[q]);
                 }
             }
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
-#pragma unroll
-                for (int i = 0; i < m; ++i) b[q][i] *= -1.0;                // K, k (:72-75)
                 const bool mine = q == 0 ? (n < 64 ? lane <= n : true) : lane == 0;
                 if (mine) {
                     const int col = q == 0 ? col0 : NP;
@@ -818,7 +883,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
                 for (int r = 0; r < m; ++r) acc += sQuu[ucol * ldm + r] * kk[r];
                 bcast_all<m>(acc, Qk);                                      // Qk[l] = (Quu^T k)[l], the same on every lane
-                while (__hip_atomic_load(&sOut[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
                 const int j = lane < n ? lane : 0;
                 double a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -846,51 +910,10 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             ILQR_SUB_MARK1(I, 3);
         } else wave_switch(wave, [&](auto Wc) {
             constexpr int W = decltype(Wc)::value;
-            if constexpr (W == 2) {
-                // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum; handed to the chain
-                // (wave 0) through the flag
-                constexpr int JP = (n + 3) / 4;
-                const int i = li < m ? li : m - 1;
-                double acc = 0.0;
-#pragma unroll
-                for (int q = 0; q < JP; ++q) {
-                    const int l = lk * JP + q;
-                    if ((n % 4 == 0) || l < n) acc += sFu[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
-                }
-                acc = sum_quarters(acc);
-                if (lane < m) sQu[lane] = acc + (STAGE ? sG[n + lane] : (double)A.gu[t * m + lane]);
-                wave_lds_fence();
-                if (lane == 0) __hip_atomic_store(&sOut[5], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (STORE_VALUE && Qv != nullptr && lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
-            }
-            if constexpr (W == 1) {
-                // Qx = fxᵀp′ + gx (:44-46): state i on lanes i and i + 32 (half of the sum each) when n <= 32
-                if constexpr (n <= 32) {
-                    constexpr int JP = (n + 1) / 2;
-                    const int i = (lane & 31) < n ? (lane & 31) : n - 1, h = lane >> 5;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int q = 0; q < JP; ++q) {
-                        const int l = h * JP + q;
-                        if ((n % 2 == 0) || l < n) acc += sFx[i * ld + (l < n ? l : 0)] * sp[l < n ? l : 0];
-                    }
-                    acc = sum_halves(acc);
-                    if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
-                } else {
-                    const int i = lane < n ? lane : n - 1;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < n; ++l) acc += sFx[i * ld + l] * sp[l];
-                    if (lane < n) sQx[lane] = acc + (STAGE ? sG[lane] : (double)A.gx[t * n + lane]);
-                }
-                wave_lds_fence();
-                if (lane == 0) __hip_atomic_store(&sOut[6], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (STORE_VALUE && Qv != nullptr && lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
-            }
             if constexpr (W > 0 && RS::tab.ct[W][0] >= 0) {     // what is left of T; a Qxx tile on another wave may wait for it
                 run_tiles(Wc, IntC<2>{});
                 wave_lds_fence();
-                if (lane == 0) __hip_atomic_store(&sOut[7], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(&sOut[4 + W], (double)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // Qxx = T fx + gxx (:53-54), written where P′ was (generic schedule: nobody reads P′ after window B) or to its own buffer
             // (TN = 2: a tile of T is still being formed from P′ in this window); the wave that stored a tile adds its gxx entries
@@ -898,8 +921,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 constexpr int s = decltype(Sc)::value, e = RS::tab.qxx[W][s];
                 if constexpr (e >= 0) {
                     constexpr int q = e & ~RS::RIC_WAIT_T, a = q / TN, c = q % TN;
-                    if constexpr ((e & RS::RIC_WAIT_T) != 0)
-                        while (__hip_atomic_load(&sOut[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
+                    if constexpr ((e & RS::RIC_WAIT_T) != 0) static_for<1, 4>([&](auto Vc) {
+                        constexpr int V = decltype(Vc)::value;
+                        if constexpr (V != W && RS::tab.ct[V][0] >= 0)
+                            while (__hip_atomic_load(&sOut[4 + V], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
+                    });
                     const double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
                     tile_store<ld>(sQ, acc, 16 * a, 16 * c, li, lk);
                     constexpr int xb = M::HESS_XX_TILE_START[q], xc = M::HESS_XX_TILE_START[q + 1] - xb;

@@ -78,7 +78,7 @@ constexpr __host__ __device__ int large_lds_base_doubles(int n, int m) {
     // 17 <= nx <= 32 (two tile rows): the hand-made schedule computes one tile of T while Qxx is being stored, so Qxx gets a
     // buffer of its own there (elsewhere it is written over P', which nobody reads any more by then)
     const int qxx = NP == 32 ? NP * ld : 0;
-    return 3 * NP * ld + MP * ld + (4 * NP + 2) * ldm + MP * ldm + LARGE_CHOL + 2 * NP + 8 + LAYOUT_LDS_DOUBLES + qxx;
+    return 3 * NP * ld + MP * ld + (4 * NP + 2) * ldm + 2 * MP * ldm + LARGE_CHOL + 2 * NP + 8 + LAYOUT_LDS_DOUBLES + qxx;
 }
 constexpr __host__ __device__ int large_stage_doubles(int n, int m, int hess_nnz) {
     const int want = pad2(pad2(hess_nnz > 0 ? hess_nnz : 1) + n + m);
