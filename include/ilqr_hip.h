@@ -202,14 +202,21 @@ int ilqr_scalar_slot(const char* name);
  * per wave, no horizon limit. All run the same arithmetic up to the association of a few sums. */
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);
 /* Straggler hand-over of the packed kernel (no counterpart in the reference, which is one trajectory per Solver): a batched
- * launch lasts as long as its slowest instance, and in the packed kernel a straggler keeps a whole wave at ~120 us per
- * iteration. An instance that is still unconverged when it ENTERS outer iteration `outer` of constrained_ilqr_solve!
- * (src/solve.jl:105) leaves the packed kernel at that boundary — duals, penalties and nominal trajectory are complete in its
- * workspace block — and a second launch on the same stream finishes exactly those instances with the latency kernel (two
- * waves per instance, state in LDS: ~65 us per iteration). The rule looks at the instance alone: results never depend on the
- * other instances of the batch; a handed-over instance follows the latency kernel's arithmetic from that boundary on (the two
- * kernels agree to rounding, both parity-tested). outer = -1: auto = max_dual_updates / 2 + 1 (default); 0: off; >= 2: as given. */
+ * launch lasts as long as its slowest instance, and in the packed kernel a straggler keeps a whole wave at 120-240 us per
+ * cycle (one line-search trial per cycle). Instances that leave the packed kernel do so with their state complete in the
+ * workspace block — at the start of an outer iteration of constrained_ilqr_solve! (src/solve.jl:105) or at the head of an
+ * inner iteration of ilqr_solve! (src/solve.jl:22), where the block holds the nominal trajectory, the linearisation, the
+ * accumulated Hessians, K, k and the loop's scalars — and a second launch on the same stream finishes exactly those with the
+ * latency kernel (two waves per instance, state in LDS: 50-75 us per iteration, a rejected trial one rollout instead of a
+ * cycle). The two kernels do the same arithmetic (trajectories, policies and duals bitwise: tests/test_gpu_parity.py), so
+ * which instances change kernels, and when, never shows in a result.
+ *   ilqr_set_handover(outer): -1 (default) = by head count, below; 0 = no hand-over; k >= 2 = an instance still unconverged
+ *     when it ENTERS outer iteration k leaves at that boundary.
+ *   ilqr_set_handover_live(live), used when outer = -1: once no more than `live` instances of the batch are still running,
+ *     every survivor leaves at its next resumable point. -1 auto = min(1024, batch / 4), what the latency kernel holds at full
+ *     speed; 0 off; n >= 1 as given. */
 int ilqr_set_handover(ilqr_handle* h, int32_t outer);
+int ilqr_set_handover_live(ilqr_handle* h, int32_t live);
 
 /* Per-iteration record of what the reference prints when `verbose` (src/solve.jl:40-45): for every
  * instance up to `capacity` rows of 8 doubles {outer, inner, objective, gradient_norm, max_violation,

@@ -281,8 +281,12 @@ class Solver:
         _ffi.check(_ffi.lib().ilqr_set_kernel_variant(self._h, int(v)))
 
     def set_handover_(self, outer):
-        """Straggler hand-over of the packed kernel (see ilqr_set_handover): -1 auto, 0 off, k >= 2 = instances entering outer iteration k."""
+        """Straggler hand-over of the packed kernel (see ilqr_set_handover): -1 auto (by head count), 0 off, k >= 2 = instances entering outer iteration k."""
         _ffi.check(_ffi.lib().ilqr_set_handover(self._h, int(outer)))
+
+    def set_handover_live_(self, live):
+        """Hand-over by head count (see ilqr_set_handover_live): -1 auto, 0 off, n = survivors of the batch at which they all leave."""
+        _ffi.check(_ffi.lib().ilqr_set_handover_live(self._h, int(live)))
 
     def enable_trace_(self, capacity):
         """Record per-iteration rows (what `verbose` prints in the reference) during solve_."""

@@ -106,7 +106,9 @@ struct ilqr_handle {
     double* d_u;   // staging for host-pointer initialize_rollout
     double* trace;
     int trace_cap;
-    int handover;         // straggler hand-over of the packed kernel: -1 auto, 0 off, k > 1 = instances entering outer iteration k
+    int handover;         // straggler hand-over of the packed kernel: -1 auto (by head count), 0 off, k > 1 = instances entering outer iteration k
+    int handover_live;    // head-count rule: survivors of the batch at which they all leave (-1 auto, 0 off)
+    int* done_counter;    // device counter of finished instances for that rule
     int variant;          // 0 auto, 1 latency kernel (all-LDS, 2 waves per instance), 2 throughput kernel (slim), 3 packed kernel (4 instances per wave, no LDS)
     bool lds_fits;        // the LDS-resident kernels can hold this horizon (otherwise only the packed kernel runs it)
     int num_simds;
@@ -133,7 +135,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.trace = h->trace; a.trace_cap = h->trace_cap;
     a.qv = h->qv; a.QL = h->QL;
     a.stage_param = 0.0; a.stage_flag = 0;
-    a.handover_outer = 0; a.resume = 0;
+    a.handover_outer = 0; a.resume = 0; a.handover_live = 0; a.done_counter = h->done_counter;
     return a;
 }
 
@@ -415,7 +417,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu, vt->hess_nnz) * 8
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
-    h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024; h->handover = -1;
+    h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024; h->handover = -1; h->handover_live = -1; h->done_counter = nullptr;
     h->qv = nullptr; h->QL = ilqr::make_qlayout(vt->nx, vt->nu, d->horizon); h->full_stale = false; h->P_dirty = false;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
@@ -441,6 +443,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     }
     h->ws_bytes = (size_t)h->B * (size_t)h->L.stride * 8;
     if ((e = hipMalloc((void**)&h->ws, h->ws_bytes)) != hipSuccess) return bail(e, "hipMalloc(workspace)");
+    if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->done_counter, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(hand-over counter)");
     if ((e = hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     *out = h;
     int rc = ilqr_reset(h);
@@ -457,7 +460,7 @@ int ilqr_create_sharded(const ilqr_problem_desc* d, const int32_t* devices, int3
     if (d->horizon < 2 || d->batch < 1) return fail(ILQR_ERR_INVALID, "horizon must be >= 2 and batch >= 1");
     if (n_devices > d->batch) return fail(ILQR_ERR_INVALID, "more devices than instances");
     ilqr_handle* h = new ilqr_handle();
-    h->vt = nullptr; h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr; h->trace = nullptr; h->qv = nullptr;
+    h->vt = nullptr; h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr; h->trace = nullptr; h->qv = nullptr; h->done_counter = nullptr;
     h->B = d->batch; h->device = devices[0]; h->constrained = d->constrained ? 1 : 0; h->trace_cap = 0; h->variant = 0;
     const int per = (d->batch + n_devices - 1) / n_devices;
     for (int i = 0, lo = 0; i < n_devices && lo < d->batch; ++i, lo += per) {
@@ -490,6 +493,7 @@ int ilqr_destroy(ilqr_handle* h) {
     for (auto& p : h->timing) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->ws) hipFree(h->ws);
     if (h->d_x1) hipFree(h->d_x1);
+    if (h->done_counter) hipFree(h->done_counter);
     if (h->d_u) hipFree(h->d_u);
     if (h->trace) hipFree(h->trace);
     if (h->qv) hipFree(h->qv);
@@ -613,18 +617,27 @@ int ilqr_solve(ilqr_handle* h) {
                       (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
     if (!packed && !h->lds_fits) return drop(fail(ILQR_ERR_LDS, "this horizon only runs on the packed kernel"));
     if (packed) {
-        // straggler hand-over: instances still unconverged when they enter outer iteration k leave the packed kernel at that
-        // boundary and are finished by the latency kernel (two waves per instance, LDS-resident state: about half the time per
-        // iteration when few instances are left). The rule looks at the instance alone, so a result never depends on which
-        // other instances share the batch. auto: k = max_dual_updates / 2 + 1 (6 with the reference's default of 10).
-        int ho = h->handover < 0 ? h->opt.max_dual_updates / 2 + 1 : h->handover;
-        if (!h->constrained || !h->lds_fits || ho < 2 || ho > h->opt.max_dual_updates) ho = 0;
-        a.handover_outer = ho;
+        // straggler hand-over: the survivors of a batch leave the packed kernel and are finished by the latency kernel (two waves
+        // per instance, LDS-resident state; a rejected line-search trial costs it one rollout where it costs the packed kernel a
+        // whole cycle of the wave) in a launch that follows on the stream. By head count (the default) — once no more than `live`
+        // instances of the batch are still running, each of them leaves at the next head of an inner or outer iteration;
+        // auto: live = min(1024, B / 4), what the latency kernel holds at full speed. By outer iteration (ilqr_set_handover(k >= 2))
+        // — an instance entering outer iteration k leaves at that boundary. Both kernels do the same arithmetic, so which
+        // instances change kernels, and when, never shows in a result.
+        // (Measured and dropped: a pool of latency workgroups BESIDE the packed kernel taking leavers from a device queue — at
+        // 8192 instances the packed kernel's 2048 waves fill every CU, a pool workgroup only starts once they retire)
+        int ho = h->handover < 0 ? 0 : h->handover;
+        int live = h->handover < 0 ? (h->handover_live < 0 ? std::min(1024, h->B / 4) : h->handover_live) : 0;
+        const bool can = h->constrained && h->lds_fits && h->done_counter != nullptr;
+        if (!can || ho < 2 || ho > h->opt.max_dual_updates) ho = 0;
+        if (!can) live = 0;
+        a.handover_outer = ho; a.handover_live = live;
+        if (live > 0) HIP_TRY(hipMemsetAsync(h->done_counter, 0, sizeof(int), h->stream));
 #ifdef ILQR_PK_DEBUG_HOOK      // phase-timing hook of tools/packed_phases.py (see ilqr_device_packed.hpp); never compiled into the product library
         if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);
 #endif
         if (h->vt->launch_solve_packed(&a, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (packed variant) launch failed"));
-        if (ho > 0) {
+        if (ho > 0 || live > 0) {
             ilqr::KArgs r = a;
             r.resume = 1; r.stage = 0;
             if (h->vt->launch_solve(&r, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (hand-over resume) launch failed"));
@@ -795,6 +808,13 @@ int ilqr_set_handover(ilqr_handle* h, int32_t outer) {
     if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_handover(s, outer); });
     if (!h || outer < -1 || outer == 1) return fail(ILQR_ERR_INVALID, "hand-over: -1 (auto), 0 (off) or the outer iteration (>= 2) from which stragglers leave the packed kernel");
     h->handover = outer;
+    return ILQR_OK;
+}
+
+int ilqr_set_handover_live(ilqr_handle* h, int32_t live) {
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_handover_live(s, live); });
+    if (!h || live < -1) return fail(ILQR_ERR_INVALID, "hand-over by head count: -1 (auto), 0 (off) or the number of surviving instances at which they leave the packed kernel");
+    h->handover_live = live;
     return ILQR_OK;
 }
 

@@ -55,6 +55,12 @@ struct KArgs {
     // resume = 1 picks up exactly the instances so marked (S_RESUME) and finishes them with two waves and LDS-resident state each.
     int handover_outer;
     int resume;
+    // ... and by head count: once no more than handover_live instances of the batch are still running (done_counter, zeroed by
+    // the host before the launch, counts the finished ones), every survivor leaves at its next resumable point — the start of
+    // an outer iteration, or the start of inner iteration S_INNER_IT of one (S_OBJ_PREV carries the loop's previous objective;
+    // the linearisation, the accumulated Hessians, K and k are in the workspace block). 0 = off.
+    int handover_live;
+    int* done_counter;
 };
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
@@ -1442,8 +1448,9 @@ __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
 //   al_outer = true : AL outer loop (Solver with constraints)
 //   al_outer = false: a single ilqr_solve! (plain Objective, or the stage test)
 template <class M, bool STORE_VALUE>
-__device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constrained, bool al_outer, int o_start = 1) {
-    if (al_outer && o_start == 1) {
+__device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constrained, bool al_outer, int o_start = 1, int it_start = 0,
+                            double obj_prev0 = 0.0) {
+    if (al_outer && o_start == 1 && it_start == 0) {
         // reset!(solver.data) (:93, src/data/solver.jl:49-59); λ ← 0, ρ ← ρ0 (:96-103)
         I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
         for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
@@ -1459,12 +1466,16 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
     for (int o = o_start; o <= outer_max; ++o) {                      // src/solve.jl:105 (o_start > 1: resumed after a hand-over)
         if (al_outer) I.outer_iterations = o;
         // ---------------- ilqr_solve! (src/solve.jl:1-54)
-        reset_model_objective<M>(I, false);                           // (:9-10)
-        if (opt.reset_cache) {                                        // (:12) reset!(data)
-            I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0;
+        // (resumed inside an inner solve, it_start >= 1: the workspace block holds the loop's state at the head of that iteration)
+        const bool mid = it_start > 0 && o == o_start;
+        if (!mid) {
+            reset_model_objective<M>(I, false);                       // (:9-10)
+            if (opt.reset_cache) {                                    // (:12) reset!(data)
+                I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0;
+            }
         }
-        double obj_prev = 0.0;
-        for (int it = 0; it <= opt.max_iterations; ++it) {            // it = 0: (:14-21); it ≥ 1: (:22-51)
+        double obj_prev = mid ? obj_prev0 : 0.0;
+        for (int it = mid ? it_start : 0; it <= opt.max_iterations; ++it) {     // it = 0: (:14-21); it ≥ 1: (:22-51)
             if (it == 0) cost_bang<M>(I, false, constrained);         // (:14)
             else forward_pass<M>(I, opt, constrained);                // (:23)
             if (it == 0 || opt.line_search != 0) {                    // (:16-18), (:27-33)
@@ -1562,24 +1573,25 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
     }
 }
 
-// solve!(solver) for every instance — src/solve.jl:137-143
-template <class M>
-__global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x;
-    if (b >= a.B) return;
-    int o_start = 1;
-    if (a.resume) {                       // second launch after the packed kernel: only the instances it handed over
-        o_start = (int)(a.ws + (size_t)b * (size_t)a.L.stride)[a.L.scal + S_RESUME];
-        if (o_start < 2) return;
+// one instance from its workspace block to the end of solve!: from the start, or (resumed) from where the packed kernel left it
+template <class M, bool RESUMED>
+__device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int b) {
+    constexpr bool resumed = RESUMED;
+    int o_start = 1, it_start = 0;
+    double obj_prev0 = 0.0;
+    if constexpr (RESUMED) {
+        const double* sc = a.ws + (size_t)b * (size_t)a.L.stride + a.L.scal;
+        o_start = (int)sc[S_RESUME];
+        it_start = (int)sc[S_INNER_IT];
+        obj_prev0 = sc[S_OBJ_PREV];
     }
     Inst<M> I;
     inst_setup<M>(I, a, smem, b);
-    if (o_start == 1) { I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0; }
+    if (!resumed) { I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0; }
     else I.trace_len = (int)I.scal[S_TRACE_LEN];
     {
         ILQR_PROF_BEGIN();
-        solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0, o_start);
+        solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0, o_start, it_start, obj_prev0);
         ILQR_PROF_END(I, PROF_OTHER);   // total; phases are subtracted on the host
     }
     if (I.lane == 0 && I.wave == 0) {
@@ -1587,6 +1599,27 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs
         I.scal[S_RESUME] = 0.0;
     }
     inst_writeback<M>(I, a, smem, b);
+}
+
+// solve!(solver) for every instance — src/solve.jl:137-143
+template <class M>
+__global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    solve_instance<M, false>(a, smem, b);
+}
+
+// The same for the instances the packed kernel handed over, in the launch that follows it on the stream: workgroup b finishes
+// instance b if it was marked (S_RESUME). A kernel of its own: the entry inside an inner solve costs registers the plain kernel
+// does not have to spare.
+template <class M>
+__global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel_resume(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    if ((int)(a.ws + (size_t)b * (size_t)a.L.stride)[a.L.scal + S_RESUME] < 1) return;
+    solve_instance<M, true>(a, smem, b);
 }
 
 // throughput variant: two waves per SIMD (<= 256 registers), Jacobians in HBM (see Slim<M>)
@@ -1782,7 +1815,7 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 6   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+#define ILQR_MODEL_ABI_VERSION 7   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against
@@ -1810,6 +1843,15 @@ struct ModelModule {
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<M>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if constexpr (packed_ok<M>::value) {         // hand-over exists where the packed kernel does
+            if (a->resume) {
+                if (lds > 64 * 1024 &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel_resume<M>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+                hipLaunchKernelGGL(solve_kernel_resume<M>, dim3(a->B), dim3(64 * waves_of<M>::value), lds, (hipStream_t)stream, *a);
+                return hipGetLastError() == hipSuccess ? 0 : -1;
+            }
+        }
         hipLaunchKernelGGL(solve_kernel<M>, dim3(a->B), dim3(64 * waves_of<M>::value), lds, (hipStream_t)stream, *a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }

@@ -682,7 +682,22 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
         I.outer = 1;
     }
     I.state = live ? ST_INIT : ST_DONE;
-    int resume = 0;
+    int resume = 0, resume_it = 0;
+    double resume_obj_prev = 0.0;
+    // hand-over by head count (KArgs::handover_live): this wave's finished instances are added to the batch-wide counter at the
+    // head of every cycle; once the survivors of the whole batch are few enough, every one of them leaves at its next resumable point
+    int n_prev = __popcll(__ballot(live && I.j == 0));
+    bool ho_now = false;
+    auto write_scalars = [&]() {
+        scal[S_OBJECTIVE] = I.objective; scal[S_MAX_VIOLATION] = I.max_violation;
+        scal[S_STEP_SIZE] = I.step_size; scal[S_GRADIENT_NORM] = I.gradient_norm;
+        scal[S_STATUS] = (double)I.status; scal[S_ITERATIONS] = (double)I.iterations;
+        scal[S_OUTER_ITERATIONS] = (double)(al_outer ? I.outer : 0); scal[S_POTRF_INFO] = (double)I.potrf_info;
+        scal[S_ROLLOUTS] = (double)I.rollouts; scal[S_STATES_EQ_NOMINAL] = (double)I.states_eq_nominal;
+        scal[S_DELTA] = I.delta;
+        scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
+        scal[S_RESUME] = (double)resume; scal[S_INNER_IT] = (double)resume_it; scal[S_OBJ_PREV] = resume_obj_prev;
+    };
     __syncthreads();
     const int outer_max = al_outer ? opt.max_dual_updates : 1;
     if (outer_max < 1) I.state = ST_DONE;
@@ -696,6 +711,13 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
         if (dbg & 1) {
             if (dbg_cycles++ >= opt.max_iterations) break;
             if (live && dbg_cycles > 1) { I.state = ST_FORWARD; I.trial = 1; I.needB = 0; I.it = 1; }
+        }
+        if (a.handover_live > 0 && !ho_now && al_outer) {
+            const int n_now = __popcll(__ballot(I.state != ST_DONE && I.j == 0));
+            if (n_now < n_prev && (threadIdx.x & 63) == 0) atomicAdd(a.done_counter, n_prev - n_now);
+            n_prev = n_now;
+            const int done = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            ho_now = a.B - done <= a.handover_live;
         }
         // ------------------------------------------------ A: outer-loop transitions (src/solve.jl:105-126) and ilqr_solve! entry (:9-18)
         {
@@ -723,7 +745,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                     I.outer += 1;
                     // straggler hand-over: this instance's workspace block is complete at the boundary (duals and penalties
                     // updated, nominal trajectory in place); it leaves for the latency kernel's resume launch
-                    if (a.handover_outer > 1 && I.outer >= a.handover_outer) { I.state = ST_DONE; resume = I.outer; }
+                    if ((a.handover_outer > 1 && I.outer >= a.handover_outer) || ho_now) { I.state = ST_DONE; resume = I.outer; }
                     else I.state = ST_INIT;
                 }
                 __syncthreads();
@@ -813,6 +835,12 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                 if (end_inner) I.state = al_outer ? ST_OUTER : ST_DONE;
                 else { I.it += 1; I.trial = 1; I.state = ST_FORWARD; }
                 I.leaving = end_inner ? 1 : 0;
+                if (!end_inner && al_outer && ho_now) {
+                    // hand-over inside the inner solve, at the head of iteration I.it: the block holds the nominal trajectory, K, k,
+                    // the accumulated Hessians and (written out below like at the end of an inner solve) this linearisation
+                    resume = I.outer; resume_it = I.it; resume_obj_prev = I.obj_prev;
+                    I.state = ST_DONE; I.leaving = 1;
+                }
             }
             if (__any(I.leaving != 0)) {       // write the last linearisation of the inner solve out (terminal gx[N] is already there)
                 if (I.leaving) {
@@ -826,17 +854,9 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
             }
         }
     }
+    if (a.handover_live > 0 && !ho_now && al_outer && n_prev > 0 && (threadIdx.x & 63) == 0) atomicAdd(a.done_counter, n_prev);
     __syncthreads();
-    if (live && I.j == 0) {
-        scal[S_OBJECTIVE] = I.objective; scal[S_MAX_VIOLATION] = I.max_violation;
-        scal[S_STEP_SIZE] = I.step_size; scal[S_GRADIENT_NORM] = I.gradient_norm;
-        scal[S_STATUS] = (double)I.status; scal[S_ITERATIONS] = (double)I.iterations;
-        scal[S_OUTER_ITERATIONS] = (double)(al_outer ? I.outer : 0); scal[S_POTRF_INFO] = (double)I.potrf_info;
-        scal[S_ROLLOUTS] = (double)I.rollouts; scal[S_STATES_EQ_NOMINAL] = (double)I.states_eq_nominal;
-        scal[S_DELTA] = I.delta;
-        scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
-        scal[S_RESUME] = (double)resume;
-    }
+    if (live && I.j == 0) write_scalars();
 }
 
 }  // namespace ilqr

@@ -1178,6 +1178,38 @@ def test_straggler_handover_from_the_packed_to_the_latency_kernel(pkg, oracle, c
     assert np.abs(on["x"] - ref["x"])[same].max() < 1e-7
 
 
+@pytest.mark.parametrize("config,B,live", [("acrobot51", 45, 30), ("acrobot51", 45, 44), ("car", 37, 20), ("particle", 9, 8), ("acrobot", 300, 150)])
+def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live):
+    """ilqr_set_handover_live: once no more than `live` instances of the batch are still running, each survivor leaves the packed
+    kernel at the head of its next inner or outer iteration and the latency kernel finishes it in a launch behind it. WHICH
+    instances leave, and where, depends on the timing of the run — so nothing may depend on it: counts, trace rows and every
+    array must be those of the packed kernel alone, bitwise (the two kernels do the same arithmetic; only the REPORTED
+    objective of a trace row is summed in another order: one ulp), run after run."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+
+    def run(on):
+        s = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(config, {})))
+        s.set_kernel_variant_("packed"); s.set_handover_(-1 if on else 0); s.set_handover_live_(live); s.enable_trace_(900)
+        s.initialize_rollout_(x1, ub); s.solve_()
+        out = dict(x=s.get_trajectory()[0], u=s.get_trajectory()[1], K=s.get_policy()[0], k=s.get_policy()[1], st=s.stats(),
+                   tl=s.scalar("trace_len"), tr=s.trace(), resume=s.scalar("resume"), lam=s.buffer("constraint_dual"),
+                   fx=s.buffer("jacobian_state"), gxx=s.buffer("hessian_state_state"))
+        s.close()
+        return out
+    off = run(False)
+    for rep in range(3):
+        on = run(True)
+        assert (on["resume"] == 0).all()
+        for k in ("iterations", "outer_iterations", "rollouts", "status", "potrf_info"):
+            assert np.array_equal(off["st"][k], on["st"][k]), k
+        assert np.array_equal(off["tl"], on["tl"])
+        cols = [0, 1, 3, 4, 5, 6, 7]
+        assert np.array_equal(off["tr"][:, :, cols], on["tr"][:, :, cols], equal_nan=True)
+        assert np.allclose(off["tr"][:, :, 2], on["tr"][:, :, 2], rtol=1e-14, atol=0, equal_nan=True)
+        for k in ("x", "u", "K", "k", "lam", "fx", "gxx"):
+            assert np.array_equal(off[k], on[k], equal_nan=True), k
+
+
 def test_c_callables_define_a_large_path_model(pkg, oracle, tmp_path):
     """ilqr_compile_model beyond nx, nu <= 4 (src/dynamics.jl:55-60, src/costs.jl:1-15, src/constraints.jl:54-64 accept any
     size): the synth12 callables of examples/synth12_model.c as C source -> AdaptedLargeModel (compact forms, every entry
