@@ -728,7 +728,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
         ILQR_SUB_BEGIN();
         const int tn = t > 0 ? t - 1 : 0;                                 // (t = 0: a harmless re-read instead of a branch)
-        // operands of the NEXT step, requested now
+        // operands of the NEXT step, requested now (issuing them in the shadow of the window's first tile instead was measured:
+        // the window got 450 clk longer)
         if (STAGE) stage_load(tn, rval);
 #pragma unroll
         for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)tn * JVP + (tid - 64) + NS * j] : 0.0;
@@ -951,8 +952,20 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         // ------------------------------------------------ window D: P (:79-84) | p, ∇L (:86-89, src/solve.jl:73-81); next step's Jacobian entries
         // P = K^T ux_tmp + K^T Qux + Qux^T K + Qxx   (:81-84), accumulated in this order, on one tile per wave when nx <= 32; ux_tmp = Quu K (:79) comes out of its MFMAs in exactly the layout the next MFMA's B operand wants
         // (k = lane>>4 + 4 reg, j = lane&15). All fragments of a tile are read first, then its eight MFMAs issue back to back.
+        // The next step's operands go into LDS (they were requested in window A; nobody reads their places in this window) in the
+        // shadow of the wave's first P tile, by the threads that requested them.
+        // (unconditional: at t = 0 it rewrites step 0's own values, and the loads must be consumed on every path through the loop —
+        // a path that skipped them would leave them pending at the loop edge and every iteration would start by waiting)
+        auto place_next = [&]() {
+#pragma unroll
+            for (int j = 0; j < EJ; ++j)
+                if (poff[j] >= 0) S[poff[j]] = pval[j];
+            if (STAGE) stage_store(rval);
+        };
         wave_switch(wave, [&](auto Wc) { static_for<0, SLOTS>([&](auto Sc) {
             constexpr int q = RS::tab.p[decltype(Wc)::value][decltype(Sc)::value];
+            constexpr bool first = decltype(Sc)::value == 0;
+            if constexpr (q < 0 && first) place_next();
             if constexpr (q >= 0) {
                 constexpr int KS = m4 / 4;
                 constexpr int a = q / TN, c = q % TN;
@@ -978,6 +991,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 for (int sx = 0; sx < KS; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fKa[sx], fQc[sx], acc, 0, 0, 0);
 #pragma unroll
                 for (int sx = 0; sx < KS; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fQa[sx], fKc[sx], acc, 0, 0, 0);
+                if constexpr (first) place_next();
                 const double4_t v = acc + qxx;
                 tile_store<ld>(sP, v, 16 * a, 16 * c, li, lk);
                 if (STORE_VALUE) {
@@ -989,14 +1003,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
             }
         }); });
-        // the next step's operands into LDS, by the threads that requested them (waits for the loads requested at the top of the step;
-        // placed here so that the acknowledgements of wave 0's K, k stores are not waited for as well) ...
-        // (unconditional: at t = 0 it rewrites step 0's own values, and the loads must be consumed on every path through the loop —
-        // a path that skipped them would leave them pending at the loop edge and every iteration would start by waiting)
-#pragma unroll
-        for (int j = 0; j < EJ; ++j)
-            if (poff[j] >= 0) S[poff[j]] = pval[j];
-        if (STAGE) stage_store(rval);
         if (wave == 0 && lane < n) sp[lane] = pn;                         // p' of the next step (its readers of this step are past B3)
         __syncthreads();                                                  // (B0) P′, p′, patched fx, fu visible
         ILQR_SUB_MARK1(I, 5); ILQR_SUB_MARK2(I, 5);
