@@ -692,14 +692,20 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #pragma unroll
     for (int j = 0; j < EJ; ++j) pval[j] = 0.0;
     // (one load per element through a selected ADDRESS: selecting among three loaded values would need them at once)
-    const long gx_rel = A.gx - A.hc, gu_rel = A.gu - A.hc;                // the three arrays sit in the same instance block
+    // element e of a thread is element (rstride t + rbase) of the instance block, counted from hc (the three arrays sit in the same
+    // block): stride and base are fixed per thread, so a step's address is one multiply-add
+    int rbase[ER], rstride[ER];
+#pragma unroll
+    for (int j = 0; j < ER; ++j) {
+        const int e = (tid - 64) + NS * j;
+        const int gx_rel = (int)(A.gx - A.hc), gu_rel = (int)(A.gu - A.hc);
+        rstride[j] = e < HSP ? HSP : (e < HSP + n ? n : m);
+        rbase[j] = e < HSP ? e : (e < HSP + n ? gx_rel + (e - HSP) : gu_rel + (e - HSP - n));
+        if (!(tid >= 64 && e < HSP + NG)) rstride[j] = 0;                  // (0 = no element; bases may be negative: gx, gu lie before hc)
+    }
     auto stage_load = [&](int t, double (&R)[ER]) {
 #pragma unroll
-        for (int j = 0; j < ER; ++j) {
-            const int e = (tid - 64) + NS * j;
-            const long off = e < HSP ? (long)t * HSP + e : (e < HSP + n ? gx_rel + t * n + (e - HSP) : gu_rel + t * m + (e - HSP - n));
-            R[j] = (tid >= 64 && e < HSP + NG) ? (double)A.hc[off] : 0.0;
-        }
+        for (int j = 0; j < ER; ++j) R[j] = rstride[j] > 0 ? (double)A.hc[t * rstride[j] + rbase[j]] : 0.0;
     };
     // where a staged element goes: the gxx entries and the gradients into the staging row; the guu / gux entries into dense
     // matrices Guu, Gux (zero elsewhere, for good: the same positions are rewritten every step) that the waves forming Quu / Qux
@@ -730,9 +736,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         const int tn = t > 0 ? t - 1 : 0;                                 // (t = 0: a harmless re-read instead of a branch)
         // operands of the NEXT step, requested now (issuing them in the shadow of the window's first tile instead was measured:
         // the window got 450 clk longer)
-        if (STAGE) stage_load(tn, rval);
+        if (wave != 0) {                                                  // (wave 0 requests nothing: a scalar branch past it all)
+            if (STAGE) stage_load(tn, rval);
 #pragma unroll
-        for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)tn * JVP + (tid - 64) + NS * j] : 0.0;
+            for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[tn * JVP + (tid - 64) + NS * j] : 0.0;
+        }
         // ------------------------------------------------ window A: ûx = fuᵀP′ (:57) | T = fxᵀP′ (:52)
         auto run_tiles = [&](auto Wc, auto WINc) {                        // window WIN's tasks of wave W, all compile-time
             constexpr int W = decltype(Wc)::value, WIN = decltype(WINc)::value;
