@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profile capture on the GPU box (run through gpurun): kernel trace + separate PMC passes, as MI355X_MICROARCH.md prescribes
-# (no --pmc together with other trace domains). Outputs under gpurun_out/$1; copy the summary into profiles/.
+# (no --pmc together with other trace domains). The profiled command is bench.py's timed loop alone (--no-secondary: the default
+# run's extra figures launch the same kernel two at a time, which would enter the per-kernel average). Outputs under gpurun_out/$1; copy the summary into profiles/.
 #   tools/capture_profiles.sh <tag> <config> <batch> [variant]
 set -u
 TAG=${1:-prof_final}
@@ -11,8 +12,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-ARGS="bench.py --config $CFG --batch $B --variant $VAR --steps 4 --warmup 2 --no-cpu-baseline --no-pmc"
-SHORT="bench.py --config $CFG --batch $B --variant $VAR --steps 2 --warmup 1 --no-cpu-baseline --no-pmc"
+ARGS="bench.py --config $CFG --batch $B --variant $VAR --steps 4 --warmup 2 --no-cpu-baseline --no-pmc --no-secondary"
+SHORT="bench.py --config $CFG --batch $B --variant $VAR --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-secondary"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o r1 -- python3 $ARGS > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o r1 -- python3 $SHORT > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o r1 -- python3 $SHORT > $OUT/write.log 2>&1
