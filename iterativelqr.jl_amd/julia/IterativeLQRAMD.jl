@@ -11,7 +11,7 @@
 module IterativeLQRAMD
 
 export Options, Solver, Dynamics, Cost, Constraint, initialize_controls!, initialize_states!, initialize_rollout!,
-       set_parameters!, solve!, get_trajectory, get_policy, stats, set_kernel_variant!, enable_trace!, trace
+       set_parameters!, solve!, get_trajectory, get_policy, stats, set_kernel_variant!, set_handover!, set_handover_live!, enable_trace!, trace
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "lib", "libilqr_hip.so"))
 
@@ -286,6 +286,10 @@ end
 
 # 0 = auto, 1 = latency, 2 = throughput, 3 = packed (four instances per wave, no horizon limit)
 set_kernel_variant!(s::Solver, v::Integer) = check(ccall((:ilqr_set_kernel_variant, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, v))
+# straggler hand-over of the packed kernel (include/ilqr_hip.h): outer = -1 by head count (default), 0 off, k >= 2 by outer iteration;
+# live = survivors of the batch at which they all leave (-1 auto)
+set_handover!(s::Solver, outer::Integer) = check(ccall((:ilqr_set_handover, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, outer))
+set_handover_live!(s::Solver, live::Integer) = check(ccall((:ilqr_set_handover_live, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, live))
 
 # what `verbose` prints per inner iteration (src/solve.jl:40-45), recorded on the device: rows of
 # (outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts) per instance
