@@ -253,24 +253,36 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
     const LargeArgs A = large_args_from_lds<M>(base);
     constrained = __builtin_amdgcn_readfirstlane(constrained);
     const int tid = threadIdx.x, T = A.T, N = A.N;
-    for (int t = tid; t < T; t += NT) {                                  // Hessians accumulate: each timestep exactly once
+    // A timestep's linearisation is one long serial instruction stream per thread (4.4 k instructions for synth32), so it is cut in
+    // two along its function boundaries: waves 0, 1 evaluate the state-dependent Jacobian entries of timestep t, waves 2, 3 the
+    // cost gradients, the accumulated Hessian row and the Gauss-Newton AL terms of the same t (wave-uniform roles: no divergence;
+    // both halves read x̄_t, ū_t). Hessians accumulate: each timestep exactly once per half.
+    constexpr int NH = NT / 2;
+    const int half = __builtin_amdgcn_readfirstlane(tid / NH);
+    for (int t = tid % NH; t < T; t += NH) {
         double w[cdim<M::NW>::v];
         load_w<M::NW>((const double*)A.w, t, w);
         double xt[n];
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = A.xb[t * n + i];
-        double* hrow = (double*)(A.hc + (size_t)t * LD::HSP);
-        if (t < N) {
-            double ut[m];
+        if (half == 0) {
+            if (t < N) {
+                double ut[m];
 #pragma unroll
-            for (int i = 0; i < m; ++i) ut[i] = A.ub[t * m + i];
-            {
+                for (int i = 0; i < m; ++i) ut[i] = A.ub[t * m + i];
                 double v[cdim<LD::JV>::v];
                 v[0] = 0.0;
                 M::dyn_jac_var(xt, ut, w, v);
 #pragma unroll
                 for (int q = 0; q < LD::JV; ++q) A.fv[(size_t)t * LD::JVP + q] = v[q];
             }
+            continue;
+        }
+        double* hrow = (double*)(A.hc + (size_t)t * LD::HSP);
+        if (t < N) {
+            double ut[m];
+#pragma unroll
+            for (int i = 0; i < m; ++i) ut[i] = A.ub[t * m + i];
             double gx[n], gu[m];
             M::cost_s_grad(xt, ut, w, gx, gu);
             M::cost_s_hess_c(xt, ut, w, hrow);
