@@ -1801,7 +1801,10 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
         if (lane < m) { su[lane] = ul; g[L.ub + t * m + lane] = ul; }
         wave_lds_fence();
         const double u_next = (lane < m && t + 1 < N) ? a.u_in[((size_t)b * N + t + 1) * m + lane] : 0.0;
-        const double y = dyn_row<M>(aff, sx, su, xl, lane, g + L.w, t);
+        double ua[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) ua[j] = su[j];
+        const double y = dyn_row<M>(aff, sx, ua, xl, lane, g + L.w, t);
         xl = y;
         ul = u_next;
         if (lane < n) g[L.xb + (t + 1) * n + lane] = y;

@@ -598,7 +598,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     typedef LargeDims<M> LD;
     constexpr int n = M::NX, m = M::NU, NP = LD::NP, ld = LD::ld, ldm = LD::ldm, TN = LD::TN, NT = LD::NT;
     constexpr int n4 = LD::n4, m4 = LD::m4, JV = LD::JV, JVP = LD::JVP, HXX = LD::HXX, HUU = LD::HUU, HUX = LD::HUX, HSP = LD::HSP;
-    constexpr int NQ = TN * TN;                            // tiles of T, Qxx, P
     constexpr int NS = NT - 64;                            // threads that fetch the next step's operands: waves 1..3 (wave 0 only stores)
     constexpr int EJ = (JV + NS - 1) / NS > 0 ? (JV + NS - 1) / NS : 1;            // Jacobian patch entries per fetching thread
     constexpr int EU = (HUU + HUX + 63) / 64 > 0 ? (HUU + HUX + 63) / 64 : 1;      // guu / gux entries per lane of wave 0
@@ -620,7 +619,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *sP = S + LD::oP, *sT = S + LD::oT, *sUh = S + LD::oUh, *sQux = S + LD::oQux,
            *sK = S + LD::oK, *sGux = S + LD::oGux, *sQuu = S + LD::oQuu, *sGuu = S + LD::oGuu;
     double *sp = S + LD::oVec, *sQx = sp + NP, *sOut = sQx + NP;
-    double *sQu = sQux + NP * ldm, *sk = sK + NP * ldm;              // Qu and k ride along as column NP of Qux and K
+    double* sQu = sQux + NP * ldm;                                   // Qu and k ride along as column NP of Qux and K
     double* sU = S + LD::oChol;                                            // the Cholesky factor, column c at sU + c m
     constexpr int oQ = LD::QXB > 0 ? LD::oQxx : LD::oP;                    // where Qxx waits for P: its own buffer or P′'s place
     double* sQ = S + oQ;
@@ -1076,12 +1075,9 @@ __device__ __forceinline__ double kx_partial(const double* Kt, const double* xv,
 // row `lane` of x⁺ = f(x, u) (src/rollout.jl:29): affine part from the lane's coefficient row, remainder either elementwise on
 // the lane's own component (M::dyn_rem_own) or through the generated wave-cooperative code
 template <class M>
-__device__ __forceinline__ double dyn_row(const double (&aff)[M::NX + M::NU + 1], const double* sx, const double* su, double xl, int lane,
+__device__ __forceinline__ double dyn_row(const double (&aff)[M::NX + M::NU + 1], const double* sx, const double (&ua)[M::NU], double xl, int lane,
                                           const double* W, int t) {
     constexpr int n = M::NX, m = M::NU;
-    double ua[m];
-#pragma unroll
-    for (int j = 0; j < m; ++j) ua[j] = su[j];
     // four interleaved partial sums: a dependent fp64 FMA chain advances one link per ~8 clk on a lone wave, forty links in a
     // row were a third of the rollout step
     double y4[4] = {aff[n + m], 0.0, 0.0, 0.0};
@@ -1113,18 +1109,18 @@ __device__ __forceinline__ double dyn_row(const double (&aff)[M::NX + M::NU + 1]
 template <class M>
 __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
     typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, NP = LD::NP, CH = LD::CH, KN = m * n;
+    constexpr int n = M::NX, m = M::NU, CH = LD::CH, KN = m * n;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, N = A.N;
-    double *sx = lds_dyn + LD::oFw, *su = sx + NP, *ring = lds_dyn + LD::oRing;
+    double *sx = lds_dyn + LD::oFw, *ring = lds_dyn + LD::oRing;
     const int row = lane < n ? lane : n - 1;
     double aff[n + m + 1];
 #pragma unroll
     for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
     double xl = lane < n ? A.xb[lane] : 0.0;                                  // x[1] = x̄[1]  (:19)
     if (lane < n) A.x[lane] = xl;
-    const int ui = lane < m ? lane : 0;
+    const int ui = li < m ? li : 0;                                           // (every row of 16 lanes forms the same m actions)
     for (int c0 = 0; c0 < N; c0 += CH) {
         const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
         for (int t = c0; t < c1; ++t) {
@@ -1136,9 +1132,12 @@ __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
             double v = a_t;                                                   // α k + ū   (:24-26)
             v += acc;                                                         // + K x      (:27)
             v += -1.0 * b_t;                                                  // − K x̄     (:28)
-            if (lane < m) { su[lane] = v; A.u[t * m + lane] = v; }
-            wave_lds_fence();
-            const double y = dyn_row<M>(aff, sx, su, xl, lane, (const double*)A.w, t);      // (:29)
+            if (lane < m) A.u[t * m + lane] = v;
+            // action i sits on lane i of every 16-lane row (the quarter sums leave four identical rows): the row's lanes get all of
+            // u by one DPP row broadcast each — no LDS round trip between the feedback term and the dynamics
+            double ua[m];
+            bcast_all<m>(v, ua);
+            const double y = dyn_row<M>(aff, sx, ua, xl, lane, (const double*)A.w, t);      // (:29)
             xl = y;
             if (lane < n) A.x[(t + 1) * n + lane] = y;
             wave_lds_fence();
@@ -1152,16 +1151,16 @@ __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
 template <class M>
 __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
     typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, CH = LD::CH, KN = m * n, JV = LD::JV, JVP = LD::JVP;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, CH = LD::CH, JV = LD::JV, JVP = LD::JVP;
     constexpr int EJ = (JV + 63) / 64 > 0 ? (JV + 63) / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, N = A.N;
     double* S = lds_dyn;
-    double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *zx = S + LD::oFw + NP + MP, *zu = zx + NP, *ring = S + LD::oRing;
+    double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *zx = S + LD::oFw + NP + MP, *ring = S + LD::oRing;
     int poff[EJ];
     double pval[EJ], dpart = 0.0, kv = 0.0, Luv = 0.0, Lxv = 0.0;
-    const int ui = lane < m ? lane : m - 1, xi = lane < n ? lane : n - 1;
+    const int ui = li < m ? li : m - 1, xi = lane < n ? lane : n - 1;         // (every row of 16 lanes forms the same m Δu)
 #pragma unroll
     for (int j = 0; j < EJ; ++j) {
         const int q = lane + 64 * j;
@@ -1192,16 +1191,18 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
             const double acc = kx_partial<M>(Kt, zx, li, lk);
             const double du = kv + acc;
             const double zown = zx[xi];
-            if (lane < m) { zu[lane] = du; dpart += Luv * du; }
+            if (lane < m) dpart += Luv * du;
             if (lane < n) dpart += Lxv * zown;
-            wave_lds_fence();
-            double a1 = 0.0, a2 = 0.0;                                        // Δx⁺ = fu Δu + fx Δx
+            // Δu_i sits on lane i of every 16-lane row: one DPP row broadcast each instead of an LDS round trip
+            double dua[m];
+            bcast_all<m>(du, dua);
+            double a1 = 0.0, a2[4] = {0.0, 0.0, 0.0, 0.0};                    // Δx⁺ = fu Δu + fx Δx (fx Δx in four interleaved partial sums:
+#pragma unroll                                                                 //  a dependent fp64 chain advances one link per ~8 clk)
+            for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * dua[j];
 #pragma unroll
-            for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * zu[j];
-#pragma unroll
-            for (int j = 0; j < n; ++j) a2 += sFx[j * ld + xi] * zx[j];
+            for (int j = 0; j < n; ++j) a2[j & 3] += sFx[j * ld + xi] * zx[j];
             wave_lds_fence();
-            if (lane < n) zx[lane] = a1 + a2;
+            if (lane < n) zx[lane] = a1 + ((a2[0] + a2[1]) + (a2[2] + a2[3]));
             kv = kv_n; Luv = Luv_n; Lxv = Lxv_n;
             wave_lds_fence();
         }
@@ -1213,7 +1214,7 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
 template <class M>
 __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, double alpha, int want_delta) {
     typedef LargeDims<M> LD;
-    constexpr int n = M::NX, m = M::NU, NP = LD::NP, MP = LD::MP, ld = LD::ld, NT = LD::NT, CH = LD::CH, KN = m * n;
+    constexpr int n = M::NX, m = M::NU, NP = LD::NP, ld = LD::ld, NT = LD::NT, CH = LD::CH, KN = m * n;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
