@@ -1172,6 +1172,10 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
         }
     }
     if (lane < n) zx[lane] = 0.0;
+#pragma unroll
+    for (int j = 0; j < EJ; ++j)
+        if (poff[j] >= 0) S[poff[j]] = pval[j];                               // fx_0, fu_0
+    wave_lds_fence();
     if (N > 0) { kv = A.k[ui]; Luv = A.Lu[ui]; Lxv = A.Lx[xi]; }
     for (int c0 = 0; c0 < N; c0 += CH) {
         const int c1 = (c0 + CH) < N ? (c0 + CH) : N;
@@ -1180,29 +1184,32 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
 #endif
         for (int t = c0; t < c1; ++t) {
             const double* Kt = ring + (t % (2 * CH)) * LD::RSTEP;
-#pragma unroll
-            for (int j = 0; j < EJ; ++j)
-                if (poff[j] >= 0) S[poff[j]] = pval[j];
-            wave_lds_fence();
+            // (fx_t's state-dependent entries are in place: written at the end of the previous step, behind its closing fence)
             const int t1 = t + 1 < N ? t + 1 : t;
 #pragma unroll
             for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[(size_t)t1 * JVP + lane + 64 * j] : 0.0;
             const double kv_n = A.k[t1 * m + ui], Luv_n = A.Lu[t1 * m + ui], Lxv_n = A.Lx[t1 * n + xi];
+            // Δx⁺ = fu Δu + fx Δx: fx Δx needs nothing of this step, so it goes first (four interleaved partial sums: a dependent
+            // fp64 chain advances one link per ~8 clk) and runs while the feedback term's operands are on their way
+            double a2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < n; ++j) a2[j & 3] += sFx[j * ld + xi] * zx[j];
+            const double zown = zx[xi];
             const double acc = kx_partial<M>(Kt, zx, li, lk);
             const double du = kv + acc;
-            const double zown = zx[xi];
             if (lane < m) dpart += Luv * du;
             if (lane < n) dpart += Lxv * zown;
             // Δu_i sits on lane i of every 16-lane row: one DPP row broadcast each instead of an LDS round trip
             double dua[m];
             bcast_all<m>(du, dua);
-            double a1 = 0.0, a2[4] = {0.0, 0.0, 0.0, 0.0};                    // Δx⁺ = fu Δu + fx Δx (fx Δx in four interleaved partial sums:
-#pragma unroll                                                                 //  a dependent fp64 chain advances one link per ~8 clk)
-            for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * dua[j];
+            double a1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < n; ++j) a2[j & 3] += sFx[j * ld + xi] * zx[j];
-            wave_lds_fence();
+            for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * dua[j];
+            wave_lds_fence();                                                 // every read of Δx and of fx_t, fu_t is done
             if (lane < n) zx[lane] = a1 + ((a2[0] + a2[1]) + (a2[2] + a2[3]));
+#pragma unroll
+            for (int j = 0; j < EJ; ++j)
+                if (poff[j] >= 0) S[poff[j]] = pval[j];                       // fx_{t+1}, fu_{t+1} (requested at the head of this step)
             kv = kv_n; Luv = Luv_n; Lxv = Lxv_n;
             wave_lds_fence();
         }
