@@ -945,6 +945,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         constexpr int V = decltype(Vc)::value;
                         if constexpr (V != W && RS::tab.ct[V][0] >= 0)
                             while (__hip_atomic_load(&sOut[4 + V], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (double)t) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");     // nothing of the tile may be read ahead of the flag (the flag is data in LDS, served in order:
+                                                            // a compiler barrier is all the acquire this needs — a real fence would wait for the pending global loads too)
                     });
                     const double4_t acc = tile_mm<n4, 1, ld, 1, ld>(sT + 16 * a, sFx + ld * 16 * c, li, lk);
                     tile_store<ld>(sQ, acc, 16 * a, 16 * c, li, lk);
