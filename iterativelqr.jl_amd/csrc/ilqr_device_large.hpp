@@ -742,6 +742,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     if (STAGE && N > 0) { stage_load(N - 1, rval); stage_store(rval); }
     double gmax = 0.0;
     __syncthreads();
+    // wave 0 carries the step's critical path in every window (ûx, Qux, the chain, a P tile) and shares its SIMD with a wave of the
+    // CU's other instance: its instructions go first whenever they can issue
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
         ILQR_SUB_BEGIN();
         const int tn = t > 0 ? t - 1 : 0;                                 // (t = 0: a harmless re-read instead of a branch)
@@ -1028,6 +1031,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         __syncthreads();                                                  // (B0) P′, p′, patched fx, fu visible
         ILQR_SUB_MARK1(I, 5); ILQR_SUB_MARK2(I, 5);
     }
+    __builtin_amdgcn_s_setprio(0);
     // the serial chain lived on wave 0: hand its scalars to all waves (identical control flow afterwards)
     const double gn = wave_max(gmax);
     if (tid == 0) { sOut[0] = gn; sOut[1] = (double)potrf_info; }
