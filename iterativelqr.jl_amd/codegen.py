@@ -502,6 +502,32 @@ def _emit_large_model_extras(L, add, dynamics, n, m, nw, sig_xu):
     # compact form: entry q of dyn_jac_var's output belongs at JAC_VAR_IDX[q] of the concatenation [fx (n*n) | fu (n*m)]
     L.extend(_itable("JAC_VAR_IDX", [int(l[3:-1]) + (n * n if l.startswith("fu") else 0) for l, _ in var]))
     add("void", "dyn_jac_var", sig_xu + [_arr("v", len(var), False)], dynamics, [("v[%d]" % q, e) for q, (_, e) in enumerate(var)])
+    # elementwise state-dependent entries: v_q = h(x_{i_q}; w) + c_q with ONE expression h for every q and a constant c_q per entry
+    # (e.g. x⁺ = A x + B u + c sin x: the variable entries are A_ii + c cos x_i on the diagonal of fx). The linearisation then
+    # evaluates them one (timestep, entry) pair per thread, coalesced, instead of all of a timestep's entries on one thread
+    # (JAC_VAR_SRC[q] = i_q, JAC_VAR_ADD[q] = c_q)
+    own_j = sp.Symbol("xl", real=True)
+    h0, src, addc, jac_elem = None, [], [], len(var) > 0
+    for _, e in var:
+        e = sp.expand(e)
+        fs = [k_ for k_, s_ in enumerate(xs) if s_ in e.free_symbols]
+        if len(fs) != 1 or any(s_ in e.free_symbols for s_ in us):
+            jac_elem = False
+            break
+        cq, rest = e.as_independent(*e.free_symbols, as_Add=True)
+        hq = rest.subs(xs[fs[0]], own_j)
+        if h0 is None:
+            h0 = hq
+        elif hq != h0:
+            jac_elem = False
+            break
+        src.append(fs[0])
+        addc.append(float(cq))
+    L.append("    static constexpr bool JAC_VAR_ELEMENTWISE = %s;" % ("true" if jac_elem else "false"))
+    if jac_elem:
+        L.extend(_itable("JAC_VAR_SRC", src))
+        L.extend(_table("JAC_VAR_ADD", [addc]))
+        add("double", "dyn_jac_var_own", ["const double xl", _arr("w", nw)], dynamics, [], ret_expr=h0)
     # --- affine split of the dynamics
     aff = [[0.0] * (n + m + 1) for _ in range(n)]
     rem = []

@@ -253,30 +253,45 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
     const LargeArgs A = large_args_from_lds<M>(base);
     constrained = __builtin_amdgcn_readfirstlane(constrained);
     const int tid = threadIdx.x, T = A.T, N = A.N;
-    // A timestep's linearisation is one long serial instruction stream per thread (4.4 k instructions for synth32), so it is cut in
-    // two along its function boundaries: waves 0, 1 evaluate the state-dependent Jacobian entries of timestep t, waves 2, 3 the
-    // cost gradients, the accumulated Hessian row and the Gauss-Newton AL terms of the same t (wave-uniform roles: no divergence;
-    // both halves read x̄_t, ū_t). Hessians accumulate: each timestep exactly once per half.
-    constexpr int NH = NT / 2;
-    const int half = __builtin_amdgcn_readfirstlane(tid / NH);
+    // A timestep's linearisation is one long serial instruction stream per thread (4.4 k instructions for synth32, two thirds of
+    // them the 32 cosines of the state-dependent Jacobian entries), so it is cut along its function boundaries.
+    // Where every state-dependent Jacobian entry is the same function of ONE state component (M::JAC_VAR_ELEMENTWISE), those
+    // entries are evaluated one (timestep, entry) pair per thread by all four waves, coalesced; the cost gradients, the accumulated
+    // Hessian row and the Gauss-Newton AL terms follow, one timestep per thread. Otherwise waves 0, 1 evaluate the Jacobian entries
+    // of timestep t while waves 2, 3 do the rest of the same t (wave-uniform roles: no divergence; both halves read x̄_t, ū_t).
+    // Hessians accumulate: each timestep exactly once.
+    constexpr bool JE = M::JAC_VAR_ELEMENTWISE;
+    constexpr int NH = JE ? NT : NT / 2;
+    const int half = JE ? 1 : __builtin_amdgcn_readfirstlane(tid / NH);
+    if constexpr (JE) {
+        constexpr int JV = LD::JV;
+        for (int e = tid; e < N * JV; e += NT) {
+            const int t = e / JV, q = e - t * JV;
+            double w[cdim<M::NW>::v];
+            load_w<M::NW>((const double*)A.w, t, w);
+            A.fv[(size_t)t * LD::JVP + q] = M::dyn_jac_var_own(A.xb[t * n + M::JAC_VAR_SRC[q]], w) + M::JAC_VAR_ADD[0][q];
+        }
+    }
     for (int t = tid % NH; t < T; t += NH) {
         double w[cdim<M::NW>::v];
         load_w<M::NW>((const double*)A.w, t, w);
         double xt[n];
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = A.xb[t * n + i];
-        if (half == 0) {
-            if (t < N) {
-                double ut[m];
+        if constexpr (!JE) {
+            if (half == 0) {
+                if (t < N) {
+                    double ut[m];
 #pragma unroll
-                for (int i = 0; i < m; ++i) ut[i] = A.ub[t * m + i];
-                double v[cdim<LD::JV>::v];
-                v[0] = 0.0;
-                M::dyn_jac_var(xt, ut, w, v);
+                    for (int i = 0; i < m; ++i) ut[i] = A.ub[t * m + i];
+                    double v[cdim<LD::JV>::v];
+                    v[0] = 0.0;
+                    M::dyn_jac_var(xt, ut, w, v);
 #pragma unroll
-                for (int q = 0; q < LD::JV; ++q) A.fv[(size_t)t * LD::JVP + q] = v[q];
+                    for (int q = 0; q < LD::JV; ++q) A.fv[(size_t)t * LD::JVP + q] = v[q];
+                }
+                continue;
             }
-            continue;
         }
         double* hrow = (double*)(A.hc + (size_t)t * LD::HSP);
         if (t < N) {

@@ -258,7 +258,7 @@ struct AdaptedLargeModel : AdaptedModel<F, NX_, NU_, NW_, NCS_, NCT_, INEQ_S_, I
     }
     // ---- dynamics row form: no affine part known, the whole f is the "remainder", evaluated by every lane
     static constexpr double DYN_AFF[NX][NX + NU + 1] = {};
-    static constexpr bool DYN_HAS_REM = true, DYN_REM_ELEMENTWISE = false;
+    static constexpr bool DYN_HAS_REM = true, DYN_REM_ELEMENTWISE = false, JAC_VAR_ELEMENTWISE = false;
     template <class BC = WaveBC>
     __device__ __forceinline__ static void dyn_rem_wave(const int, const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&r)[NX]) {
         Base::dyn(x, u, w, r);
