@@ -1789,11 +1789,10 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
     const Layout& L = a.L;
     double* g = a.ws + (size_t)b * (size_t)L.stride;
     const int N = L.T - 1;
-    const int row = lane < n ? lane : n - 1;
-    double aff[n + m + 1];
-#pragma unroll
-    for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
-    double xl = lane < n ? a.x1[(size_t)b * n + lane] : 0.0;
+    DynAff<M> aff;
+    aff.init(lane);
+    const int xrow = DynAff<M>::SPLIT ? (lane & 31) : lane;
+    double xl = xrow < n ? a.x1[(size_t)b * n + xrow] : 0.0;
     if (lane < n) g[L.xb + lane] = xl;
     double ul = (lane < m && N > 0) ? a.u_in[(size_t)b * N * m + lane] : 0.0;
     for (int t = 0; t < N; ++t) {

@@ -1093,20 +1093,42 @@ __device__ __forceinline__ double kx_partial(const double* Kt, const double* xv,
     return sum_quarters(acc);
 }
 
-// row `lane` of x⁺ = f(x, u) (src/rollout.jl:29): affine part from the lane's coefficient row, remainder either elementwise on
-// the lane's own component (M::dyn_rem_own) or through the generated wave-cooperative code
+// row i of x⁺ = f(x, u) (src/rollout.jl:29): affine part from the lane's coefficients, remainder either elementwise on the lane's
+// own component (M::dyn_rem_own) or through the generated wave-cooperative code. nx <= 32 leaves half the wave without a row:
+// lane i + 32 then takes the second half of row i's state terms (and the action terms), and the halves meet in one
+// v_permlane32_swap — 24 instead of 40 FMAs and half the LDS reads per lane on the rollout's serial chain.
 template <class M>
-__device__ __forceinline__ double dyn_row(const double (&aff)[M::NX + M::NU + 1], const double* sx, const double (&ua)[M::NU], double xl, int lane,
+struct DynAff {
+    static constexpr int n = M::NX, m = M::NU;
+    static constexpr bool SPLIT = n <= 32;
+    static constexpr int HX = SPLIT ? (n + 1) / 2 : n;           // state terms per lane
+    double cx[HX], cu[m], c0;
+    int x0;                                                      // first state term of this lane
+    __device__ __forceinline__ void init(int lane) {
+        const int r = SPLIT ? (lane & 31) : lane, row = r < n ? r : n - 1, h = SPLIT ? lane >> 5 : 0;
+        x0 = h * HX;
+#pragma unroll
+        for (int j = 0; j < HX; ++j) cx[j] = x0 + j < n ? M::DYN_AFF[row][x0 + j < n ? x0 + j : 0] : 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) cu[j] = (!SPLIT || h == 1) ? M::DYN_AFF[row][n + j] : 0.0;
+        c0 = h == 0 ? M::DYN_AFF[row][n + m] : 0.0;
+    }
+};
+template <class M>
+__device__ __forceinline__ double dyn_row(const DynAff<M>& aff, const double* sx, const double (&ua)[M::NU], double xl, int lane,
                                           const double* W, int t) {
-    constexpr int n = M::NX, m = M::NU;
-    // four interleaved partial sums: a dependent fp64 FMA chain advances one link per ~8 clk on a lone wave, forty links in a
-    // row were a third of the rollout step
-    double y4[4] = {aff[n + m], 0.0, 0.0, 0.0};
+    constexpr int n = M::NX, m = M::NU, HX = DynAff<M>::HX;
+    // four interleaved partial sums: a dependent fp64 FMA chain advances one link per ~8 clk on a lone wave
+    double y4[4] = {aff.c0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < n; ++j) y4[j & 3] += aff[j] * sx[j];
+    for (int j = 0; j < HX; ++j) {                               // (a padding term of an odd nx re-reads x_0 against a zero coefficient)
+        const int jj = (!DynAff<M>::SPLIT || n % 2 == 0 || aff.x0 + j < n) ? aff.x0 + j : 0;
+        y4[j & 3] += aff.cx[j] * sx[jj];
+    }
 #pragma unroll
-    for (int j = 0; j < m; ++j) y4[j & 3] += aff[n + j] * ua[j];
+    for (int j = 0; j < m; ++j) y4[j & 3] += aff.cu[j] * ua[j];
     double y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
+    if constexpr (DynAff<M>::SPLIT) y = sum_halves(y);
     if constexpr (M::DYN_HAS_REM) {
         double w[cdim<M::NW>::v];
         load_w<M::NW>(W, t, w);
@@ -1135,11 +1157,11 @@ __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
     const LargeArgs A = large_args_from_lds<M>(base);
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, N = A.N;
     double *sx = lds_dyn + LD::oFw, *ring = lds_dyn + LD::oRing;
-    const int row = lane < n ? lane : n - 1;
-    double aff[n + m + 1];
-#pragma unroll
-    for (int j = 0; j < n + m + 1; ++j) aff[j] = M::DYN_AFF[row][j];
-    double xl = lane < n ? A.xb[lane] : 0.0;                                  // x[1] = x̄[1]  (:19)
+    DynAff<M> aff;
+    aff.init(lane);
+    // (with the split rows lanes 32.. carry a copy of x_{lane - 32}: their sine argument stays finite and their row sum is the same)
+    const int xrow = DynAff<M>::SPLIT ? (lane & 31) : lane;
+    double xl = xrow < n ? A.xb[xrow] : 0.0;                                  // x[1] = x̄[1]  (:19)
     if (lane < n) A.x[lane] = xl;
     const int ui = li < m ? li : 0;                                           // (every row of 16 lanes forms the same m actions)
     for (int c0 = 0; c0 < N; c0 += CH) {
@@ -1181,7 +1203,10 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
     double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *zx = S + LD::oFw + NP + MP, *ring = S + LD::oRing;
     int poff[EJ];
     double pval[EJ], dpart = 0.0, kv = 0.0, Luv = 0.0, Lxv = 0.0;
-    const int ui = li < m ? li : m - 1, xi = lane < n ? lane : n - 1;         // (every row of 16 lanes forms the same m Δu)
+    constexpr bool DSPLIT = n <= 32;
+    constexpr int HXD = DSPLIT ? (n + 1) / 2 : n;
+    const int xr = DSPLIT ? (lane & 31) : lane, j0 = DSPLIT ? (lane >> 5) * HXD : 0;
+    const int ui = li < m ? li : m - 1, xi = xr < n ? xr : n - 1;             // (every row of 16 lanes forms the same m Δu)
 #pragma unroll
     for (int j = 0; j < EJ; ++j) {
         const int q = lane + 64 * j;
@@ -1212,9 +1237,13 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
             const double kv_n = A.k[t1 * m + ui], Luv_n = A.Lu[t1 * m + ui], Lxv_n = A.Lx[t1 * n + xi];
             // Δx⁺ = fu Δu + fx Δx: fx Δx needs nothing of this step, so it goes first (four interleaved partial sums: a dependent
             // fp64 chain advances one link per ~8 clk) and runs while the feedback term's operands are on their way
+            // (nx <= 32: lane i + 32 takes the second half of row i's terms, the halves meet in one v_permlane32_swap)
             double a2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int j = 0; j < n; ++j) a2[j & 3] += sFx[j * ld + xi] * zx[j];
+            for (int j = 0; j < HXD; ++j) {
+                const int jj = (!DSPLIT || n % 2 == 0 || j0 + j < n) ? j0 + j : n;     // (row n of the padded LDS copy of fx is zero)
+                a2[j & 3] += sFx[jj * ld + xi] * zx[jj < n ? jj : 0];
+            }
             const double zown = zx[xi];
             const double acc = kx_partial<M>(Kt, zx, li, lk);
             const double du = kv + acc;
@@ -1227,7 +1256,9 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
 #pragma unroll
             for (int j = 0; j < m; ++j) a1 += sFu[j * ld + xi] * dua[j];
             wave_lds_fence();                                                 // every read of Δx and of fx_t, fu_t is done
-            if (lane < n) zx[lane] = a1 + ((a2[0] + a2[1]) + (a2[2] + a2[3]));
+            double a2s = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+            if constexpr (DSPLIT) a2s = sum_halves(a2s);
+            if (lane < n) zx[lane] = a1 + a2s;
 #pragma unroll
             for (int j = 0; j < EJ; ++j)
                 if (poff[j] >= 0) S[poff[j]] = pval[j];                       // fx_{t+1}, fu_{t+1} (requested at the head of this step)
