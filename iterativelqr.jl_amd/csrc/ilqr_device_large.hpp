@@ -1079,18 +1079,37 @@ __device__ __forceinline__ void backward_pass_large(Inst<M>& I) {
 // u = ((α k + ū) + K x) − K x̄ in that order) for every t, so that the serial chain of a step is K x, the affine row and the
 // remainder only. K x and K x̄ use the same summation scheme (four partial sums per action, combined pairwise), so the
 // feedback term vanishes exactly where x = x̄.
-template <class M>
-__device__ __forceinline__ double kx_partial(const double* Kt, const double* xv, int li, int lk) {
-    // Σ_j K[i][j] x[j] for action i = li: lane (li, lk) sums the lk-th quarter of the states, then the quarters are combined
+// v + (v of lane li ^ 8 of the same 16-lane row)
+__device__ __forceinline__ double sum_row_halves(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true);      // row_ror:8
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+// Σ_j K[i][j] x[j] for action i: the summation scheme shared by the rollout's K x, the precomputed K x̄ and the sensitivity sweep's
+// K Δx (the feedback term must vanish exactly where x = x̄). Lane (li, lk) of the wave sums the lk-th quarter of the states for
+// action li; with nu <= 8 half of every 16-lane row would repeat its neighbour's work, so lane li + 8 takes the second half of
+// the quarter instead (one DPP rotation joins them) — four terms per lane on the serial chain instead of eight. Then the
+// quarters are combined pairwise. K(j, i) and x(j) come through the two callables.
+template <class M, class FK, class FX>
+__device__ __forceinline__ double kx_sum(int li, int lk, FK&& Kji, FX&& xj) {
     constexpr int n = M::NX, m = M::NU, JP = (n + 3) / 4;
-    const int i = li < m ? li : m - 1;
+    constexpr bool EIGHTHS = m <= 8 && JP % 2 == 0;
+    constexpr int JQ = EIGHTHS ? JP / 2 : JP;
+    const int ia = EIGHTHS ? (li & 7) : li, i = ia < m ? ia : m - 1;
+    const int j0 = lk * JP + (EIGHTHS ? (li >> 3) * JQ : 0);
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < JP; ++q) {
-        const int j = lk * JP + q;
-        if ((n % 4 == 0) || j < n) acc += Kt[(j < n ? j : 0) * m + i] * xv[j < n ? j : 0];
+    for (int q = 0; q < JQ; ++q) {
+        const int j = j0 + q;
+        if ((n % 4 == 0) || j < n) acc += Kji(j < n ? j : 0, i) * xj(j < n ? j : 0);
     }
+    if constexpr (EIGHTHS) acc = sum_row_halves(acc);
     return sum_quarters(acc);
+}
+template <class M>
+__device__ __forceinline__ double kx_partial(const double* Kt, const double* xv, int li, int lk) {
+    return kx_sum<M>(li, lk, [&](int j, int i) { return Kt[j * M::NU + i]; }, [&](int j) { return xv[j]; });
 }
 
 // row i of x⁺ = f(x, u) (src/rollout.jl:29): affine part from the lane's coefficients, remainder either elementwise on the lane's
@@ -1284,15 +1303,8 @@ __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, d
     double* sOut = S + LD::oVec + 2 * NP;
     // ---- a_t, b_t for every timestep (wave per timestep, same lane mapping as the rollout's K x)
     for (int t = wave; t < N; t += LD::W) {
-        const int i = li < m ? li : m - 1;
-        constexpr int JP = (n + 3) / 4;
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < JP; ++q) {
-            const int j = lk * JP + q;
-            if ((n % 4 == 0) || j < n) acc += A.K[(size_t)t * KN + (j < n ? j : 0) * m + i] * A.xb[t * n + (j < n ? j : 0)];
-        }
-        acc = sum_quarters(acc);
+        const double acc = kx_sum<M>(li, lk, [&](int j, int i) { return (double)A.K[(size_t)t * KN + j * m + i]; },
+                                     [&](int j) { return (double)A.xb[t * n + j]; });
         if (lane < m) {
             double v = A.k[t * m + lane] * alpha;                         // (:24-25)
             v += A.ub[t * m + lane];                                      // (:26)
