@@ -9,18 +9,22 @@
 //     (Layout::hc, order M::HESS_IDX: [gxx sorted by 16x16 tile | guu | gux]); the Riccati step adds them to Qxx, Quu, Qux
 //     where they fall — bitwise what adding the dense arrays gives, zeros contribute nothing;
 //   * the full jacobian_* / hessian_* arrays of the reference are a host-visible mirror, written on demand by
-//     materialise_large_kernel and read back into the compact form by gather_large_kernel after a host write.
-// Riccati step (src/backward_pass.jl:42-90): 132 v_mfma_f64_16x16x4_f64 tiles for n = 32, m = 8 around the serial
-// potrf / potrs chain, scheduled over the four waves in four windows (one workgroup barrier each):
-//     A   waves 0,1: ûx = fuᵀP′ (the tiles the chain waits for)          waves 2,3: first half of T = fxᵀP′
-//     B   waves 0,1: Qux = ûx fx, Quu = ûx fu                            waves 2,3: rest of T
-//     C   wave 0: + guu, gux; potrf; potrs → K, k (the serial chain)      waves 1-3: Qu (flag to wave 0), Qx; Qxx = T fx + gxx
-//     D   wave 0: ûxt = Quu K; p, ∇L                                      waves 1-3: P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx; all: patch fx, fu
-// Every tile is one generic call (tile_mm) with run-time tile coordinates; operand fragments are read from zero-padded LDS
-// matrices with odd leading dimensions (transposition = stride pattern, no bounds checks), the MFMAs of a tile issue back to back.
-// Forward sweep: wave 0 runs the closed-loop rollout (K x as four partial sums per action on the 64 lanes, the affine part of
-// row i of the dynamics on lane i, generated wave-cooperative remainder), wave 1 the sensitivity recursion Δz with ∇Lᵀ·Δz,
-// waves 2,3 stage K_t into an LDS ring a chunk ahead; a_t = α k_t + ū_t and b_t = K_t x̄_t are formed beforehand time-parallel.
+//     mirror_large_kernel and read back into the compact form by it after a host write.
+// Riccati step (src/backward_pass.jl:42-90): 136 v_mfma_f64_16x16x4_f64 for n = 32, m = 8 around the serial Cholesky chain,
+// scheduled statically (RicSchedule) over the four waves in four windows, one workgroup barrier each, and compiled into one
+// straight-line instruction stream per wave (tile coordinates are immediates). For 17 <= nx <= 32:
+//     A   waves 0,1: ûx = fuᵀP′ (the tiles the chain waits for)          waves 2,3: T(0,.) = fxᵀP′
+//     B   waves 0,1: Qux = ûx fx + gux    wave 2: Quu = ûx fu + guu      wave 3: Qu = fuᵀp′ + gu, Qx = fxᵀp′ + gx
+//     C   wave 0: potrf and potrs fused in registers → K, k; p, ∇L       waves 1-3: T(1,.) (flags in LDS), Qxx = T fx + gxx
+//     D   every wave one tile of P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx; the next step's operands go into LDS in its shadow
+// Operand fragments are read from zero-padded LDS matrices with odd leading dimensions (transposition = stride pattern, no
+// bounds checks), all fragments of a tile before its first MFMA, the MFMAs of a tile back to back.
+// Forward sweep: wave 0 runs the closed-loop rollout, wave 1 the sensitivity recursion Δz with ∇Lᵀ·Δz, waves 2,3 stage K_t, a_t,
+// b_t into an LDS ring a chunk ahead; a_t = α k_t + ū_t and b_t = K_t x̄_t are formed beforehand time-parallel. Matrix-vector
+// products use every lane: K x as eight (nu <= 8) or four partial sums per action, a dynamics / sensitivity row as two halves
+// on lanes i and i + 32 (nx <= 32), joined by DPP / permlane moves; actions reach all lanes by DPP row broadcasts.
+// gradients!: state-dependent Jacobian entries one (timestep, entry) pair per thread where they are elementwise
+// (M::JAC_VAR_ELEMENTWISE), else on waves 0, 1 beside the cost / AL terms on waves 2, 3.
 // Same reference semantics and citations as ilqr_device.hpp.
 #pragma once
 
