@@ -27,6 +27,13 @@ namespace ilqr {
 
 template <class M> struct packed_ok { static constexpr bool value = (M::NX <= 4 && M::NU <= 4); };
 
+#ifndef ILQR_PK_TRIALS
+#define ILQR_PK_TRIALS 4      // line-search trials per cycle of the packed kernel's state machine (1 = the first version: one)
+#endif
+#ifndef ILQR_PK_REJECTS
+#define ILQR_PK_REJECTS 8     // ... the extra ones only for an instance with that many rejected trials so far
+#endif
+
 namespace pk {
 
 enum { ST_INIT = 0, ST_FORWARD = 1, ST_OUTER = 2, ST_DONE = 3 };
@@ -767,7 +774,13 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
             }
         }
         if (!__any(I.state != ST_DONE)) break;
-        // ------------------------------------------------ C: one line-search trial of forward_pass! (src/forward_pass.jl)
+        // ------------------------------------------------ C: line-search trials of forward_pass! (src/forward_pass.jl)
+        // One trial for every instance in its forward pass — and up to three more, at once, for an instance whose trial was rejected
+        // and that has ILQR_PK_REJECTS rejected trials behind it already: for such an instance (the stragglers: instance 2300 of
+        // config 4's shard 2 spends 682 trials on 725 iterations) a rejected trial then costs one rollout + cost pass instead of a
+        // whole cycle, at the price of one such pass for the wave's other instances (which is why the ordinary instance, a dozen
+        // rejections in 350 iterations, does not get them: car:4096 was 1.5 % slower with extra trials for everybody). Every
+        // instance takes the same steps in the same order either way.
         {
             const bool fw = I.state == ST_FORWARD;
             if (__any(fw)) {
@@ -775,9 +788,12 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                 if (first) { I.status = 0; I.J_prev = I.objective; I.delta = 0.0; I.step_size = 1.0; }   // (:10, :13, :26)
                 const bool want_delta = first && opt.line_search == 1;
                 if (want_delta) I.delta = I.delta_next;                                   // (:16-20) came out of the backward pass (adjoint form)
-                // while step_size >= min_step_size && iteration <= 25   (:28-29)
-                const bool go = fw && (I.step_size >= opt.min_step_size) && (I.trial <= 25);
-                if (__any(go)) {
+#pragma clang loop unroll(disable)
+                for (int rep = 0; rep < ILQR_PK_TRIALS; ++rep) {
+                    // while step_size >= min_step_size && iteration <= 25   (:28-29)
+                    const bool go = fw && !I.needB && (I.step_size >= opt.min_step_size) && (I.trial <= 25) &&
+                                    (rep == 0 || I.rollouts - I.iterations >= ILQR_PK_REJECTS);
+                    if (!__any(go)) break;
                     if (!(dbg & 16)) {                                                      // (:34)
                         rollout<M>(I, go, I.step_size);
                     }
