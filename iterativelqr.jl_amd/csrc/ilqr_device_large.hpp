@@ -27,6 +27,7 @@
 // (M::JAC_VAR_ELEMENTWISE), else on waves 0, 1 beside the cost / AL terms on waves 2, 3.
 // Same reference semantics and citations as ilqr_device.hpp.
 #pragma once
+#include "ilqr_ric_schedule.hpp"
 
 namespace ilqr {
 
@@ -537,57 +538,6 @@ __device__ __forceinline__ void potrs_U_lds(const double* U, const double (&R)[m
 // Forming that tile twice — on waves 1 and 3, two tiles each in C — was measured: the chain no longer waits 0.45 k clk per
 // timestep, but the eight extra MFMAs cost more when both instances of a CU are active: 3.83 -> 3.94 ms on BASELINE C5.)
 // Other sizes: critical tiles alternate over waves 0, 1; T tiles over waves 2, 3 (half in A, half in B); Qxx / P over waves 1..3.
-enum { RIC_UH = 1 << 5, RIC_T = 2 << 5, RIC_QUX = 3 << 5, RIC_QUU = 4 << 5, RIC_END = 0xff };   // task byte: kind << 5 | tile index
-template <int TN>
-struct RicSchedule {
-    static constexpr int NQ = TN * TN, MAXL = 8, SLOTS = (NQ + 2) / 3, RIC_WAIT_T = 0x40;       // a task list is one 64-bit word: eight task bytes
-    struct Tab {
-        int a[4][MAXL], b[4][MAXL], ct[4][MAXL], qxx[4][SLOTS], p[4][SLOTS];
-        unsigned long long wa[4], wb[4], wc[4];                               // the lists packed, RIC_END-terminated
-    };
-    static constexpr Tab make() {
-        Tab t{};
-        int na[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0}, nc[4] = {0, 0, 0, 0}, nq[4] = {0, 0, 0, 0}, np[4] = {0, 0, 0, 0};
-        for (int w = 0; w < 4; ++w) {
-            for (int i = 0; i < MAXL; ++i) { t.a[w][i] = -1; t.b[w][i] = -1; t.ct[w][i] = -1; }
-            for (int i = 0; i < SLOTS; ++i) { t.qxx[w][i] = -1; t.p[w][i] = -1; }
-        }
-        if (TN == 2) {
-            // A: ûx | T(0,.)   B: Qux, Quu | (wave 3: Qu, Qx)   C: chain | T(1,.), Qxx   D: P
-            t.a[0][na[0]++] = RIC_UH + 0; t.a[1][na[1]++] = RIC_UH + 1; t.a[2][na[2]++] = RIC_T + 0; t.a[3][na[3]++] = RIC_T + 1;
-            t.b[0][nb[0]++] = RIC_QUX + 0; t.b[1][nb[1]++] = RIC_QUX + 1; t.b[2][nb[2]++] = RIC_QUU;
-            t.ct[2][nc[2]++] = RIC_T + 2; t.ct[3][nc[3]++] = RIC_T + 3;
-            // Qxx(1,.) needs T(1,0) and T(1,1), formed in this same window by waves 2 and 3: those tiles wait for the flags of the
-            // OTHER waves that form T here (RIC_WAIT_T)
-            t.qxx[1][nq[1]++] = 0; t.qxx[1][nq[1]++] = 2 | RIC_WAIT_T; t.qxx[2][nq[2]++] = 1; t.qxx[3][nq[3]++] = 3 | RIC_WAIT_T;
-            t.p[0][np[0]++] = 3; t.p[1][np[1]++] = 0; t.p[2][np[2]++] = 1; t.p[3][np[3]++] = 2;
-        } else {
-            for (int c = 0; c < TN; ++c) { const int w = c % 2; t.a[w][na[w]++] = RIC_UH + c; }
-            for (int v = 2; v < 4; ++v) {
-                const int cnt = (NQ - (v - 2) + 1) / 2, first = (cnt + 1) / 2;
-                for (int k = 0; k < cnt; ++k) {
-                    const int q = (v - 2) + 2 * k;
-                    if (k < first) t.a[v][na[v]++] = RIC_T + q; else t.b[v][nb[v]++] = RIC_T + q;
-                }
-            }
-            for (int i = 0; i <= TN; ++i) { const int w = i % 2; t.b[w][nb[w]++] = i < TN ? RIC_QUX + i : RIC_QUU; }
-            for (int q = 0; q < NQ; ++q) { const int w = 1 + (q + 1) % 3; t.qxx[w][nq[w]++] = q; }
-            for (int q = 0; q < NQ; ++q) { const int w = (q + 1) % 4; t.p[w][np[w]++] = q; }      // wave 0 last: it also stores p, Lx, Lu
-        }
-        for (int w = 0; w < 4; ++w) {
-            t.wa[w] = 0; t.wb[w] = 0; t.wc[w] = 0;
-            for (int i = MAXL - 1; i >= 0; --i) {
-                t.wa[w] = (t.wa[w] << 8) | (unsigned long long)(t.a[w][i] < 0 ? RIC_END : t.a[w][i]);
-                t.wb[w] = (t.wb[w] << 8) | (unsigned long long)(t.b[w][i] < 0 ? RIC_END : t.b[w][i]);
-                t.wc[w] = (t.wc[w] << 8) | (unsigned long long)(t.ct[w][i] < 0 ? RIC_END : t.ct[w][i]);
-            }
-        }
-        return t;
-    }
-    static constexpr Tab tab = make();
-    static_assert(NQ <= 16, "tile index fits five bits; at most eight tasks per list (TN <= 4)");
-};
-
 // compile-time loop and a switch on the (uniform) wave index that hands the index over as a constant: the Riccati step's static
 // schedule is compiled into four straight-line instruction streams, one per wave, with every tile coordinate an immediate
 template <int V> struct IntC { static constexpr int value = V; };
