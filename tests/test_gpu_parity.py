@@ -1210,6 +1210,31 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
             assert np.array_equal(off[k], on[k], equal_nan=True), k
 
 
+def test_packed_kernel_extra_trials_for_an_instance_that_keeps_rejecting(pkg):
+    """The packed kernel gives an instance with eight rejected line-search trials behind it up to three more trials within the
+    cycle (ilqr_device_packed.hpp, ILQR_PK_TRIALS / ILQR_PK_REJECTS). Instance 2300 of shard 2 of BASELINE config 4 spends 1407
+    rollouts on 725 iterations: with its three neighbours in one wave the path is taken hundreds of times, and every count, trace
+    row and array must be what the latency kernel (one trial after the other, no cycles) gives — bitwise."""
+    B = 4
+    model, T, x1, ub = pkg.workloads.make_inputs("acrobot", B, offset=2 * 8192 + 2300)
+    out = {}
+    for variant in ("packed", "latency"):
+        s = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+        s.set_kernel_variant_(variant); s.set_handover_(0); s.enable_trace_(1000)
+        s.initialize_rollout_(x1, ub); s.solve_()
+        out[variant] = dict(x=s.get_trajectory()[0], u=s.get_trajectory()[1], K=s.get_policy()[0], st=s.stats(), tr=s.trace(),
+                            lam=s.buffer("constraint_dual"))
+        s.close()
+    a, b = out["packed"], out["latency"]
+    assert a["st"]["rollouts"][0] - a["st"]["iterations"][0] >= 500          # the rejecting kind
+    for k in ("iterations", "outer_iterations", "rollouts", "status"):
+        assert np.array_equal(a["st"][k], b["st"][k]), k
+    cols = [0, 1, 3, 4, 5, 6, 7]
+    assert np.array_equal(a["tr"][:, :, cols], b["tr"][:, :, cols], equal_nan=True)
+    for k in ("x", "u", "K", "lam"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
 def test_c_callables_define_a_large_path_model(pkg, oracle, tmp_path):
     """ilqr_compile_model beyond nx, nu <= 4 (src/dynamics.jl:55-60, src/costs.jl:1-15, src/constraints.jl:54-64 accept any
     size): the synth12 callables of examples/synth12_model.c as C source -> AdaptedLargeModel (compact forms, every entry
