@@ -299,3 +299,26 @@ def test_cooperative_rollout_code_shape():
     _, src2 = pkg.codegen.generate_model_source("nonaffine", dyn, cost, term, pkg.Constraint(), pkg.Constraint())
     body2 = src2[src2.index("static void dyn_wave("):src2.index("static void dyn_jac(")]
     assert "(pq == 1)" in body2 and body2.count("ilqr::sincos_pair(") == 1
+
+
+def test_large_model_structure_detection():
+    """What the generator finds in a large model (codegen.py, _emit_large_model_extras) and the kernels then exploit: synth32
+    (x+ = A x + B u + c sin x) has 32 state-dependent Jacobian entries of 1280, each A_ii + c cos x_i — ONE function of ONE state
+    component plus a constant (JAC_VAR_ELEMENTWISE: gradients! evaluates them one (timestep, entry) pair per thread) — and an
+    elementwise remainder independent of u (dyn_rem_own); synth12's state-dependent entries sit in fu and mix components: no such
+    structure, the generic forms are emitted."""
+    import re
+    pkg = load_package()
+    _, s32 = pkg.models.builtin_source("synth32")
+    assert "static constexpr int JAC_NVAR = 32;" in s32
+    assert "static constexpr bool JAC_VAR_ELEMENTWISE = true;" in s32 and "static constexpr bool DYN_REM_ELEMENTWISE = true;" in s32
+    src = [int(v) for v in re.search(r"JAC_VAR_SRC\[32\] = \{([^}]*)\}", s32).group(1).split(",")]
+    assert src == list(range(32))                                                          # entry q is a function of x_q
+    own = s32[s32.index("static double dyn_jac_var_own("):]
+    own = own[:own.index("}")]
+    assert own.count("cos_fast(xl)") == 1 and "x[" not in own                             # one cosine of the lane's own component
+    add = [float(v) for v in re.search(r"JAC_VAR_ADD\[1\]\[32\] = \{\s*\{([^}]*)\}", s32).group(1).split(",")]
+    assert len(add) == 32 and all(0.9 < v < 1.0 for v in add)                             # the constants A_ii
+    m12 = pkg.models.synth12()
+    _, s12 = pkg.codegen.generate_model_source("synth12_t", m12["dynamics"], m12["cost_stage"], m12["cost_term"], m12["con_stage"], m12["con_term"])
+    assert "static constexpr bool JAC_VAR_ELEMENTWISE = false;" in s12 and "dyn_jac_var_own" not in s12 and "static void dyn_jac_var(" in s12
