@@ -44,6 +44,34 @@ __global__ __launch_bounds__(256) void tile(double* out, long long* ticks, int i
     out[blockIdx.x * blockDim.x + threadIdx.x] = sD[threadIdx.x];
     if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
 }
+// the same tile between two workgroup barriers, each wave on its own column block of the LDS matrices and reading what ANOTHER wave
+// stored in the previous window: one window of the Riccati step without anything else in it
+__global__ __launch_bounds__(256) void tile_window(double* out, long long* ticks, int iters) {
+    __shared__ double sA[32 * 33], sB[4][16 * 33], sD[4][16 * 33];
+    for (int e = threadIdx.x; e < 32 * 33; e += blockDim.x) sA[e] = e * 1e-4;
+    for (int e = threadIdx.x; e < 4 * 16 * 33; e += blockDim.x) { (&sB[0][0])[e] = 1.0 - e * 1e-5; (&sD[0][0])[e] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, wave = threadIdx.x >> 6;
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+        double fa[8], fb[8];
+        const double* src = (i & 1) ? &sD[(wave + 1) & 3][0] : &sB[(wave + 1) & 3][0];
+        double* dst = (i & 1) ? &sB[wave][0] : &sD[wave][0];
+        const double* pa = sA + 33 * li + lk; const double* pb = src + lk + 33 * li;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { fa[s] = pa[4 * s]; fb[s] = pb[4 * s]; }
+        double4_t acc = double4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s], fb[s], acc, 0, 0, 0);
+        double* p = dst + li * 33 + lk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[4 * r] = acc[r] * 1e-3;
+        __syncthreads();
+    }
+    const long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sD[wave][lane] + sB[wave][lane];
+    if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
 int main() {
     double* d; long long* t; hipMalloc(&d, 1 << 22); hipMalloc(&t, 64);
     long long h;
@@ -63,5 +91,7 @@ int main() {
     run("whole tile (16 ds_read + 8 MFMA + 4 ds_write), 1 wave", tile, 64, 1, 1);
     run("whole tile, 4 waves of a block", tile, 256, 1, 1);
     run("whole tile, 2 blocks per CU (512 blocks x 256)", tile, 256, 512, 1);
+    run("tile + workgroup barrier (one window), 4 waves of a block", tile_window, 256, 1, 1);
+    run("tile + workgroup barrier, 2 blocks per CU (512 blocks x 256)", tile_window, 256, 512, 1);
     return 0;
 }
