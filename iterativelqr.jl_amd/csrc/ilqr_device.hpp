@@ -1588,7 +1588,12 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
     Inst<M> I;
     inst_setup<M>(I, a, smem, b);
     if (!resumed) { I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0; }
-    else I.trace_len = (int)I.scal[S_TRACE_LEN];
+    else {
+        I.trace_len = (int)I.scal[S_TRACE_LEN];
+        // resumed at the head of an inner iteration: the first forward pass takes the Armijo product the packed kernel's backward
+        // pass left behind (same adjoint form, same bits) instead of the forward sensitivity sweep
+        if (it_start >= 1) { I.delta_next = I.scal[S_DELTA_NEXT]; I.delta_next_ok = 1; }
+    }
     {
         ILQR_PROF_BEGIN();
         solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0, o_start, it_start, obj_prev0);

@@ -704,6 +704,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
         scal[S_DELTA] = I.delta;
         scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
         scal[S_RESUME] = (double)resume; scal[S_INNER_IT] = (double)resume_it; scal[S_OBJ_PREV] = resume_obj_prev;
+        scal[S_DELTA_NEXT] = I.delta_next;
     };
     __syncthreads();
     const int outer_max = al_outer ? opt.max_dual_updates : 1;

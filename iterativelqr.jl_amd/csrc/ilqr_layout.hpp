@@ -24,6 +24,9 @@ enum {
     // straggler hand-over: the packed kernel left this instance at the START of outer iteration S_RESUME (>= 2) for the latency
     // kernel to finish (0 = nothing to resume)
     S_RESUME = 24,
+    // ... and, for a hand-over at the head of an inner iteration, the Armijo product ∇Lᵀ·Δz the backward pass produced for the
+    // NEXT forward pass (adjoint form): the resumed launch uses this very number instead of summing it again in another order
+    S_DELTA_NEXT = 25,
     S_COUNT = 26
 };
 

@@ -1193,7 +1193,7 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
         s.initialize_rollout_(x1, ub); s.solve_()
         out = dict(x=s.get_trajectory()[0], u=s.get_trajectory()[1], K=s.get_policy()[0], k=s.get_policy()[1], st=s.stats(),
                    tl=s.scalar("trace_len"), tr=s.trace(), resume=s.scalar("resume"), lam=s.buffer("constraint_dual"),
-                   fx=s.buffer("jacobian_state"), gxx=s.buffer("hessian_state_state"))
+                   fx=s.buffer("jacobian_state"), gxx=s.buffer("hessian_state_state"), delta=s.scalar("delta_grad_product"))
         s.close()
         return out
     off = run(False)
@@ -1206,7 +1206,9 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
         cols = [0, 1, 3, 4, 5, 6, 7]
         assert np.array_equal(off["tr"][:, :, cols], on["tr"][:, :, cols], equal_nan=True)
         assert np.allclose(off["tr"][:, :, 2], on["tr"][:, :, 2], rtol=1e-14, atol=0, equal_nan=True)
-        for k in ("x", "u", "K", "k", "lam", "fx", "gxx"):
+        # delta: the Armijo product of the LAST forward pass — the first one after a hand-over takes the number the packed kernel's
+        # backward pass left in the block (S_DELTA_NEXT), not a sum of its own in another order
+        for k in ("x", "u", "K", "k", "lam", "fx", "gxx", "delta"):
             assert np.array_equal(off[k], on[k], equal_nan=True), k
 
 
