@@ -191,7 +191,9 @@ int ilqr_enable_action_value_buffers(ilqr_handle* h);
  * "iterations","gradient_norm","outer_iterations","potrf_info","rollouts","done" (host-stepped AL loop: instance met
  * the constraint tolerance), "delta_grad_product" (∇Lᵀ·Δz of the last forward_pass!, src/forward_pass.jl:20),
  * "trace_len" (rows the last solve wrote to the trace), "count" (length of "_scalars"); shared-step mode: "obj_prev",
- * "inner_done", "j_prev", "inner_it"; "resume" (hand-over bookkeeping, 0 after a solve). -1 if unknown. */
+ * "inner_done", "j_prev", "inner_it"; "resume" (hand-over bookkeeping, 0 after a solve);
+ * "literal_backward_passes" (two-wave latency kernel, models with one action: backward passes of the last solve that met a
+ * non-positive pivot and were repeated in LAPACK's literal arithmetic — 0 on healthy instances). -1 if unknown. */
 int ilqr_scalar_slot(const char* name);
 
 /* Kernel variant of ilqr_solve (small models, nx, nu <= 4; large models have one kernel family): 0 = auto — the latency kernel

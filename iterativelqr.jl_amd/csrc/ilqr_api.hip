@@ -749,7 +749,7 @@ int ilqr_scalar_slot(const char* name) {
         {"states_eq_nominal", ilqr::S_STATES_EQ_NOMINAL}, {"profile", ilqr::S_PROF}, {"done", ilqr::S_DONE},
         {"delta_grad_product", ilqr::S_DELTA}, {"trace_len", ilqr::S_TRACE_LEN}, {"count", ilqr::S_COUNT},
         {"obj_prev", ilqr::S_OBJ_PREV}, {"inner_done", ilqr::S_INNER_DONE}, {"j_prev", ilqr::S_J_PREV}, {"inner_it", ilqr::S_INNER_IT},
-        {"resume", ilqr::S_RESUME},
+        {"resume", ilqr::S_RESUME}, {"literal_backward_passes", ilqr::S_LITERAL_PASSES},
     };
     if (!name) return -1;
     for (auto& s_ : slots)

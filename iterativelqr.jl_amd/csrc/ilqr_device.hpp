@@ -148,6 +148,15 @@ __device__ __forceinline__ void load_w(const double* W, int t, double (&w)[cdim<
 #define ILQR_PROF_BEGIN() do {} while (0)
 #define ILQR_PROF_END(I, slot) do {} while (0)
 #endif
+// -DILQR_PROFILE -DILQR_PROFILE_BAR: time the two waves of a small-model instance spend in the chunk barriers of the Riccati
+// recursion (wave 0 -> the `delta` slot, wave 1 -> LDS slot zs[7], reported in the `cost` slot INSTEAD of the cost pass)
+#if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_BAR)
+#define ILQR_BAR_BEGIN() const long long bar_t0_ = clock64()
+#define ILQR_BAR_END(I, slot) (I).prof[slot] += (double)(clock64() - bar_t0_)
+#else
+#define ILQR_BAR_BEGIN() do {} while (0)
+#define ILQR_BAR_END(I, slot) do {} while (0)
+#endif
 enum { PROF_COST = 0, PROF_GRAD, PROF_BACKWARD, PROF_DELTA, PROF_ROLLOUT, PROF_OTHER, PROF_N };
 // Comment markers at the head of every timestep body of the serial loops: tools/issue_model.py finds the loops in the assembly
 // the build keeps (-save-temps, csrc/Makefile) and reads their per-step instruction counts off it. An empty asm statement: it
@@ -276,7 +285,9 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
     J_out = wave_sum(Jp);
     viol_out = wave_max(vp);
     __syncthreads();
+#ifndef ILQR_PROFILE_BAR
     ILQR_PROF_END(I, PROF_COST);
+#endif
 }
 
 // cost!(data, problem, mode) — src/data/methods.jl:13-30.
@@ -1110,6 +1121,220 @@ __device__ void backward_pass_split(Inst<M>& I) {
     }
 }
 
+// ---- nu = 1 (acrobot, pendulum, particle): the two-wave recursion with the action dimension folded OUT of the matrix pipe.
+// v_mfma_f64_4x4x4 accumulates the four products of an element as ONE k-ascending fma chain (tools/probes/probe_mfma_order.hip,
+// profiles/r04_probe_mfma_order.txt: 128000 of 128000 elements bitwise), so rank-1 terms that the general form issues as
+// dependent MFMAs with one non-zero k slice each can share an instruction — or leave the matrix pipe — without changing a bit:
+//   matrix chain (wave 0), SIX MFMAs instead of nine and no lane read-out:
+//     * fu enters REPLICATED over the columns of its tile, gux over the rows, guu everywhere: WuR = P'ᵀ fuR has Wu in every column,
+//       QuxR = WuRᵀ fx + guxR has the row vector Qux in EVERY row, q = WuRᵀ fuR + guu has Quu on EVERY lane (the products and the
+//       order of element (0,0) of the general form) — the reciprocal is formed per lane, no v_readlane, no scalar hazard states;
+//     * the three rank-1 updates P = ((Qxx + Kᵀ Qux) + Quxᵀ K) + Kᵀ ux_tmp (src/backward_pass.jl:79-84) are ONE MFMA on tiles
+//       stacked along k: A3 = rows [K; Qux; K; 0], B3 = rows [Qux; K; ux_tmp; 0], both QuxR scaled row-wise by per-lane
+//       multipliers (K = Qux (-1/q), ux_tmp = K q: the roundings of the general form);
+//     * ONE LDS store hands over everything: row 0 of B3 (Qux) and row 2 (ux_tmp) go to the ring, row 1 (K) to its array;
+//     * a non-positive or NaN pivot is not looked for inside the loop (the reference ignores potrf's info, src/backward_pass.jl:69,
+//       but what LAPACK leaves behind then is another arithmetic): the loop keeps min 1 / q, and a pass that ends with a negative one or
+//       a NaN in P is REPEATED by the literal code (backward_pass_split) — rare (diverged instances), exact;
+//   vector chain (wave 1), FOUR MFMAs instead of nine: with p, ν, gx replicated over columns and fu, gu everywhere, Qu and
+//     w = ∇L_u + fuᵀν′ come out of their MFMAs on every lane, k = Qu (-1/q) is one multiply, and p = ((Qx + Kᵀ Qu) + Quxᵀ k) +
+//     ux_tmpᵀ k, Δ += w k, ν = (fxᵀν′ + ∇L_x) + Kᵀ w are plain fp64 FMAs in the order of the k slices they replace.
+// Addresses: every operand and result stands at the LOWEST timestep of its four-step chunk (chunks are aligned to t & ~3, the
+// first one may be short) and step t uses the immediate offset (t & 3) * stride; bases move once per chunk. Padding lanes
+// (nx < 4) aim at a zero REGION long enough for those offsets (LDS: in the ring area, zeroed by each wave before its pass; HBM:
+// behind Layout::gzero), result lanes that store nothing at a trash region.
+enum { M1_RQ = 0, M1_RU = 32, M1_RS = 64, M1_TRASH = 80, M1_ZERO = 128, M1_ZERO_N = 48 };    // doubles from Inst::ring
+static_assert(M1_ZERO + M1_ZERO_N <= RING_DOUBLES, "nu = 1 ring map fits the ring");
+template <class M, bool STORE_VALUE, int ROLE>
+__device__ bool backward_pass_m1(Inst<M>& I) {
+    constexpr int n = M::NX;
+    constexpr bool MAT = ROLE == 1, VEC = ROLE == 2;
+    static_assert(ROLE == 1 || ROLE == 2, "two-wave recursion");
+    static_assert(M::NU == 1 && n <= 4 && !slim_of<M>::value, "LDS-resident small models with one action");
+    static_assert(RING_STEPS == 4, "chunks of four steps");
+    static_assert(n == 4 || (3 * n * n < GZERO_REGION && M1_RU + 3 * n < M1_ZERO_N), "zero regions cover the largest immediate offset (nx = 4 has no padding lanes)");
+    typedef __attribute__((address_space(3))) double ldsd;
+    const int lane = I.lane, r = lane >> 4, c = lane & 3;
+    const bool vnn = r < n && c < n, vr = r < n, vc = c < n, b0 = ((lane >> 2) & 3) == 0;
+    const int N = I.N;
+    if (N <= 0) {
+        if constexpr (VEC) { I.gradient_norm = 0.0; I.delta_next = 0.0; }
+        return false;
+    }
+    auto lds = [](const double* q) -> unsigned { return (unsigned)(size_t)(const ldsd*)q; };
+    auto LD = [](unsigned a, int off) -> double { return *(const ldsd*)(size_t)(a + 8u * off); };
+    auto ST = [](unsigned a, int off, double v) { *(ldsd*)(size_t)(a + 8u * off) = v; };
+    if (n < 4 && lane < M1_ZERO_N) I.ring[M1_ZERO + lane] = 0.0;      // this wave's own reads follow its own writes (LDS serves a wave in order)
+    const unsigned zero = lds(I.ring + M1_ZERO), trash = lds(I.ring + M1_TRASH);
+    const char* gb = (const char*)I.gbase;
+    auto goff = [&](const double* q) -> unsigned { return (unsigned)((const char*)q - gb); };
+    auto GL = [&](unsigned o, int off) -> double { return *(const double*)(gb + (size_t)o + (ptrdiff_t)(8 * off)); };
+    const unsigned gz = goff(I.gzero + 2);                                // HBM zero region
+    const int t0 = N - 1, tl = t0 & ~3;
+    // Jacobians, shared by both chains: fx(r, c); fu(r) in every column
+    unsigned afx = vnn ? lds(I.fx + tl * n * n + c * n + r) : zero;   const unsigned dfx = vnn ? 32u * n * n : 0u;     // per chunk
+    unsigned afu = vr ? lds(I.fu + tl * n + r) : zero;                const unsigned dfu = vr ? 32u * n : 0u;
+    struct Opnd { double fx, fu, c0, c1, c2; };       // c0.. : gxx, gux(c) in every row, guu (matrix chain) / gx(r) in every column, gu (vector chain)
+    Opnd A, B;
+    int t = t0, par = 0;
+
+    if constexpr (MAT) {
+        unsigned oxx = vnn ? goff(I.gxx + tl * n * n + c * n + r) : gz;   const unsigned dxx = vnn ? 32u * n * n : 0u;
+        unsigned oux = vc ? goff(I.gux + tl * n + c) : gz;                const unsigned dux = vc ? 32u * n : 0u;
+        unsigned ouu = goff(I.guu + tl);
+        // the one result store: row 0 -> ring Qux, row 1 -> K[t], row 2 -> ring ux_tmp
+        const bool toK = r == 1 && vc, toR = (r == 0 || r == 2) && vc;
+        unsigned ast = toK ? lds(I.K + tl * n + c) : (toR ? lds(I.ring + (r == 2 ? M1_RU : M1_RQ) + c) : trash);
+        const unsigned dA = toK ? (unsigned)(-32 * n) : (toR ? (unsigned)(32 * n) : 0u);      // to the next chunk, ring parity 0 -> 1
+        const unsigned dB = toK ? (unsigned)(-32 * n) : (toR ? (unsigned)(-32 * n) : 0u);     //                    ring parity 1 -> 0
+        unsigned asa = lds(I.ring + M1_RS);
+        double P = vnn ? I.gxx[N * n * n + c * n + r] : 0.0;              // P[H] .= gxx[H]  (:39)
+        if (STORE_VALUE && b0 && vnn) I.P[N * n * n + c * n + r] = P;
+        // per-lane multipliers of the stacked tiles (rows 0..3)
+        double c02 = (r == 0 || r == 2) ? 1.0 : 0.0, c1 = r == 1 ? 1.0 : 0.0, c12 = (r == 1 || r == 2) ? 1.0 : 0.0,
+               c0 = r == 0 ? 1.0 : 0.0, c2 = r == 2 ? 1.0 : 0.0, c013 = r != 2 ? 1.0 : 0.0, qmin = 1.0;
+        ILQR_OPAQUE(c02); ILQR_OPAQUE(c1); ILQR_OPAQUE(c12); ILQR_OPAQUE(c0); ILQR_OPAQUE(c2); ILQR_OPAQUE(c013);
+        auto fetch = [&](Opnd& o, int i) {                              // i = t & 3 of the step fetched
+            o.fx = LD(afx, i * n * n); o.fu = LD(afu, i * n);
+            o.c0 = GL(oxx, i * n * n); o.c1 = GL(oux, i * n); o.c2 = GL(ouu, i);
+        };
+        auto step = [&](const Opnd& o, int i) {
+            ILQR_ISA_MARK("riccati_step", ROLE);
+            const double W = mfma444(P, o.fx, 0.0);                     // W = P'ᵀ fx, WuR = P'ᵀ fuR   (:52-64)
+            const double WuR = mfma444(P, o.fu, 0.0);
+            const double Qxx = mfma444(W, o.fx, o.c0);
+            const double QuxR = mfma444(WuR, o.fx, o.c1);
+            const double q = mfma444(WuR, o.fu, o.c2);
+            const double sa = recip_fast(q);                            // potrf + potrs of the 1x1 system as b (1 / q), see backward_pass_split
+            // min over the pass of 1 / q: negative iff a pivot was (q = 0, NaN or Inf end as a NaN in P). Taken on the VALU result:
+            // hipcc puts no hazard wait states around inline asm, so asm must not read an MFMA result; __builtin_fmin would add
+            // two canonicalising v_max per step
+            asm("v_min_f64 %0, %1, %2" : "=v"(qmin) : "v"(qmin), "v"(sa));
+            const double mA = fma(c02, -sa, c1);                        // rows [-1/q, 1, -1/q, 0]
+            const double mB1 = fma(c12, -sa, c0);                       // rows [1, -1/q, -1/q, 0]
+            const double mB2 = fma(c2, q, c013);                        // rows [1, 1, q, 1]
+            const double A3 = QuxR * mA;                                // rows [K; Qux; K; 0]
+            const double B3 = (QuxR * mB1) * mB2;                       // rows [Qux; K; ux_tmp = K q; 0]   (:70-75, :79)
+            const double Pn = mfma444(A3, B3, Qxx);                     // (:81-84)
+            ST(ast, i * n, B3);
+            ST(asa, i, sa);
+            if constexpr (STORE_VALUE) {
+                if (b0) {
+                    if (vnn) I.P[t * n * n + c * n + r] = Pn;
+                    if (I.Q != nullptr) {                               // policy.action_value.* (src/data/policy.jl:58-64)
+                        if (vnn) I.Q[I.QL.Qxx + t * n * n + c * n + r] = Qxx;
+                        if (r == 0 && vc) I.Q[I.QL.Qux + t * n + c] = QuxR;
+                        if (r == 0 && c == 0) I.Q[I.QL.Quu + t] = q;
+                    }
+                }
+            }
+            P = Pn;
+            --t;
+        };
+        if (t0 & 1) fetch(A, t0 & 3); else fetch(B, t0 & 3);           // steps with odd t & 3 work on set A
+        for (int e = t0 & 3;; e = 3) {                                  // e: t & 3 of the chunk's first step (< 3 only in the first chunk)
+            switch (e) {
+                case 3: fetch(B, 2); step(A, 3); [[fallthrough]];
+                case 2: fetch(A, 1); step(B, 2); [[fallthrough]];
+                case 1: fetch(B, 0); step(A, 1); [[fallthrough]];
+                default:
+                    // bases to the chunk below and its first operands, unconditionally: below t = 0 these are reads inside this
+                    // instance's own LDS set and HBM block (every array fetched here sits behind x̄, ū) whose values are never used
+                    afx -= dfx; afu -= dfu; oxx -= dxx; oux -= dux; ouu -= 32u;
+                    fetch(A, 3); step(B, 0);
+            }
+            ast += par ? dB : dA;
+            asa += par ? (unsigned)(-32) : 32u;
+            par ^= 1;
+            ILQR_BAR_BEGIN();
+            __syncthreads();                                            // hand the chunk over (the other half of the ring is free again)
+            ILQR_BAR_END(I, PROF_DELTA);
+            if (t < 0) break;
+        }
+#ifdef ILQR_M1_NOREDO
+        if (lane == 0) { I.scal[S_PROF] = qmin; I.scal[S_PROF + 1] = (double)__popcll(__builtin_amdgcn_ballot_w64(P != P)); I.scal[S_PROF + 2] = (double)__popcll(__builtin_amdgcn_ballot_w64(!(qmin > 0.0))); }
+#endif
+        return __builtin_amdgcn_ballot_w64(!(qmin > 0.0) || P != P) != 0;
+    } else {
+        unsigned agx = vr ? lds(I.gx + tl * n + r) : zero;             const unsigned dgx = vr ? 32u * n : 0u;
+        unsigned agu = lds(I.gu + tl);
+        unsigned aK = vr ? lds(I.K + tl * n + r) : zero;               // K(r), Qux(r), ux_tmp(r) in every column
+        unsigned arq = vr ? lds(I.ring + M1_RQ + r) : zero;            const unsigned dq = vr ? 32u * n : 0u;
+        unsigned asa = lds(I.ring + M1_RS);
+        unsigned ak = lds(I.k + tl), aLu = lds(I.Lu + tl);
+        unsigned aLx = vr ? lds(I.Lx + tl * n + r) : trash;            const unsigned dLx = vr ? 32u * n : 0u;
+        double p = vr ? I.gx[N * n + r] : 0.0;                          // p[H] .= gx[H]   (:40), in every column
+        if (STORE_VALUE && b0 && vr && c == 0) I.p[N * n + r] = p;
+        double gmax = 0.0, nu = 0.0, dacc = 0.0;
+        unsigned long long nanmask = 0;     // ‖·‖∞ must propagate NaN like Julia's norm; v_max_f64 drops NaNs, so they are tracked beside it
+        auto fetch = [&](Opnd& o, int i) {
+            o.fx = LD(afx, i * n * n); o.fu = LD(afu, i * n);
+            o.c0 = LD(agx, i * n); o.c1 = LD(agu, i);
+        };
+        auto step = [&](const Opnd& o, int i) {
+            ILQR_ISA_MARK("riccati_step", ROLE);
+            const double Qx = mfma444(o.fx, p, o.c0);                   // Qx = fxᵀ p' + gx (every column), Qu = fuᵀ p' + gu (every lane)   (:44-49)
+            const double Qu = mfma444(o.fu, p, o.c1);
+            const double sa = LD(asa, i);
+            const double Kc = LD(aK, i * n), Quxc = LD(arq, i * n), uxtc = LD(arq, M1_RU - M1_RQ + i * n);
+            const double k = (Qu * sa) * -1.0;                          // (:72-75)
+            // p = ux_tmpᵀ k + Kᵀ Qu + Quxᵀ k + Qx   (:86-89), summed as ((Qx + Kᵀ Qu) + Quxᵀ k) + ux_tmpᵀ k like P
+            const double pn = fma(uxtc, k, fma(Quxc, k, fma(Kc, Qu, Qx)));
+            // lagrangian_gradient!: Lx = Qx - p[t], Lu = Qu   (src/solve.jl:73-81); the padding of Lx is exactly zero
+            const double Lx = Qx - pn;
+            // (Lx as a third operand: Qu is an MFMA result, and hipcc puts no hazard wait states around inline asm — behind Lx, which
+            // a chain of compiler-scheduled VALU instructions derives from Qu, the read is safe)
+            asm("v_max_f64 %0, %1, |%2|" : "=v"(gmax) : "v"(gmax), "v"(Lx));
+            asm("v_max_f64 %0, %1, |%2| ; %3" : "=v"(gmax) : "v"(gmax), "v"(Qu), "v"(Lx));
+            nanmask |= __builtin_amdgcn_ballot_w64(__builtin_isunordered(Lx, Qu));   // either one NaN
+            ST(ak, i, k); ST(aLu, i, Qu); ST(aLx, i * n, Lx);
+            // Δ = ∇Lᵀ·Δz as the adjoint of the sensitivity recursion (see backward_pass_split): w = ∇L_u + fuᵀν′, Δ += w k,
+            // ν = (∇L_x + fxᵀν′) + Kᵀ w
+            const double wv = mfma444(o.fu, nu, Qu);
+            dacc = fma(wv, k, dacc);
+            const double nun = mfma444(o.fx, nu, Lx);
+            nu = fma(Kc, wv, nun);
+            if constexpr (STORE_VALUE) {
+                if (b0 && c == 0) {
+                    if (vr) I.p[t * n + r] = pn;
+                    if (I.Q != nullptr) {
+                        if (vr) I.Q[I.QL.Qx + t * n + r] = Qx;
+                        if (r == 0) I.Q[I.QL.Qu + t] = Qu;
+                    }
+                }
+            }
+            p = pn;
+            --t;
+        };
+        if (t0 & 1) fetch(A, t0 & 3); else fetch(B, t0 & 3);
+        for (int e = t0 & 3;; e = 3) {
+            ILQR_BAR_BEGIN();
+            __syncthreads();                                            // this chunk of the ring is complete
+            ILQR_BAR_END(I, PROF_COST);
+            switch (e) {
+                case 3: fetch(B, 2); step(A, 3); [[fallthrough]];
+                case 2: fetch(A, 1); step(B, 2); [[fallthrough]];
+                case 1: fetch(B, 0); step(A, 1); [[fallthrough]];
+                default:
+                    afx -= dfx; afu -= dfu; agx -= dgx; agu -= 32u;
+                    fetch(A, 3); step(B, 0);
+            }
+            aK -= dq; ak -= 32u; aLu -= 32u; aLx -= dLx;
+            arq += par ? (0u - dq) : dq;
+            asa += par ? (unsigned)(-32) : 32u;
+            par ^= 1;
+            if (t < 0) break;
+        }
+        I.gradient_norm = wave_max(nanmask != 0 ? __builtin_nan("") : gmax);
+        I.delta_next = lane_bcast(dacc, 0);
+#ifdef ILQR_PROFILE_BAR
+        if (lane == 0) I.zs[7] += I.prof[PROF_COST];                    // wave 1's barrier waits, picked up by wave 0 at write-back
+        I.prof[PROF_COST] = 0.0;
+#endif
+        return false;
+    }
+}
+
 template <class M, bool STORE_VALUE>
 __device__ __forceinline__ void backward_pass(Inst<M>& I) {
     ILQR_PROF_BEGIN();
@@ -1120,14 +1345,39 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
             __syncthreads();
         } else {
             // matrix chain on wave 0, vector chain on wave 1 (one ring chunk behind); scalars through LDS
-            if (I.wave == 0) {
-                backward_pass_split<M, STORE_VALUE, 1>(I);
-                if (I.lane == 0) I.zs[3] = (double)I.potrf_info;
-            } else {
-                backward_pass_split<M, STORE_VALUE, 2>(I);
-                if (I.lane == 0) { I.zs[2] = I.gradient_norm; I.zs[5] = I.delta_next; }
+            bool literal = true;
+            if constexpr (M::NU == 1) {
+                // one action: the short form, which assumes positive pivots; a pass that met another kind is repeated literally
+                if (I.wave == 0) {
+                    const bool bad = backward_pass_m1<M, STORE_VALUE, 1>(I);
+                    if (I.lane == 0) { I.zs[6] = bad ? 1.0 : 0.0; I.zs[3] = (double)I.potrf_info; }
+                } else {
+                    backward_pass_m1<M, STORE_VALUE, 2>(I);
+                    if (I.lane == 0) { I.zs[2] = I.gradient_norm; I.zs[5] = I.delta_next; }
+                }
+                __syncthreads();
+                literal = I.zs[6] != 0.0;
+#ifdef ILQR_M1_NOREDO
+                literal = false;                                        // debugging aid: what the short form alone produces
+#endif
+#ifdef ILQR_PROFILE
+                if (literal) I.prof[PROF_DELTA] += 1.0;                 // (slot unused by the two-wave kernel: counts repeated passes)
+#endif
+                if (literal) {
+                    if (I.wave == 0 && I.lane == 0) I.scal[S_LITERAL_PASSES] += 1.0;
+                    __syncthreads();                                    // both waves have read the flag before the ring is reused
+                }
             }
-            __syncthreads();
+            if (literal) {
+                if (I.wave == 0) {
+                    backward_pass_split<M, STORE_VALUE, 1>(I);
+                    if (I.lane == 0) I.zs[3] = (double)I.potrf_info;
+                } else {
+                    backward_pass_split<M, STORE_VALUE, 2>(I);
+                    if (I.lane == 0) { I.zs[2] = I.gradient_norm; I.zs[5] = I.delta_next; }
+                }
+                __syncthreads();
+            }
             I.gradient_norm = I.zs[2]; I.potrf_info = (int)I.zs[3];
             I.delta_next = I.zs[5]; I.delta_next_ok = 1;
         }
@@ -1536,6 +1786,9 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
         for (int i = I.lane + 64 * I.wave; i < nd / 2; i += 64 * waves_of<M>::value) dst[i] = src[i];
         __syncthreads();
         if (I.lane == 0 && I.wave == 0) { I.zs[0] = 0.0; I.zs[1] = 0.0; }
+#ifdef ILQR_PROFILE_BAR
+        if (I.lane == 0 && I.wave == 0) I.zs[7] = 0.0;
+#endif
         if constexpr (slim_of<M>::value) { I.fx = g + L.fx; I.fu = g + L.fu; }
     }
     I.objective = I.scal[S_OBJECTIVE]; I.max_violation = I.scal[S_MAX_VIOLATION];
@@ -1569,6 +1822,9 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
         I.scal[S_DELTA] = I.delta;
 #ifdef ILQR_PROFILE
         for (int i = 0; i < PROF_N; ++i) I.scal[S_PROF + i] = I.prof[i];
+#ifdef ILQR_PROFILE_BAR
+        if constexpr (!is_large<M>::value) I.scal[S_PROF + PROF_COST] = I.zs[7];
+#endif
 #endif
     }
 }
@@ -1587,8 +1843,10 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
     }
     Inst<M> I;
     inst_setup<M>(I, a, smem, b);
-    if (!resumed) { I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0; }
-    else {
+    if (!resumed) {
+        I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0;
+        if (I.lane == 0 && I.wave == 0) I.scal[S_LITERAL_PASSES] = 0.0;
+    } else {
         I.trace_len = (int)I.scal[S_TRACE_LEN];
         // resumed at the head of an inner iteration: the first forward pass takes the Armijo product the packed kernel's backward
         // pass left behind (same adjoint form, same bits) instead of the forward sensitivity sweep

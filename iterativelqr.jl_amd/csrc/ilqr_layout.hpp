@@ -27,11 +27,17 @@ enum {
     // ... and, for a hand-over at the head of an inner iteration, the Armijo product ∇Lᵀ·Δz the backward pass produced for the
     // NEXT forward pass (adjoint form): the resumed launch uses this very number instead of summing it again in another order
     S_DELTA_NEXT = 25,
-    S_COUNT = 26
+    // backward passes of the last solve that the short nu = 1 form (backward_pass_m1) had to hand to the literal code because a
+    // pivot was not positive (0 on healthy instances; the two-wave latency kernel counts, the other kernels leave it alone)
+    S_LITERAL_PASSES = 26,
+    S_COUNT = 28
 };
 
 // Riccati hand-over between the two waves of a small-model instance: chunks of RING_STEPS timesteps, double-buffered
 enum { RING_STEPS = 4, RING_DOUBLES = 2 * RING_STEPS * 3 * 16 };
+// doubles of zeros behind Layout::gzero + 2 in every instance block: padding lanes of operands addressed with immediate offsets
+// (backward_pass_m1) aim there
+enum { GZERO_REGION = 32 };
 
 struct Layout {
     int T, nx, nu, nw, ncs, nct;
@@ -129,7 +135,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.P = o; o += pad2(T * nx * nx);
     L.p = o; o += pad2(T * nx);
     L.scal = o; o += S_COUNT;
-    L.gzero = o; o += 2;
+    L.gzero = o; o += 2 + GZERO_REGION;       // [0] a 0.0, [1] write-only trash (packed kernel), then GZERO_REGION zeros
     L.JV = 0; L.HS = 0; L.fv = L.hc = L.ab = o;
     if (is_large_model(nx, nu)) {
         L.JV = pad2(jac_nvar > 0 ? jac_nvar : 1); L.HS = pad2(hess_nnz > 0 ? hess_nnz : 1);
