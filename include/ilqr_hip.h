@@ -260,6 +260,12 @@ typedef struct {
 } ilqr_model_source;
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len);
 
+/* Test hook: evaluates one of the device-side scalar routines of csrc/ilqr_math.hpp on cuda device 0 — "recip_fast",
+ * "rsqrt_fast", "sqrt_fast" (the d of sqrt_rsqrt_fast), "sin_fast", "cos_fast" — elementwise, y[i] = f(x[i]). These replace
+ * IEEE division / sqrt and libm on the serial chains (src/rollout.jl:27-29, src/backward_pass.jl:68-75); the tests pin their
+ * values at 0, subnormal, huge and non-finite arguments against the IEEE results. Host pointers. */
+int ilqr_device_math(const char* fn, const double* x, double* y, int32_t n);
+
 /* Model registry (generated model modules call this from a static initialiser). */
 struct ilqr_model_vtable;
 int ilqr_register_model(const struct ilqr_model_vtable* vt);

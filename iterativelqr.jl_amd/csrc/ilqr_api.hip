@@ -252,11 +252,49 @@ int each_shard(ilqr_handle* h, F f, bool threaded = false) {
 }
 #define SHARDED(h) ((h) && !(h)->shards.empty())
 
+// test hook (ilqr_device_math): the scalar routines of ilqr_math.hpp as the device executes them
+__global__ void device_math_kernel(int which, const double* x, double* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double r = 0.0, s, c;
+    switch (which) {
+        case 0: r = ilqr::recip_fast(v); break;
+        case 1: r = ilqr::rsqrt_fast(v); break;
+        case 2: ilqr::sqrt_rsqrt_fast(v, r, s); break;
+        case 3: ilqr::sincos_fast(v, r, c); break;
+        default: ilqr::sincos_fast(v, s, r); break;
+    }
+    y[i] = r;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* ilqr_last_error(void) { return g_err.c_str(); }
+
+int ilqr_device_math(const char* fn, const double* x, double* y, int32_t n) {
+    static const char* names[] = {"recip_fast", "rsqrt_fast", "sqrt_fast", "sin_fast", "cos_fast"};
+    int which = -1;
+    for (int i = 0; i < 5; ++i)
+        if (fn && !std::strcmp(fn, names[i])) which = i;
+    if (which < 0 || !x || !y || n < 0) return fail(ILQR_ERR_INVALID, "ilqr_device_math: unknown function or null argument");
+    if (ilqr_device_count() < 1) return fail(ILQR_ERR_NO_DEVICE, "no HIP device");
+    if (n == 0) return ILQR_OK;
+    double *dx = nullptr, *dy = nullptr;
+    hipError_t e;
+    auto bail = [&](hipError_t err, const char* what) { if (dx) (void)hipFree(dx); if (dy) (void)hipFree(dy); return fail(ILQR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    if ((e = hipSetDevice(0)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipMalloc(&dx, (size_t)n * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&dy, (size_t)n * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    hipLaunchKernelGGL(device_math_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, which, dx, dy, n);
+    if ((e = hipGetLastError()) != hipSuccess) return bail(e, "launch");
+    if ((e = hipMemcpy(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost)) != hipSuccess) return bail(e, "hipMemcpy");
+    (void)hipFree(dx); (void)hipFree(dy);
+    return ILQR_OK;
+}
 
 int ilqr_device_count(void) {
     int n = 0;

@@ -1194,17 +1194,25 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
         double c02 = (r == 0 || r == 2) ? 1.0 : 0.0, c1 = r == 1 ? 1.0 : 0.0, c12 = (r == 1 || r == 2) ? 1.0 : 0.0,
                c0 = r == 0 ? 1.0 : 0.0, c2 = r == 2 ? 1.0 : 0.0, c013 = r != 2 ? 1.0 : 0.0, qmin = 1.0;
         ILQR_OPAQUE(c02); ILQR_OPAQUE(c1); ILQR_OPAQUE(c12); ILQR_OPAQUE(c0); ILQR_OPAQUE(c2); ILQR_OPAQUE(c013);
+        // LDS operands one step ahead on two sets (A: odd t & 3, B: even); the accumulated Hessians come from HBM / L2, whose round
+        // trip is longer than a step of this form: TWO steps ahead, four sets (G0..G3 by t & 3), the chunk below at negative immediates
+        struct Hess { double xx, ux, uu; };
+        Hess G0, G1, G2, G3;
         auto fetch = [&](Opnd& o, int i) {                              // i = t & 3 of the step fetched
             o.fx = LD(afx, i * n * n); o.fu = LD(afu, i * n);
-            o.c0 = GL(oxx, i * n * n); o.c1 = GL(oux, i * n); o.c2 = GL(ouu, i);
         };
-        auto step = [&](const Opnd& o, int i) {
+        auto fetch_g = [&](int i) -> Hess {                             // i = t & 3 of the step fetched, -4..-1: in the chunk below
+            Hess g;
+            g.xx = GL(oxx, i * n * n); g.ux = GL(oux, i * n); g.uu = GL(ouu, i);
+            return g;
+        };
+        auto step = [&](const Opnd& o, const Hess& g, int i) {
             ILQR_ISA_MARK("riccati_step", ROLE);
             const double W = mfma444(P, o.fx, 0.0);                     // W = P'ᵀ fx, WuR = P'ᵀ fuR   (:52-64)
             const double WuR = mfma444(P, o.fu, 0.0);
-            const double Qxx = mfma444(W, o.fx, o.c0);
-            const double QuxR = mfma444(WuR, o.fx, o.c1);
-            const double q = mfma444(WuR, o.fu, o.c2);
+            const double Qxx = mfma444(W, o.fx, g.xx);
+            const double QuxR = mfma444(WuR, o.fx, g.ux);
+            const double q = mfma444(WuR, o.fu, g.uu);
             const double sa = recip_fast(q);                            // potrf + potrs of the 1x1 system as b (1 / q), see backward_pass_split
             // min over the pass of 1 / q: negative iff a pivot was (q = 0, NaN or Inf end as a NaN in P). Taken on the VALU result:
             // hipcc puts no hazard wait states around inline asm, so asm must not read an MFMA result; __builtin_fmin would add
@@ -1232,17 +1240,24 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             --t;
         };
         if (t0 & 1) fetch(A, t0 & 3); else fetch(B, t0 & 3);           // steps with odd t & 3 work on set A
+        switch (t0 & 3) {                                               // Hessians of the first two steps
+            case 3: G3 = fetch_g(3); G2 = fetch_g(2); break;
+            case 2: G2 = fetch_g(2); G1 = fetch_g(1); break;
+            case 1: G1 = fetch_g(1); G0 = fetch_g(0); break;
+            default: G0 = fetch_g(0); G3 = fetch_g(-1);
+        }
         for (int e = t0 & 3;; e = 3) {                                  // e: t & 3 of the chunk's first step (< 3 only in the first chunk)
+            // requests below t = 0 are reads inside this instance's own LDS set and HBM block (every array fetched here sits behind
+            // x̄, ū) whose values are never used
             switch (e) {
-                case 3: fetch(B, 2); step(A, 3); [[fallthrough]];
-                case 2: fetch(A, 1); step(B, 2); [[fallthrough]];
-                case 1: fetch(B, 0); step(A, 1); [[fallthrough]];
+                case 3: fetch(B, 2); G1 = fetch_g(1); step(A, G3, 3); [[fallthrough]];
+                case 2: fetch(A, 1); G0 = fetch_g(0); step(B, G2, 2); [[fallthrough]];
+                case 1: fetch(B, 0); G3 = fetch_g(-1); step(A, G1, 1); [[fallthrough]];
                 default:
-                    // bases to the chunk below and its first operands, unconditionally: below t = 0 these are reads inside this
-                    // instance's own LDS set and HBM block (every array fetched here sits behind x̄, ū) whose values are never used
-                    afx -= dfx; afu -= dfu; oxx -= dxx; oux -= dux; ouu -= 32u;
-                    fetch(A, 3); step(B, 0);
+                    afx -= dfx; afu -= dfu;
+                    fetch(A, 3); G2 = fetch_g(-2); step(B, G0, 0);
             }
+            oxx -= dxx; oux -= dux; ouu -= 32u;
             ast += par ? dB : dA;
             asa += par ? (unsigned)(-32) : 32u;
             par ^= 1;

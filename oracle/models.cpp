@@ -90,6 +90,18 @@ struct PendulumEulerF {
     }
 };
 
+// A pendulum with a POLE in its dynamics (no reference counterpart: a test model for what a division by zero, or by something
+// tiny, inside f does to a solve — IEEE gives +-Inf there and the reference carries it on, src/rollout.jl:27-29)
+struct PendulumPoleF {
+    template <class S> void operator()(const S* x, const S* u, S* y) const {
+        const double h = 0.1;
+        S f0 = x[1];
+        S f1 = u[0] - sin(x[0]) - 0.1 * x[1] + 0.001 / (x[0] - 0.3);
+        y[0] = x[0] + h * f0;
+        y[1] = x[1] + h * f1;
+    }
+};
+
 // ----------------------------------------------------------------- acrobot
 // test/acrobot.jl:9-74
 template <class S>
@@ -412,6 +424,12 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
         z->kt.num_state = 2; z->kt.ctx = &z->goal;
     } else if (!std::strcmp(name, "pendulum_euler")) {
         z->dyn = make_dynamics<2, 1, PendulumEulerF>();
+        quad_init(&z->qs, 2, 1); quad_init(&z->qt, 2, 0);
+        for (int i = 0; i < 2; ++i) { z->qs.q[i] = 1.0; z->qt.q[i] = 10.0; }
+        z->qs.r[0] = 0.1;
+        constrained = false;
+    } else if (!std::strcmp(name, "pendulum_pole")) {
+        z->dyn = make_dynamics<2, 1, PendulumPoleF>();
         quad_init(&z->qs, 2, 1); quad_init(&z->qt, 2, 0);
         for (int i = 0; i < 2; ++i) { z->qs.q[i] = 1.0; z->qt.q[i] = 10.0; }
         z->qs.r[0] = 0.1;

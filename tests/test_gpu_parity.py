@@ -1280,3 +1280,164 @@ def test_c_callables_define_a_large_path_model(pkg, oracle, tmp_path):
     out = subprocess.run([exe, os.path.join(root, "examples", "synth12_model.c")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert out.returncode == 0, out.stdout.decode()[-2000:]
     assert b"max |dx| = 0.000e+00" in out.stdout
+
+
+def test_synth32_literal_config5_shard_against_the_oracle(pkg, oracle):
+    """BASELINE configs[4] exactly as SURVEY §8(d) states it and as `bench.py --config synth32` and profiles/r0x_synth32* measure
+    it: x1 ~ 0.5 N(0,1), ū = 0 (NOT perturbed), default tolerances, the 512-instance shard of rank 5. Every instance against the
+    oracle: control flow identical on >= 99 %, |Δx|, |Δu| <= 1e-7, |ΔK| <= 5e-7 max|K| (src/solve.jl:88-129, whole solve)."""
+    B = 512
+    model, T, x1, ub = pkg.workloads.make_inputs("synth32", B, offset=5 * B)
+    assert not ub.any()
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); K, _ = sol.get_policy(); st = sol.stats()
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=8)
+    rs = ref["stats"]
+    same = (st["iterations"] == rs["iterations"]) & (st["outer_iterations"] == rs["outer_iterations"]) \
+        & (st["rollouts"] == rs["rollouts"]) & (st["status"] == rs["status"])
+    assert same.mean() >= 0.99, same.mean()
+    assert np.abs(x - ref["x"])[same].max() <= 1e-7 and np.abs(u - ref["u"])[same].max() <= 1e-7
+    assert np.abs(K - ref["K"])[same].max() <= 5e-7 * np.abs(ref["K"]).max()
+    assert (st["potrf_info"] == 0).all() and (rs["potrf_info"] == 0).all()
+    sol.close()
+
+
+@pytest.mark.parametrize("config,col", [("synth32", 0), ("synth32", 5)])
+def test_large_path_backward_pass_with_a_failed_pivot(pkg, oracle, config, col):
+    """The reference ignores potrf's return code (src/backward_pass.jl:68-69): when Quu is not positive definite, K and k are what
+    potrs makes of the partly factored matrix dpotf2 leaves behind, and the recursion goes on with them. The large path takes
+    that case on a branch of its own (ilqr_device_large.hpp: failed pivot -> the literal dpotf2 sequence and LDS-resident solves);
+    here guu gets a negative diagonal entry at three timesteps (pivot `col` + 1 fails first), and potrf_info, K, k, P, p and the
+    Lagrangian gradient must be the oracle's."""
+    B = 3
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+    ub = ub + 1.2 * np.sin(np.arange(ub.size).reshape(ub.shape))
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.initialize_rollout_(x1, ub)
+    refs = [_oracle_solver(oracle, model, T, x1[b], ub[b])[1] for b in range(B)]
+    n, m = sol.nx, sol.nu
+    for r in refs:
+        r.call("reset_model_objective"); r.call("cost_bang", 0); r.call("gradients")
+    for b, r in enumerate(refs):
+        guu = r.buffer("hessian_action_action").reshape(T - 1, m, m).copy()
+        for t in ((T - 2, T // 2, 3) if b < 2 else ()):              # the third instance stays positive definite
+            guu[t, col, col] = -5.0 - b
+        r.set_buffer("hessian_action_action", guu)
+    _sync_from_oracle(sol, refs, T)
+    sol.run_stage_("backward_pass")
+    for r in refs:
+        r.call("backward_pass"); r.call("lagrangian_gradient")
+    st = sol.stats()
+    want = np.array([r.stats().potrf_info for r in refs])
+    assert (want[:2] == col + 1).all() and want[2] == 0
+    assert np.array_equal(st["potrf_info"], want)
+    for name in ("K", "k", "P", "p"):
+        gb = sol.buffer(name)
+        for b in range(B):
+            assert _rel(gb[b], refs[b].buffer(name)) < 1e-8, (name, b, _rel(gb[b], refs[b].buffer(name)))
+    Lx = sol.buffer("gradient_state_lagrangian"); Lu = sol.buffer("gradient_action_lagrangian")
+    for b in range(B):
+        g = refs[b].buffer("gradient")
+        assert _rel(Lx[b], g[:(T - 1) * n]) < 1e-8 and _rel(Lu[b], g[T * n:]) < 1e-8
+    sol.close()
+
+
+def test_one_action_backward_pass_with_a_failed_pivot_is_repeated_literally(pkg, oracle):
+    """Latency kernel, models with one action: the short form of the Riccati recursion (backward_pass_m1) assumes positive pivots
+    and a pass that meets another kind is repeated by the literal code. Acrobot with guu < 0 at two timesteps: potrf_info, K, k,
+    P, p against the oracle (src/backward_pass.jl:68-75: LAPACK leaves q on the diagonal, potrs divides by it twice); the
+    healthy instance beside them takes the short form alone, and a whole solve counts no repeated pass."""
+    B = 3
+    model, T, x1, ub = pkg.workloads.make_inputs("acrobot51", B)
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.set_kernel_variant_("latency")
+    sol.initialize_rollout_(x1, ub)
+    refs = [_oracle_solver(oracle, model, T, x1[b], ub[b])[1] for b in range(B)]
+    n, m = sol.nx, sol.nu
+    for r in refs:
+        r.call("reset_model_objective"); r.call("cost_bang", 0); r.call("gradients")
+    for b, r in enumerate(refs[:2]):
+        guu = r.buffer("hessian_action_action").copy()
+        guu[[T - 3, 7]] = -50.0 - 10.0 * b
+        r.set_buffer("hessian_action_action", guu)
+    _sync_from_oracle(sol, refs, T)
+    sol.run_stage_("backward_pass")
+    for r in refs:
+        r.call("backward_pass"); r.call("lagrangian_gradient")
+    want = np.array([r.stats().potrf_info for r in refs])
+    assert (want[:2] == 1).all() and want[2] == 0
+    assert np.array_equal(sol.stats()["potrf_info"], want)
+    for name in ("K", "k", "P", "p"):
+        gb = sol.buffer(name)
+        for b in range(B):
+            assert _rel(gb[b], refs[b].buffer(name)) < 1e-8, (name, b)
+    sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()
+    assert (sol.scalar("literal_backward_passes") == 0).all() and (sol.stats()["potrf_info"] == 0).all()
+    sol.close()
+
+
+def test_device_reciprocal_and_rsqrt_at_special_values(pkg):
+    """ilqr::recip_fast / rsqrt_fast / sqrt_rsqrt_fast (v_rcp_f64 / v_rsq_f64 + Newton steps) replace IEEE division and sqrt on
+    the serial chains (src/rollout.jl:27-29 through the generated dynamics, src/backward_pass.jl:68-75). On ordinary arguments they
+    are within 1.5 ulp of IEEE; this pins what they return where IEEE gives a special value, as documented in DESIGN.md §6."""
+    import ctypes as C
+    L = pkg._ffi.lib()
+
+    def run(fn, xs):
+        xs = np.ascontiguousarray(xs, dtype=np.float64); ys = np.empty_like(xs)
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        pkg._ffi.check(L.ilqr_device_math(fn.encode(), p(xs), p(ys), len(xs)))
+        return ys
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(1e-3, 1e3, 4000), -rng.uniform(1e-3, 1e3, 1000), 10.0 ** rng.uniform(-280, 280, 2000)])
+    r = run("recip_fast", xs)
+    assert (np.abs(r - 1.0 / xs) <= 1.5 * np.spacing(np.abs(1.0 / xs))).all()
+    pos = np.abs(xs)
+    assert (np.abs(run("rsqrt_fast", pos) - 1.0 / np.sqrt(pos)) <= 2.0 * np.spacing(1.0 / np.sqrt(pos))).all()
+    assert (np.abs(run("sqrt_fast", pos) - np.sqrt(pos)) <= 1.0 * np.spacing(np.sqrt(pos))).all()
+    tiny = np.nextafter(0.0, 1.0)
+    sp = np.array([0.0, -0.0, tiny, -tiny, 1e-310, 1e308, -1e308, np.inf, -np.inf, np.nan])
+    with np.errstate(all="ignore"):
+        ieee = 1.0 / sp
+    r = run("recip_fast", sp)
+    # IEEE: +-Inf at +-0 and at subnormals whose reciprocal overflows, a subnormal at 1e308, +-0 at +-Inf. The Newton step turns the
+    # infinite ones into NaN (0 * Inf) and flushes the subnormal result: a NaN where the reference would carry an Inf — an
+    # instance that is diverged in the reference too (the Inf becomes a NaN one operation later: Inf - Inf, 0 * Inf, sin(Inf))
+    assert np.isinf(ieee[:4]).all() and np.isnan(r[:4]).all()
+    assert np.isnan(r[4]) or np.isinf(r[4])
+    assert abs(r[5]) <= 1.0e-307 and abs(r[6]) <= 1.0e-307 and np.isnan(r[9])
+    assert np.isnan(r[7:9]).all() or (r[7:9] == 0.0).all()
+    rs = run("rsqrt_fast", np.array([0.0, tiny, 1e-310, np.inf, np.nan]))
+    assert np.isnan(rs[[0, 4]]).all() or (np.isinf(rs[0]) and np.isnan(rs[4]))     # IEEE 1/sqrt(0) = Inf; callers test the pivot first
+    sn, cs = run("sin_fast", np.array([0.0, np.inf, np.nan, 1e300])), run("cos_fast", np.array([0.0, np.inf, np.nan, 1e300]))
+    assert sn[0] == 0.0 and cs[0] == 1.0 and np.isnan(sn[1:3]).all() and np.isnan(cs[1:3]).all() and abs(sn[3]) <= 1.0
+
+
+def test_dynamics_with_a_pole_against_the_oracle(pkg, oracle):
+    """A dynamics with a division whose denominator is exactly zero at the initial state of some instances, close to zero on the
+    way of others (pendulum_pole, oracle/models.cpp): IEEE division in the oracle and in the per-lane model code, recip_fast on
+    the cooperative rollout path. Instances that hit the pole exactly are diverged in both (NaN objective, same counts);
+    every other instance must agree as any model does."""
+    import sympy as sp
+    T, B = 21, 24
+    dyn = pkg.Dynamics(lambda x, u: [x[0] + 0.1 * x[1], x[1] + 0.1 * (u[0] - sp.sin(x[0]) - 0.1 * x[1] + 0.001 / (x[0] - 0.3))], 2, 1)
+    stage = pkg.Cost(lambda x, u: x[0] * x[0] + x[1] * x[1] + 0.1 * u[0] * u[0], 2, 1)
+    term = pkg.Cost(lambda x, u: 10.0 * (x[0] * x[0] + x[1] * x[1]), 2, 0)
+    rng = np.random.default_rng(11)
+    x1 = np.stack([rng.uniform(-0.2, 0.6, B), rng.uniform(-0.5, 0.5, B)], 1)
+    x1[0] = [0.3, 0.0]; x1[1] = [0.3, 0.2]                         # denominator exactly zero at t = 1
+    x1[2] = [0.25, 0.5]                                             # x0 reaches 0.3 exactly after one step: 0.25 + 0.1 * 0.5
+    ub = 0.05 * rng.standard_normal((B, T - 1, 1))
+    sol = pkg.Solver([dyn] * (T - 1), [stage] * (T - 1) + [term], batch=B, options=pkg.Options(verbose=0), name="user_pendulum_pole")
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); st = sol.stats()
+    ref = oracle.solve_batch("pendulum_pole", T, x1, ub, nthreads=4)
+    rs = ref["stats"]
+    for k in ("iterations", "rollouts", "status"):
+        assert np.array_equal(st[k], rs[k]), (k, st[k], rs[k])
+    dead = ~np.isfinite(ref["x"]).all(axis=(1, 2))
+    assert dead[:2].all() and not dead[3:].all()
+    assert np.array_equal(np.isfinite(x).all(axis=(1, 2)), ~dead)
+    assert np.abs(x - ref["x"])[~dead].max() < 1e-8 and np.abs(u - ref["u"])[~dead].max() < 1e-8
+    sol.close()
