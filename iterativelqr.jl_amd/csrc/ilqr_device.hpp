@@ -108,6 +108,11 @@ template <class M> struct slim_of<M, decltype((void)M::SLIM)> { static constexpr
 // 1 k-cycle step cannot pay for a barrier), the large-model one splits its MFMA tiles. Scalars produced by one
 // wave are handed to the other through LDS.
 template <class M> struct waves_of { static constexpr int value = is_large<M>::value ? LARGE_WAVES : (slim_of<M>::value ? 1 : 2); };
+// Two-wave latency kernel, models with one action: the Lagrangian gradient ∇L (src/solve.jl:67-83) is written straight to its place
+// in the instance's HBM block by the short Riccati form (backward_pass_m1) and never kept current in LDS — nothing reads it back
+// inside a launch (‖∇L‖∞ and ∇Lᵀ·Δz are carried in registers); the LDS copy a launch starts with (loaded with the rest of the set)
+// serves the stage kernels' forward sensitivity sweep, and the write-back leaves the HBM values alone.
+template <class M> struct lagrangian_home_is_hbm { static constexpr bool value = !is_large<M>::value && !slim_of<M>::value && M::NU == 1; };
 
 // parameters of timestep t (empty when NW == 0)
 template <int NW>
@@ -173,6 +178,7 @@ struct Inst {
     double *gxx, *guu, *gux, *P, *p, *scal;
     double *gbase;         // HBM: this instance's workspace block
     int fv_off, hc_off;    // large path: offsets of the compact Jacobian / Hessian rows inside the block
+    int hLx, hLu;          // offsets of the Lagrangian gradient inside the block (see lagrangian_home_is_hbm)
     double *zs;            // LDS: zs[0] == 0.0 always, zs[1] is a write-only trash slot
     double *ring;          // LDS: Riccati hand-over ring between the two waves (small path)
     double *lds;           // large path: LDS staging area (the workspace itself stays in HBM)
@@ -1143,7 +1149,7 @@ __device__ void backward_pass_split(Inst<M>& I) {
 // first one may be short) and step t uses the immediate offset (t & 3) * stride; bases move once per chunk. Padding lanes
 // (nx < 4) aim at a zero REGION long enough for those offsets (LDS: in the ring area, zeroed by each wave before its pass; HBM:
 // behind Layout::gzero), result lanes that store nothing at a trash region.
-enum { M1_RQ = 0, M1_RU = 32, M1_RS = 64, M1_TRASH = 80, M1_ZERO = 128, M1_ZERO_N = 48 };    // doubles from Inst::ring
+enum { M1_RQ = 0, M1_RU = 32, M1_RS = 64, M1_TRASH = 96, M1_ZERO = 128, M1_ZERO_N = 80 };    // doubles from Inst::ring (every row 8 slots of nx)
 static_assert(M1_ZERO + M1_ZERO_N <= RING_DOUBLES, "nu = 1 ring map fits the ring");
 template <class M, bool STORE_VALUE, int ROLE>
 __device__ bool backward_pass_m1(Inst<M>& I) {
@@ -1152,7 +1158,7 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
     static_assert(ROLE == 1 || ROLE == 2, "two-wave recursion");
     static_assert(M::NU == 1 && n <= 4 && !slim_of<M>::value, "LDS-resident small models with one action");
     static_assert(RING_STEPS == 4, "chunks of four steps");
-    static_assert(n == 4 || (3 * n * n < GZERO_REGION && M1_RU + 3 * n < M1_ZERO_N), "zero regions cover the largest immediate offset (nx = 4 has no padding lanes)");
+    static_assert(n == 4 || (3 * n * n < GZERO_REGION && M1_RS + 3 * n < M1_ZERO_N && 3 * n < GTRASH_REGION), "zero regions cover the largest immediate offset (nx = 4 has no padding lanes)");
     typedef __attribute__((address_space(3))) double ldsd;
     const int lane = I.lane, r = lane >> 4, c = lane & 3;
     const bool vnn = r < n && c < n, vr = r < n, vc = c < n, b0 = ((lane >> 2) & 3) == 0;
@@ -1164,7 +1170,9 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
     auto lds = [](const double* q) -> unsigned { return (unsigned)(size_t)(const ldsd*)q; };
     auto LD = [](unsigned a, int off) -> double { return *(const ldsd*)(size_t)(a + 8u * off); };
     auto ST = [](unsigned a, int off, double v) { *(ldsd*)(size_t)(a + 8u * off) = v; };
-    if (n < 4 && lane < M1_ZERO_N) I.ring[M1_ZERO + lane] = 0.0;      // this wave's own reads follow its own writes (LDS serves a wave in order)
+    if (n < 4) {
+        for (int i = lane; i < M1_ZERO_N; i += 64) I.ring[M1_ZERO + i] = 0.0;   // this wave's own reads follow its own writes (LDS serves a wave in order)
+    }
     const unsigned zero = lds(I.ring + M1_ZERO), trash = lds(I.ring + M1_TRASH);
     const char* gb = (const char*)I.gbase;
     auto goff = [&](const double* q) -> unsigned { return (unsigned)((const char*)q - gb); };
@@ -1182,18 +1190,17 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
         unsigned oxx = vnn ? goff(I.gxx + tl * n * n + c * n + r) : gz;   const unsigned dxx = vnn ? 32u * n * n : 0u;
         unsigned oux = vc ? goff(I.gux + tl * n + c) : gz;                const unsigned dux = vc ? 32u * n : 0u;
         unsigned ouu = goff(I.guu + tl);
-        // the one result store: row 0 -> ring Qux, row 1 -> K[t], row 2 -> ring ux_tmp
-        const bool toK = r == 1 && vc, toR = (r == 0 || r == 2) && vc;
-        unsigned ast = toK ? lds(I.K + tl * n + c) : (toR ? lds(I.ring + (r == 2 ? M1_RU : M1_RQ) + c) : trash);
+        // the ONE result store: row 0 -> ring Qux, row 1 -> K[t], row 2 -> ring ux_tmp, row 3 -> ring 1 / q
+        const bool toK = r == 1 && vc, toR = (r != 1) && vc;
+        unsigned ast = toK ? lds(I.K + tl * n + c) : (toR ? lds(I.ring + (r == 0 ? M1_RQ : (r == 2 ? M1_RU : M1_RS)) + c) : trash);
         const unsigned dA = toK ? (unsigned)(-32 * n) : (toR ? (unsigned)(32 * n) : 0u);      // to the next chunk, ring parity 0 -> 1
         const unsigned dB = toK ? (unsigned)(-32 * n) : (toR ? (unsigned)(-32 * n) : 0u);     //                    ring parity 1 -> 0
-        unsigned asa = lds(I.ring + M1_RS);
         double P = vnn ? I.gxx[N * n * n + c * n + r] : 0.0;              // P[H] .= gxx[H]  (:39)
         if (STORE_VALUE && b0 && vnn) I.P[N * n * n + c * n + r] = P;
         // per-lane multipliers of the stacked tiles (rows 0..3)
         double c02 = (r == 0 || r == 2) ? 1.0 : 0.0, c1 = r == 1 ? 1.0 : 0.0, c12 = (r == 1 || r == 2) ? 1.0 : 0.0,
-               c0 = r == 0 ? 1.0 : 0.0, c2 = r == 2 ? 1.0 : 0.0, c013 = r != 2 ? 1.0 : 0.0, qmin = 1.0;
-        ILQR_OPAQUE(c02); ILQR_OPAQUE(c1); ILQR_OPAQUE(c12); ILQR_OPAQUE(c0); ILQR_OPAQUE(c2); ILQR_OPAQUE(c013);
+               c0 = r == 0 ? 1.0 : 0.0, c2 = r == 2 ? 1.0 : 0.0, c013 = r != 2 ? 1.0 : 0.0, c3 = r == 3 ? 1.0 : 0.0, qmin = 1.0;
+        ILQR_OPAQUE(c02); ILQR_OPAQUE(c1); ILQR_OPAQUE(c12); ILQR_OPAQUE(c0); ILQR_OPAQUE(c2); ILQR_OPAQUE(c013); ILQR_OPAQUE(c3);
         // LDS operands one step ahead on two sets (A: odd t & 3, B: even); the accumulated Hessians come from HBM / L2, whose round
         // trip is longer than a step of this form: TWO steps ahead, four sets (G0..G3 by t & 3), the chunk below at negative immediates
         struct Hess { double xx, ux, uu; };
@@ -1222,10 +1229,11 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             const double mB1 = fma(c12, -sa, c0);                       // rows [1, -1/q, -1/q, 0]
             const double mB2 = fma(c2, q, c013);                        // rows [1, 1, q, 1]
             const double A3 = QuxR * mA;                                // rows [K; Qux; K; 0]
-            const double B3 = (QuxR * mB1) * mB2;                       // rows [Qux; K; ux_tmp = K q; 0]   (:70-75, :79)
+            // rows [Qux; K; ux_tmp = K q; 1 / q]   (:70-75, :79) — the fourth row rides along for the vector chain: it meets the zero
+            // row of A3 in the product
+            const double B3 = fma(QuxR * mB1, mB2, c3 * sa);
             const double Pn = mfma444(A3, B3, Qxx);                     // (:81-84)
             ST(ast, i * n, B3);
-            ST(asa, i, sa);
             if constexpr (STORE_VALUE) {
                 if (b0) {
                     if (vnn) I.P[t * n * n + c * n + r] = Pn;
@@ -1259,7 +1267,6 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             }
             oxx -= dxx; oux -= dux; ouu -= 32u;
             ast += par ? dB : dA;
-            asa += par ? (unsigned)(-32) : 32u;
             par ^= 1;
             ILQR_BAR_BEGIN();
             __syncthreads();                                            // hand the chunk over (the other half of the ring is free again)
@@ -1276,8 +1283,13 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
         unsigned aK = vr ? lds(I.K + tl * n + r) : zero;               // K(r), Qux(r), ux_tmp(r) in every column
         unsigned arq = vr ? lds(I.ring + M1_RQ + r) : zero;            const unsigned dq = vr ? 32u * n : 0u;
         unsigned asa = lds(I.ring + M1_RS);
-        unsigned ak = lds(I.k + tl), aLu = lds(I.Lu + tl);
-        unsigned aLx = vr ? lds(I.Lx + tl * n + r) : trash;            const unsigned dLx = vr ? 32u * n : 0u;
+        unsigned ak = lds(I.k + tl);
+        // the Lagrangian gradient goes straight to its place in the instance's HBM block (plain stores, nobody in the workgroup
+        // reads it back during a solve: ‖∇L‖∞ and ∇Lᵀ·Δz are carried in registers) — an LDS store costs the wave 25 clk with the
+        // CUs busy (profiles/r02_probe_lds.txt), a global one its issue slot
+        unsigned oLu = goff(I.gbase + I.hLu + tl);
+        unsigned oLx = vr ? goff(I.gbase + I.hLx + tl * n + r) : goff(I.gzero + 2 + GZERO_REGION);   const unsigned dLx = vr ? 32u * n : 0u;
+        auto GS = [&](unsigned o, int off, double v) { *(double*)(const_cast<char*>(gb) + (size_t)o + (ptrdiff_t)(8 * off)) = v; };
         double p = vr ? I.gx[N * n + r] : 0.0;                          // p[H] .= gx[H]   (:40), in every column
         if (STORE_VALUE && b0 && vr && c == 0) I.p[N * n + r] = p;
         double gmax = 0.0, nu = 0.0, dacc = 0.0;
@@ -1290,7 +1302,7 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             ILQR_ISA_MARK("riccati_step", ROLE);
             const double Qx = mfma444(o.fx, p, o.c0);                   // Qx = fxᵀ p' + gx (every column), Qu = fuᵀ p' + gu (every lane)   (:44-49)
             const double Qu = mfma444(o.fu, p, o.c1);
-            const double sa = LD(asa, i);
+            const double sa = LD(asa, i * n);
             const double Kc = LD(aK, i * n), Quxc = LD(arq, i * n), uxtc = LD(arq, M1_RU - M1_RQ + i * n);
             const double k = (Qu * sa) * -1.0;                          // (:72-75)
             // p = ux_tmpᵀ k + Kᵀ Qu + Quxᵀ k + Qx   (:86-89), summed as ((Qx + Kᵀ Qu) + Quxᵀ k) + ux_tmpᵀ k like P
@@ -1302,7 +1314,7 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             asm("v_max_f64 %0, %1, |%2|" : "=v"(gmax) : "v"(gmax), "v"(Lx));
             asm("v_max_f64 %0, %1, |%2| ; %3" : "=v"(gmax) : "v"(gmax), "v"(Qu), "v"(Lx));
             nanmask |= __builtin_amdgcn_ballot_w64(__builtin_isunordered(Lx, Qu));   // either one NaN
-            ST(ak, i, k); ST(aLu, i, Qu); ST(aLx, i * n, Lx);
+            ST(ak, i, k); GS(oLu, i, Qu); GS(oLx, i * n, Lx);
             // Δ = ∇Lᵀ·Δz as the adjoint of the sensitivity recursion (see backward_pass_split): w = ∇L_u + fuᵀν′, Δ += w k,
             // ν = (∇L_x + fxᵀν′) + Kᵀ w
             const double wv = mfma444(o.fu, nu, Qu);
@@ -1334,9 +1346,9 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
                     afx -= dfx; afu -= dfu; agx -= dgx; agu -= 32u;
                     fetch(A, 3); step(B, 0);
             }
-            aK -= dq; ak -= 32u; aLu -= 32u; aLx -= dLx;
+            aK -= dq; ak -= 32u; oLu -= 32u; oLx -= dLx;
             arq += par ? (0u - dq) : dq;
-            asa += par ? (unsigned)(-32) : 32u;
+            asa += par ? (unsigned)(-32 * n) : 32u * n;
             par ^= 1;
             if (t < 0) break;
         }
@@ -1392,6 +1404,10 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
                     if (I.lane == 0) { I.zs[2] = I.gradient_norm; I.zs[5] = I.delta_next; }
                 }
                 __syncthreads();
+                if constexpr (lagrangian_home_is_hbm<M>::value) {       // the literal code leaves ∇L in LDS: take it home
+                    for (int i = threadIdx.x; i < I.N * M::NX; i += 128) I.gbase[I.hLx + i] = I.Lx[i];
+                    for (int i = threadIdx.x; i < I.N * M::NU; i += 128) I.gbase[I.hLu + i] = I.Lu[i];
+                }
             }
             I.gradient_norm = I.zs[2]; I.potrf_info = (int)I.zs[3];
             I.delta_next = I.zs[5]; I.delta_next_ok = 1;
@@ -1671,6 +1687,17 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     }
 }
 
+// data.gradient .= 0 of reset!(solver.data) (src/data/solver.jl:49-59), wherever this kernel keeps it
+template <class M>
+__device__ __forceinline__ void zero_lagrangian_gradient(Inst<M>& I) {
+    for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
+    for (int i = I.lane; i < I.N * M::NU; i += 64) I.Lu[i] = 0.0;
+    if constexpr (lagrangian_home_is_hbm<M>::value) {
+        for (int i = I.lane; i < I.N * M::NX; i += 64) I.gbase[I.hLx + i] = 0.0;
+        for (int i = I.lane; i < I.N * M::NU; i += 64) I.gbase[I.hLu + i] = 0.0;
+    }
+}
+
 // reset!(problem.model); reset!(problem.objective) — src/solve.jl:9-10
 template <class M>
 __device__ void reset_model_objective(Inst<M>& I, bool literal = true) {
@@ -1718,8 +1745,7 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
     if (al_outer && o_start == 1 && it_start == 0) {
         // reset!(solver.data) (:93, src/data/solver.jl:49-59); λ ← 0, ρ ← ρ0 (:96-103)
         I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
-        for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
-        for (int i = I.lane; i < I.N * M::NU; i += 64) I.Lu[i] = 0.0;
+        zero_lagrangian_gradient<M>(I);
         for (int i = I.lane; i < I.C; i += 64) {
             I.lam[i] = 0.0;
             I.rho[i] = opt.initial_constraint_penalty;
@@ -1779,7 +1805,7 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w; I.ring = smem + L.ring;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
     I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x & 63; I.wave = threadIdx.x >> 6;
-    I.lds = smem; I.gbase = g; I.fv_off = 0; I.hc_off = 0;
+    I.lds = smem; I.gbase = g; I.fv_off = 0; I.hc_off = 0; I.hLx = L.Lx; I.hLu = L.Lu;
     I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;      // (the stage kernel continues from the stored count, see there)
     I.Q = a.qv ? a.qv + (size_t)b * (size_t)a.QL.stride : nullptr; I.QL = a.QL;
@@ -1826,7 +1852,14 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
         double2* dst = reinterpret_cast<double2*>(g);
         const double2* src = reinterpret_cast<const double2*>(smem);
         const int nd = slim_of<M>::value ? L.lds_doubles_slim : L.lds_doubles;
-        for (int i = I.lane + 64 * I.wave; i < nd / 2; i += 64 * waves_of<M>::value) dst[i] = src[i];
+        if constexpr (lagrangian_home_is_hbm<M>::value) {
+            // everything but the Lagrangian gradient, whose HBM values are the current ones (Lx, Lu: adjacent, even offsets and lengths)
+            const int lo = L.Lx / 2, hi = (L.Lu + pad2(I.N * M::NU)) / 2;
+            for (int i = I.lane + 64 * I.wave; i < nd / 2; i += 64 * waves_of<M>::value)
+                if (i < lo || i >= hi) dst[i] = src[i];
+        } else {
+            for (int i = I.lane + 64 * I.wave; i < nd / 2; i += 64 * waves_of<M>::value) dst[i] = src[i];
+        }
     }
     if (I.lane == 0 && I.wave == 0) {
         I.scal[S_OBJECTIVE] = I.objective; I.scal[S_MAX_VIOLATION] = I.max_violation;
@@ -1943,8 +1976,7 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, 2) void stage_kernel(KArgs
         case ILQR_STAGE_AL_BEGIN: {      // src/solve.jl:93-103: reset!(data), λ ← 0, ρ ← ρ0
             I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; I.gradient_norm = 0.0;
             I.outer_iterations = 0; I.potrf_info = 0; I.rollouts = 0;
-            for (int i = I.lane; i < I.N * M::NX; i += 64) I.Lx[i] = 0.0;
-            for (int i = I.lane; i < I.N * M::NU; i += 64) I.Lu[i] = 0.0;
+            zero_lagrangian_gradient<M>(I);
             for (int i = I.lane; i < I.C; i += 64) { I.lam[i] = 0.0; I.rho[i] = a.opt.initial_constraint_penalty; }
             if (I.lane == 0 && I.wave == 0) I.scal[S_DONE] = 0.0;
             __syncthreads();

@@ -37,7 +37,7 @@ enum {
 enum { RING_STEPS = 4, RING_DOUBLES = 2 * RING_STEPS * 3 * 16 };
 // doubles of zeros behind Layout::gzero + 2 in every instance block: padding lanes of operands addressed with immediate offsets
 // (backward_pass_m1) aim there
-enum { GZERO_REGION = 32 };
+enum { GZERO_REGION = 32, GTRASH_REGION = 16 };     // ... and doubles behind those that result lanes with nothing to store may write
 
 struct Layout {
     int T, nx, nu, nw, ncs, nct;
@@ -135,7 +135,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.P = o; o += pad2(T * nx * nx);
     L.p = o; o += pad2(T * nx);
     L.scal = o; o += S_COUNT;
-    L.gzero = o; o += 2 + GZERO_REGION;       // [0] a 0.0, [1] write-only trash (packed kernel), then GZERO_REGION zeros
+    L.gzero = o; o += 2 + GZERO_REGION + GTRASH_REGION;       // [0] a 0.0, [1] write-only trash (packed kernel), GZERO_REGION zeros, a trash region
     L.JV = 0; L.HS = 0; L.fv = L.hc = L.ab = o;
     if (is_large_model(nx, nu)) {
         L.JV = pad2(jac_nvar > 0 ? jac_nvar : 1); L.HS = pad2(hess_nnz > 0 ? hess_nnz : 1);

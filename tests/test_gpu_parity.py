@@ -1439,5 +1439,5 @@ def test_dynamics_with_a_pole_against_the_oracle(pkg, oracle):
     dead = ~np.isfinite(ref["x"]).all(axis=(1, 2))
     assert dead[:2].all() and not dead[3:].all()
     assert np.array_equal(np.isfinite(x).all(axis=(1, 2)), ~dead)
-    assert np.abs(x - ref["x"])[~dead].max() < 1e-8 and np.abs(u - ref["u"])[~dead].max() < 1e-8
+    assert np.abs(x[~dead] - ref["x"][~dead]).max() < 1e-8 and np.abs(u[~dead] - ref["u"][~dead]).max() < 1e-8
     sol.close()
