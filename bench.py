@@ -81,6 +81,9 @@ def parse_args(argv=None):
                          "doubles per line-search trial, line search stepped from the host (Solver.solve_shared_step_)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the two short secondary passes (distinct shards per rank; two batches in flight) reported as extra keys")
+    ap.add_argument("--sharded-handle", action="store_true",
+                    help="ONE process, ONE solver handle over the first N devices (ilqr_create_sharded: what a Julia host holding one "
+                         "Solver would use) instead of one process per GPU; same JSON line, ranks.launcher says so")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -193,7 +196,11 @@ def worker(args, solver_factory=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    sharded = bool(getattr(args, "sharded_handle", False))
+    ndev = args.gpus if sharded else 1           # devices under this process's handle
+    if sharded and world != 1:
+        raise SystemExit("bench.py: --sharded-handle is one process over N devices, not a rank of %d" % world)
+    if not sharded and world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d — launch with `python bench.py --gpus N` (it starts the ranks "
                          "itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     import torch
@@ -209,6 +216,8 @@ def worker(args, solver_factory=None):
             raise SystemExit("bench.py needs a GPU (no CPU fallback)")
         if not share and torch.cuda.device_count() <= local_rank:
             raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
+        if sharded and not share and torch.cuda.device_count() < ndev:
+            raise SystemExit("bench.py: --sharded-handle --gpus %d but only %d device(s) visible" % (ndev, torch.cuda.device_count()))
     gpu = 0 if share else local_rank
     backend = None
     if world > 1:
@@ -231,15 +240,29 @@ def worker(args, solver_factory=None):
     # other shards), so distinct shards would fold that data lottery into the scaling figure
     lo, _ = pkg.distributed.shard_range(rank, B)
     model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if args.distinct_shards else 0))
+    if sharded:
+        # one handle, ndev contiguous ranges of B instances: the same B instances on every device (fixed per-GPU work, like the
+        # process-per-GPU default) or ndev * B distinct ones
+        if args.distinct_shards:
+            model, T, x1, ub = pkg.workloads.make_inputs(args.config, ndev * B)
+        else:
+            x1, ub = np.tile(x1, (ndev, 1)), np.tile(ub, (ndev, 1, 1))
     if stub:
         sols = [solver_factory(rank, model, T, B, x1, ub) if solver_factory is not None else _StubSolver(rank, B)]
         d_x1 = d_u = None
     else:
-        d_x1 = torch.from_numpy(x1).to(dev)
-        d_u = torch.from_numpy(ub).to(dev)
-        sols = [pkg.Solver(model=model, horizon=T, batch=B, device=gpu,
-                           options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
-                for _ in range(max(1, args.inflight))]
+        if sharded:
+            d_x1 = d_u = None
+            devs = [0] * ndev if share else list(range(ndev))
+            sols = [pkg.Solver(model=model, horizon=T, batch=ndev * B, devices=devs,
+                               options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))]
+            sols[0].initialize_rollout_(x1, ub)        # inputs to every device's HBM, once, outside the timed region
+        else:
+            d_x1 = torch.from_numpy(x1).to(dev)
+            d_u = torch.from_numpy(ub).to(dev)
+            sols = [pkg.Solver(model=model, horizon=T, batch=B, device=gpu,
+                               options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
+                    for _ in range(max(1, args.inflight))]
     sol = sols[0]
     for s_ in sols:
         s_.set_kernel_variant_(args.variant)
@@ -252,7 +275,10 @@ def worker(args, solver_factory=None):
         s = sols[counter[0] % len(sols)]
         counter[0] += 1
         s.reset_()
-        s.initialize_rollout_device_(d_x1.data_ptr() if d_x1 is not None else 0, d_u.data_ptr() if d_u is not None else 0)
+        if sharded and not stub:
+            s.initialize_rollout_resident_()
+        else:
+            s.initialize_rollout_device_(d_x1.data_ptr() if d_x1 is not None else 0, d_u.data_ptr() if d_u is not None else 0)
         if args.shared_step and not stub:
             s.solve_shared_step_(pkg.distributed.torch_allreduce_sum(dist, cdev))
         else:
@@ -292,7 +318,7 @@ def worker(args, solver_factory=None):
     # [rB, (r+1)B) of one big synthetic batch (BASELINE config 4's situation: the step then lasts as long as the unluckiest
     # shard's slowest instance), and two batches in flight per GPU (the next batch fills SIMDs freed by early finishers)
     secondary = {}
-    if not args.shared_step and not args.no_secondary and solver_factory is None:
+    if not args.shared_step and not args.no_secondary and solver_factory is None and not sharded:
         k2 = max(1, min(3, args.steps))
 
         def timed(step_fn, handles):
@@ -356,16 +382,20 @@ def worker(args, solver_factory=None):
         return
 
     rank_ms = [r[0] for r in per_rank]
-    value = world * B * args.steps / elapsed
+    n_gpus = ndev if sharded else world
+    value = n_gpus * B * args.steps / elapsed
+    # BASELINE.json's metric is quoted on acrobot T=101 at 1024 instances per GPU; any other --config / --batch names itself
+    headline = args.config == "acrobot" and B == 1024
     out = {
-        "metric": "trajectories/sec (whole node), acrobot T=101 batch=1024/GPU",
-        "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "trajectories/sec (whole node), acrobot T=101 batch=1024/GPU" if headline
+                  else "trajectories/sec (whole node), %s T=%d batch=%d/GPU (NOT the BASELINE metric's configuration)" % (args.config, T, B),
+        "value": value, "unit": "trajectories/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s (nx=%d, nu=%d, T=%d) AL-iLQR solve!, batch=%d per GPU, fp64, faithful reference semantics"
                                % (args.config, sol.nx, sol.nu, T, B),
-                   "global_batch": world * B, "horizon": T,
-                   "parallelism": "batch-shard x%d (no collective), %s" % (world, "distinct shards" if args.distinct_shards else "same %d instances per GPU" % B),
+                   "global_batch": n_gpus * B, "horizon": T,
+                   "parallelism": "batch-shard x%d (no collective), %s" % (n_gpus, "distinct shards" if args.distinct_shards else "same %d instances per GPU" % B),
                    "batches_in_flight": len(sols), "kernel_variant": args.variant,
                    "mode": ("shared_step: one step size per iteration for the global batch, all-reduce(sum) of 3 doubles per trial over %s, "
                             "host-stepped line search — changes the iterates, not comparable with the reference" % (backend or "one rank"))
@@ -373,7 +403,8 @@ def worker(args, solver_factory=None):
         "ranks": {"world_size": world, "collective_backend": backend, "group_world_size": (dist.get_world_size() if dist is not None else 1),
                   "ms_per_step_per_rank": rank_ms, "slowest_rank": int(np.argmax(rank_ms)),
                   "solve_kernel_ms_per_rank": [r[1] for r in per_rank],
-                  "launcher": os.environ.get("ILQR_BENCH_LAUNCHER", "external (torchrun)" if world > 1 else "single process"),
+                  "launcher": ("one process, ilqr_create_sharded over %d device(s)" % ndev) if sharded
+                              else os.environ.get("ILQR_BENCH_LAUNCHER", "external (torchrun)" if world > 1 else "single process"),
                   "shared_device_test_hook": share, "stub": stub},
         "solve_stats": {"inner_iterations_mean": float(st["iterations"].mean()),
                         "iterations_max": it_max,       # the kernel lasts as long as its slowest instance
@@ -387,10 +418,10 @@ def worker(args, solver_factory=None):
         out["secondary"] = secondary
     if not stub:
         n_, m_ = sol.nx, sol.nu
-        io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))
+        io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))     # per device
         C = (T - 1) * sol.nc_stage + sol.nc_term
         abytes = float(algorithmic_bytes(sol.nx, sol.nu, T, C, st["iterations"].astype(np.float64),
-                                         st["rollouts"].astype(np.float64)).sum())
+                                         st["rollouts"].astype(np.float64)).sum()) / ndev     # (per device: one handle over ndev of them)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -402,7 +433,7 @@ def worker(args, solver_factory=None):
                 # stage-materialised model a resident solve sits
                 "io_lower_bound_bytes_per_launch": io_bytes,
                 "io_lower_bound_GBs": io_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0}
-        if world == 1 and not args.no_pmc and not args.shared_step:
+        if world == 1 and not args.no_pmc and not args.shared_step and not sharded:
             for s_ in sols:
                 s_.synchronize()
             tr, why = measure_traffic(args)
@@ -423,10 +454,19 @@ def worker(args, solver_factory=None):
             mfma_per_step = NPt * n4 + NPt * NPt * n4 + NPt * n4 + n4 + NPt * NPt * n4 + NPt * NPt * 4 * m4
             passes = float((st["iterations"] + st["outer_iterations"]).sum())
             flops = passes * (T - 1) * mfma_per_step * 2048.0
+            # the flops the recursion needs (4n^3 + 12mn^2 + 6m^2n + m^3/3 + 2n^2 + 8mn per timestep), i.e. without
+            # the zero padding of the 16x16 tiles
+            n_l, m_l = float(sol.nx), float(sol.nu)
+            useful = passes * (T - 1) * (4 * n_l ** 3 + 12 * m_l * n_l ** 2 + 6 * m_l ** 2 * n_l + m_l ** 3 / 3 + 2 * n_l ** 2 + 8 * m_l * n_l) / ndev
+            flops /= ndev
             roof["mfma"] = {"achieved": flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": 78.6, "unit": "TFLOP/s",
                             "frac": flops / (kernel_ms * 1e-3) / 1e12 / 78.6 if kernel_ms > 0 else 0.0,
+                            "useful_achieved": useful / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0,
+                            "useful_frac": useful / (kernel_ms * 1e-3) / 1e12 / 78.6 if kernel_ms > 0 else 0.0,
                             "mfma_per_riccati_step": mfma_per_step, "backward_passes": passes,
-                            "note": "v_mfma_f64_16x16x4_f64 flops incl. tile padding / kernel time; the matrix pipe is shared by the two instances of a CU"}
+                            "note": "achieved / frac: v_mfma_f64_16x16x4_f64 flops INCLUDING the zero padding of the tiles (what the matrix pipe "
+                                    "executes); useful_*: the recursion's own flops (SURVEY Appendix D); backward passes counted as inner "
+                                    "iterations + one per ilqr_solve! call; the matrix pipe is shared by the two instances of a CU"}
             roof["actual_bound"] = ("per-timestep latency of the Riccati step: four MFMA-tile windows around the serial potrf / potrs chain "
                                     "(about 8 k clk per timestep for one instance alone, of which 2.2 k are MFMA pipe time per SIMD); "
                                     "the launch lasts as long as its slowest instance")
@@ -437,10 +477,14 @@ def worker(args, solver_factory=None):
             roof["issue_model_unavailable"] = why_not
         elif kernel_ms > 0 and args.variant in ("auto", "latency") and B <= 1024 and sol.nx <= 4 and sol.nu <= 4:
             rollouts_per_iter = float(st["rollouts"].sum()) / max(1.0, it_sum)
-            per_iter_clk = (T - 1) * (im["rollout_step_occupancy_clk"] * rollouts_per_iter + im["riccati_step_occupancy_clk"]) \
-                + im["per_iteration_other_clk"]
+            # the two serial loops alone (the slower wave of the Riccati recursion sets its pace): nothing measured enters the floor —
+            # the cost pass, the linearisation, copies and barriers of an iteration are what `other_ms` is left with
+            ric_clk = max(im["riccati_step_occupancy_clk"], im.get("wave1_riccati_step_occupancy_clk", 0.0))
+            per_iter_clk = (T - 1) * (im["rollout_step_occupancy_clk"] * rollouts_per_iter + ric_clk)
             slots_iter = (T - 1) * (im["rollout_step_instr"] * rollouts_per_iter + im["riccati_step_instr"])
             floor_ms = it_max * per_iter_clk / (im["clock_ghz"] * 1e6)
+            chain_ms = it_max * (T - 1) * (im["rollout_step_chain"]["clk"] * rollouts_per_iter + im["riccati_step_chain"]["clk"]) / (im["clock_ghz"] * 1e6) \
+                if "rollout_step_chain" in im else None
             roof["bound"] = "issue"
             roof["roofline_kind"] = "hbm (SURVEY §8(d): achieved / peak / frac are the modelled HBM figure the survey asks for)"
             roof["actual_bound"] = ("instruction issue of ONE wave: the slowest instance's critical wave issues one instruction per 5-6 clk "
@@ -449,7 +493,12 @@ def worker(args, solver_factory=None):
             roof["issue_model"] = dict(im, iterations_max=it_max, rollouts_per_iteration=rollouts_per_iter,
                                        issue_slots_per_iteration=slots_iter,
                                        measured_clk_per_issue_slot=kernel_ms * im["clock_ghz"] * 1e6 / (it_max * slots_iter),
-                                       predicted_floor_ms=floor_ms, achieved_over_floor=kernel_ms / floor_ms)
+                                       predicted_floor_ms=floor_ms, achieved_over_floor=kernel_ms / floor_ms,
+                                       other_ms=kernel_ms - floor_ms, dependent_chain_ms=chain_ms,
+                                       floor_basis="issue time of the instruction lists of the two serial loops (rollout, Riccati) of the slowest "
+                                                   "instance, single-wave rates; other_ms = everything else of its iterations (cost pass, linearisation, "
+                                                   "copies, barriers, SIMD sharing); dependent_chain_ms = the same loops if only their register "
+                                                   "dependences counted (rollout_step_chain, riccati_step_chain): what more issue bandwidth could reach")
         out["roofline"] = roof
 
         if world == 1:
@@ -464,7 +513,7 @@ def worker(args, solver_factory=None):
                 sol.get_trajectory()
                 sol.get_policy()
             host_elapsed = (time.perf_counter() - h0) / host_steps
-            out["host_boundary"] = {"value": B / host_elapsed, "unit": "trajectories/s",
+            out["host_boundary"] = {"value": ndev * B / host_elapsed, "unit": "trajectories/s",
                                     "note": "one rank, inputs from host memory and x, u, K, k copied back (PCIe-inclusive)"}
 
         if world == 1 and not args.no_cpu_baseline:
@@ -495,7 +544,7 @@ def main(argv=None):
     args = parse_args(argv)
     if args.pmc_child:
         return pmc_child(args)
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.sharded_handle:
         # launcher: N fresh ranks, started before this process has made any HIP call
         from ilqr_amd_loader import load_package
         pkg = load_package()

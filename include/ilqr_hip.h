@@ -125,6 +125,10 @@ int ilqr_initialize_states(ilqr_handle* h, const double* x);
  * and is asynchronous on the handle's stream. */
 int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u);
 int ilqr_initialize_rollout_device(ilqr_handle* h, const double* d_x1, const double* d_u);
+/* The same from the inputs the handle keeps in HBM since the last ilqr_initialize_rollout (every device of a sharded handle
+ * keeps its own range): a re-solve of the same (x1, ū) — solve!(solver) again after initialize_controls!/initialize_states!,
+ * src/solver.jl:56-66 — without a host-to-device copy. Asynchronous. */
+int ilqr_initialize_rollout_resident(ilqr_handle* h);
 
 /* solve!(solver) — src/solve.jl:137-143. Asynchronous: enqueues the whole
  * AL/iLQR solve of every instance on the handle's stream. */

@@ -52,6 +52,7 @@ SYMBOLS = {
     "ilqr_initialize_states": (C.c_int, [C.c_void_p, c_double_p]),
     "ilqr_initialize_rollout": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "ilqr_initialize_rollout_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ilqr_initialize_rollout_resident": (C.c_int, [C.c_void_p]),
     "ilqr_solve": (C.c_int, [C.c_void_p]),
     "ilqr_synchronize": (C.c_int, [C.c_void_p]),
     "ilqr_run_stage": (C.c_int, [C.c_void_p, C.c_int32]),

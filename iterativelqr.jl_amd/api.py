@@ -143,6 +143,11 @@ class Solver:
     def initialize_rollout_device_(self, d_x1_ptr, d_u_ptr):
         _ffi.check(_ffi.lib().ilqr_initialize_rollout_device(self._h, C.c_void_p(d_x1_ptr), C.c_void_p(d_u_ptr)))
 
+    def initialize_rollout_resident_(self):
+        """initialize_rollout_ again from the inputs the handle keeps in HBM since the last call with host arrays (works on a
+        handle that spans several devices, where device pointers of one device make no sense)."""
+        _ffi.check(_ffi.lib().ilqr_initialize_rollout_resident(self._h))
+
     def set_parameters_(self, w):
         """Solver(...; parameters=θ): w[b, t] is the parameter vector of timestep t of instance b."""
         w = np.ascontiguousarray(w, dtype=np.float64).reshape(self.B, self.T, self.num_user_parameter)

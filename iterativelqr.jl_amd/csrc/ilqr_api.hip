@@ -632,6 +632,13 @@ int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u) {
     return ILQR_OK;
 }
 
+int ilqr_initialize_rollout_resident(ilqr_handle* h) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_initialize_rollout_resident(s); });
+    if (!h->d_x1 || !h->d_u) return fail(ILQR_ERR_INVALID, "no resident inputs: ilqr_initialize_rollout (host pointers) has to come first");
+    return ilqr_initialize_rollout_device(h, h->d_x1, h->d_u);
+}
+
 int ilqr_solve(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_solve(s); });      // asynchronous on every device's stream

@@ -74,3 +74,28 @@ def test_a_rank_that_dies_at_start_up_ends_the_job_at_once(tmp_path):
     rc, out = pkg.distributed.launch_ranks(str(script), [], 2, stub=True, timeout=100)
     assert rc == 3 and time.time() - t0 < 20
     assert "rank0 up" in out or out == ""
+
+
+def test_sharded_handle_mode_is_one_process_over_n_devices():
+    """`bench.py --gpus N --sharded-handle`: ONE process whose solver handle spans N devices (ilqr_create_sharded — the path a Julia
+    host holding one Solver takes, /root/reference/src/solver.jl:28-46), same JSON line. Stub solve on CPU: the launcher must not
+    start ranks, n_gpus and the whole-job value must count all N ranges."""
+    p = _run(["--gpus", "2", "--sharded-handle", "--steps", "3", "--warmup", "1", "--batch", "8"], ILQR_BENCH_STUB="1")
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16
+    assert out["ranks"]["world_size"] == 1 and "ilqr_create_sharded over 2 device(s)" in out["ranks"]["launcher"]
+    assert abs(out["value"] - 16 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert "NOT the BASELINE metric" in out["metric"]              # batch 8 is not the configuration the metric is quoted on
+
+
+def test_sharded_handle_mode_refuses_without_enough_devices():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    p = _run(["--gpus", "2", "--sharded-handle", "--steps", "1", "--warmup", "0"])
+    assert p.returncode != 0
+    err = p.stderr.decode()
+    assert "needs a GPU" in err or "device(s) visible" in err

@@ -150,7 +150,125 @@ def marked_loop(body, marker):
     loop = max((owner[i] for i in marks), key=lambda o: o[1])
     k = sum(1 for i in marks if owner[i] == loop)
     lines = [body[i] for i in range(len(body)) if owner[i] == loop]
-    return classify(lines, (0, len(lines) - 1)), k
+    c = classify(lines, (0, len(lines) - 1))
+    c["chain"] = recurrence_chain(lines)
+    return c, k
+
+
+# ---- dependent-chain analysis -------------------------------------------------------------------------------------------
+# Latency of one instruction as seen by a DEPENDENT successor of the same wave, in shader clocks. VALU / SALU / DPP: the
+# dependent issue interval of tools/probes/probe_issue.hip (a dependent instruction issues as soon as an independent one would);
+# v_mfma_f64_4x4x4: 19 (result as the B operand of the next), 17 as its C operand — 19 taken; LDS read ~64 and write 13 alone on
+# the chip (profiles/r02_probe_lds.txt); a global load answered by the L2 ~500 (operands are requested ahead, so they are on the
+# recurrence only through their address registers).
+CHAIN_LAT = {"valu_f64": 5.5, "mfma": 19.0, "valu_other": 5.1, "dpp_perm": 5.5, "lds": 64.0, "vmem": 500.0, "salu": 5.2, "waitcnt": 0.0, "nop": 0.0}
+_NO_DST = ("s_cmp", "s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_barrier", "s_bitcmp", "s_setprio", "s_sleep", "s_endpgm",
+           "ds_write", "global_store", "scratch_store", "flat_store", "buffer_store", "s_setreg", "s_sendmsg")
+
+
+def _regs(tok):
+    """registers named by one operand token: v12, v[4:7], s3, s[10:11], vcc, exec, -v[1:2], |v[1:2]|, ..."""
+    tok = tok.strip().strip("-|").strip()
+    m = re.match(r"^([vsa])\[(\d+):(\d+)\]$", tok)
+    if m:
+        return ["%s%d" % (m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)]
+    m = re.match(r"^([vsa])(\d+)$", tok)
+    if m:
+        return [tok]
+    if tok in ("vcc", "vcc_lo", "vcc_hi"):
+        return ["vcc"]
+    if tok in ("exec", "exec_lo", "exec_hi"):
+        return ["exec"]
+    if tok == "m0":
+        return ["m0"]
+    return []
+
+
+def _instr_class(t):
+    op = t.split()[0]
+    if op == "s_nop":
+        return "nop"
+    if op.startswith("v_mfma"):
+        return "mfma"
+    if op.startswith("v_") and ("f64" in op or op in ("v_div_scale_f64", "v_div_fmas_f64", "v_div_fixup_f64")) and "dpp" not in t:
+        return "valu_f64"
+    if op.startswith("v_") and ("dpp" in t or "permlane" in op or "readlane" in op or "readfirstlane" in op):
+        return "dpp_perm"
+    if op.startswith("v_"):
+        return "valu_other"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "vmem"
+    if op == "s_waitcnt":
+        return "waitcnt"
+    return "salu"
+
+
+def _defs_uses(t):
+    op = t.split()[0]
+    rest = t[len(op):]
+    rest = re.sub(r"\b(offset\d*|row_\w+|quad_perm|bank_mask|row_mask|bound_ctrl|bitop3|cbsz|abid|blgp|op_sel\w*|neg_\w+|clamp|glc|slc|sc0|sc1|nt)[:\[\w,\]]*", "", rest)
+    toks = [x for x in rest.split(",")]
+    ops = [_regs(x.split()[0]) if x.split() else [] for x in toks]
+    defs, uses = [], []
+    no_dst = op.startswith(_NO_DST)
+    if op.startswith("v_cmp") and op.endswith("_e32"):
+        defs = ["vcc"]; uses = [r for o in ops for r in o]
+    elif no_dst:
+        uses = [r for o in ops for r in o]
+    else:
+        defs = ops[0] if ops else []
+        uses = [r for o in ops[1:] for r in o]
+        if op.startswith(("v_fmac", "v_mac", "v_dot")) or "dpp" in t:
+            uses += defs                                  # two-address forms (and DPP keeps the old value of masked lanes)
+    if op.startswith(("v_cndmask_b32_e32", "v_addc", "v_subb", "v_div_fmas")):
+        uses.append("vcc")
+    if op.startswith("s_") and not no_dst and not op.startswith(("s_mov", "s_cselect", "s_load", "s_getreg", "s_movk")):
+        defs = defs + ["scc"]
+    if op.startswith(("s_cmp", "s_bitcmp")):
+        defs = ["scc"]
+    if op.startswith(("s_cselect", "s_cbranch_scc", "s_addc", "s_subb")):
+        uses.append("scc")
+    if op.startswith("s_cbranch_vcc"):
+        uses.append("vcc")
+    if op.endswith("saveexec_b64"):
+        defs = defs + ["exec"]; uses.append("exec")
+    return defs, uses
+
+
+def recurrence_chain(lines, copies=4):
+    """Longest chain of true (read-after-write) register dependences that one trip of the loop adds, in instructions and in
+    clocks at CHAIN_LAT: the loop's own instruction list (program order, cold child loops excluded) is laid out `copies` times
+    and the longest path through copies 1..k is taken; the growth from k - 1 to k copies is the recurrence of one trip — what
+    bounds the loop however many instructions could issue beside it. Memory dependences through LDS are not followed (operands
+    are requested one or two steps ahead; the hand-over between the two waves is a barrier)."""
+    ins = []
+    for ln in lines:
+        t = ln.strip()
+        if not t or t.startswith((";", ".")) or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        if not t:
+            continue
+        cls = _instr_class(t)
+        d, u = _defs_uses(t)
+        w = CHAIN_LAT[cls]
+        if cls == "nop":
+            w = 1.0 + int(t.split()[1])
+        ins.append((cls, d, u, w))
+    best_n, best_c = [], []
+    last = {}          # register -> (chain length in instructions, in clocks) of its latest writer
+    for k in range(copies):
+        for cls, d, u, w in ins:
+            n0 = max([last[r][0] for r in u if r in last] or [0])
+            c0 = max([last[r][1] for r in u if r in last] or [0.0])
+            cnt = 0 if cls in ("nop", "waitcnt") else 1
+            for r in d:
+                last[r] = (n0 + cnt, c0 + w)
+        best_n.append(max(v[0] for v in last.values()))
+        best_c.append(max(v[1] for v in last.values()))
+    return {"instructions_per_trip": best_n[-1] - best_n[-2], "clk_per_trip": best_c[-1] - best_c[-2]}
 
 
 def functions(lines):
@@ -196,16 +314,24 @@ def model_for(config, lines):
         "wave1_riccati_step_instr": slots(vec, kvec), "wave1_delta_step_instr": slots(dlt, kdlt),
         "rollout_loop": dict(rol, steps_in_body=krol), "riccati_loop": dict(ric, steps_in_body=kric),
         "rollout_step_occupancy_clk": occ(rol, krol), "riccati_step_occupancy_clk": occ(ric, kric),
+        "wave1_riccati_step_occupancy_clk": occ(vec, kvec),
+        # longest chain of true register dependences per timestep (recurrence_chain): what bounds a step however its other
+        # instructions are scheduled; slots / chain says how far the step is from its own critical path
+        "rollout_step_chain": {"instructions": rol["chain"]["instructions_per_trip"] / krol, "clk": rol["chain"]["clk_per_trip"] / krol},
+        "riccati_step_chain": {"instructions": ric["chain"]["instructions_per_trip"] / kric, "clk": ric["chain"]["clk_per_trip"] / kric},
+        "wave1_riccati_step_chain": {"instructions": vec["chain"]["instructions_per_trip"] / kvec, "clk": vec["chain"]["clk_per_trip"] / kvec},
+        "rollout_slots_over_chain": slots(rol, krol) / max(1.0, rol["chain"]["instructions_per_trip"] / krol),
+        "riccati_slots_over_chain": slots(ric, kric) / max(1.0, ric["chain"]["instructions_per_trip"] / kric),
+        "chain_latency_clk_per_instruction": CHAIN_LAT,
         "occupancy_clk_per_instruction": OCC, "clock_ghz": CLOCK_GHZ,
-        "per_iteration_other_clk": {"acrobot": 13400.0, "car": 11000.0}.get(config, 14000.0),
         "note": "issue slots per timestep = (instructions + s_nop idle states of the loop holding the step marker, cold child loops "
                 "excluded) / step copies in that loop body (assembly kept by the library's own compilation). *_occupancy_clk = "
                 "the issue time of that instruction list at the single-wave rates of tools/probes/probe_issue.hip "
                 "(occupancy_clk_per_instruction; s_nop N = 5 + N). A lone wave issues one instruction per 5-6 clk whether or not it "
                 "depends on the previous one, so this IS the speed limit of the serial loops; what the measured time adds on top "
-                "is fp64-pipe sharing with the other wave of the SIMD, LDS / HBM waits and barriers. "
-                "per_iteration_other_clk = cost pass + wave 0's share of the linearisation + copies + barriers "
-                "(tools/phase_cycles.py on a -DILQR_PROFILE build, profiles/r02_phase_cycles.txt: acrobot 2.0 k + 7.2 k + 4.2 k, car 3.3 k + 4.0 k + 3.6 k ticks per iteration)",
+                "is fp64-pipe sharing with the other wave of the SIMD, LDS / HBM waits and barriers. *_chain = longest chain of true "
+                "register dependences one timestep adds (recurrence_chain): the step's own critical path; slots_over_chain says how "
+                "much of the step is issue serialisation of work that does not depend on each other",
     }, table
 
 
