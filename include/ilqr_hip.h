@@ -253,8 +253,13 @@ int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launch
  * The library wraps the source (csrc/ilqr_model_adapter.hpp), compiles it for gfx950 with hipcc as a child process (cached
  * by a hash of the source; ILQR_HIPCC / ILQR_CSRC_DIR override the tool and the kernel headers), loads the module and
  * returns the name to put into ilqr_problem_desc.model and the module path for ilqr_problem_desc.model_library.
- * nx <= 64, nu <= 16. Models with nx > 4 or nu > 4 run on the large path with every Jacobian / Hessian entry treated as
- * state-dependent / non-zero (callables carry no structure; the symbolic generator is the way to constant and sparse tables). */
+ * nx <= 64, nu <= 16. Models with nx > 4 or nu > 4 run on the large path, which streams only the state-dependent Jacobian
+ * entries and the structurally non-zero Hessian entries per timestep: for opaque callables these are found by PROBING — the
+ * source is compiled a second time with the host C++ compiler (ILQR_HOSTCXX, else g++ / c++ / clang++) and the Jacobian,
+ * Hessian and constraint-Jacobian callables are evaluated at three points; an entry bitwise equal at all of them is a constant
+ * (the role Symbolics' sparse expressions play in the reference, src/dynamics.jl:16-34). Source that does not compile for the
+ * host, or ILQR_NO_STRUCTURE_PROBE in the environment, leaves every entry state-dependent / non-zero (correct, more traffic).
+ * The dynamics callable itself stays opaque: every lane of the rollout evaluates the whole vector function. */
 typedef struct {
     const char* name;        /* C identifier */
     int32_t nx, nu, nw;      /* num_state, num_action, num_parameter */
@@ -275,6 +280,10 @@ struct ilqr_model_vtable;
 int ilqr_register_model(const struct ilqr_model_vtable* vt);
 int ilqr_model_count(void);
 const char* ilqr_model_name(int32_t i);
+/* Large models (nx > 4 or nu > 4): how many Jacobian entries per timestep the kernels treat as state-dependent and how many
+ * Hessian entries as structurally non-zero (the rest are constants / zeros: generated tables for symbolic models, found by
+ * probing the callables on the host for ilqr_compile_model); 0, 0 for small models. */
+int ilqr_model_compact_sizes(const char* model, int32_t* jac_nvar, int32_t* hess_nnz);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,7 @@ SYMBOLS = {
     "ilqr_register_model": (C.c_int, [C.c_void_p]),
     "ilqr_model_count": (C.c_int, []),
     "ilqr_model_name": (C.c_char_p, [C.c_int32]),
+    "ilqr_model_compact_sizes": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 STAGES = dict(cost_nominal=0, gradients=1, backward_pass=2, forward_pass=3, reset_model_objective=4,

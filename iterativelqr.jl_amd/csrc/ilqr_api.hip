@@ -326,6 +326,130 @@ int ilqr_register_model(const ilqr_model_vtable* vt) {
 }
 int ilqr_model_count(void) { return (int)registry().size(); }
 
+// ---- structure of a large model's callables, found by running them on the HOST (ilqr_compile_model)
+// The reference gets sparse, partly constant Jacobians and Hessians for free: Symbolics differentiates the user's function and
+// emits code for the non-trivial entries only (src/dynamics.jl:16-34, src/costs.jl:17-44). A C host hands over opaque callables;
+// what the large path streams per timestep (ilqr_device_large.hpp: state-dependent Jacobian entries, structurally non-zero
+// Hessian entries) is therefore found by PROBING: the source is compiled once more with the host compiler, every Jacobian /
+// Hessian / constraint-Jacobian callable is evaluated at three pseudo-random points, and an entry that comes out bitwise equal
+// at all of them is a constant (zero or not). A Hessian entry counts as structurally non-zero if a cost Hessian or a Gauss-Newton
+// term cxᵀ Iρ cx (src/gradients.jl:63-79) can put something there. Failing any step (no host compiler, source that does not
+// compile as host C++) is not an error: the dense tables are used, as before.
+struct ModelStructure {
+    bool found = false;
+    std::vector<double> fxc, fuc;          // constant Jacobian entries (0 where state-dependent)
+    std::vector<int> jac_var;              // indices into [fx | fu] of the state-dependent ones
+    std::vector<int> hess_idx, tile_start; // compact Hessian row: [gxx by 16x16 tile | guu | gux], indices inside each matrix
+    int nxx = 0, nuu = 0, nux = 0;
+    std::string note;
+};
+
+static int run_child(const std::vector<std::string>& args, const std::string& log) {
+    std::vector<const char*> argv;
+    for (auto& a : args) argv.push_back(a.c_str());
+    argv.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    pid_t pid = 0;
+    extern char** environ;
+    const int sp = posix_spawn(&pid, args[0].c_str(), &fa, nullptr, const_cast<char* const*>(argv.data()), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (sp != 0) return -1;
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status)) return -1;
+    return WEXITSTATUS(status);
+}
+
+static ModelStructure probe_model_structure(const ilqr_model_source* src, const std::string& dir, const std::string& tag) {
+    ModelStructure ms;
+    const int n = src->nx, m = src->nu, nw = src->nw, ncs = src->nc_stage, nct = src->nc_term;
+    if (std::getenv("ILQR_NO_STRUCTURE_PROBE")) { ms.note = "disabled by ILQR_NO_STRUCTURE_PROBE"; return ms; }
+    std::string cxx;
+    const char* cand[] = {std::getenv("ILQR_HOSTCXX"), "/usr/bin/g++", "/usr/bin/c++", "/usr/bin/clang++", "/opt/rocm/lib/llvm/bin/clang++"};
+    for (const char* c : cand)
+        if (c && access(c, X_OK) == 0) { cxx = c; break; }
+    if (cxx.empty()) { ms.note = "no host C++ compiler (set ILQR_HOSTCXX)"; return ms; }
+    const std::string pid = std::to_string((long)getpid());
+    const std::string cpp = dir + "/probe_" + tag + "." + pid + ".cpp", so = dir + "/probe_" + tag + "." + pid + ".so", log = dir + "/probe_" + tag + "." + pid + ".log";
+    FILE* f = std::fopen(cpp.c_str(), "w");
+    if (!f) { ms.note = "cannot write " + cpp; return ms; }
+    std::fprintf(f, "// GENERATED by ilqr_compile_model: the user's callables compiled for the host, to find constant / zero entries\n"
+                    "#include <cmath>\n#include <math.h>\n#define ILQR_MODEL_FN inline\nnamespace ilqr_user {\nusing namespace std;\n%s\n}\n"
+                    "extern \"C\" void ilqr_probe(int which, double* o, const double* x, const double* u, const double* w) {\n    switch (which) {\n"
+                    "        case 0: ilqr_user::dynamics_jacobian_state(o, x, u, w); break;\n        case 1: ilqr_user::dynamics_jacobian_action(o, x, u, w); break;\n"
+                    "        case 2: ilqr_user::cost_stage_hessian_state_state(o, x, u, w); break;\n        case 3: ilqr_user::cost_stage_hessian_action_action(o, x, u, w); break;\n"
+                    "        case 4: ilqr_user::cost_stage_hessian_action_state(o, x, u, w); break;\n        case 5: ilqr_user::cost_terminal_hessian_state_state(o, x, u, w); break;\n",
+                 src->source);
+    if (ncs > 0) std::fprintf(f, "        case 6: ilqr_user::constraint_stage_jacobian_state(o, x, u, w); break;\n        case 7: ilqr_user::constraint_stage_jacobian_action(o, x, u, w); break;\n");
+    if (nct > 0) std::fprintf(f, "        case 8: ilqr_user::constraint_terminal_jacobian_state(o, x, u, w); break;\n");
+    std::fprintf(f, "        default: break;\n    }\n}\n");
+    std::fclose(f);
+    const int rc = run_child({cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-w", cpp, "-o", so, "-lm"}, log);
+    auto cleanup = [&]() { std::remove(cpp.c_str()); std::remove(so.c_str()); std::remove(log.c_str()); };
+    if (rc != 0) { ms.note = "the source does not compile for the host (" + cxx + ", see " + log + ")"; std::remove(cpp.c_str()); return ms; }
+    void* hl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+    typedef void (*probe_fn)(int, double*, const double*, const double*, const double*);
+    probe_fn pf = hl ? (probe_fn)dlsym(hl, "ilqr_probe") : nullptr;
+    if (!pf) { ms.note = "cannot load the host build of the callables"; if (hl) dlclose(hl); cleanup(); return ms; }
+    const int P = 3;
+    const int sizes[9] = {n * n, n * m, n * n, m * m, m * n, n * n, ncs * n, ncs * m, nct * n};
+    std::vector<std::vector<double>> val[9];
+    unsigned long long seed = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return -1.3 + 3.0 * (double)(seed >> 11) / 9007199254740992.0; };
+    for (int p = 0; p < P; ++p) {
+        std::vector<double> x(n), u(m), w(nw > 0 ? nw : 1);
+        for (auto& v : x) v = rnd();
+        for (auto& v : u) v = rnd();
+        for (auto& v : w) v = rnd();
+        for (int k = 0; k < 9; ++k) {
+            std::vector<double> o((size_t)(sizes[k] > 0 ? sizes[k] : 1), 0.0);
+            const bool have = k < 6 || (k < 8 ? ncs > 0 : nct > 0);
+            if (have && sizes[k] > 0) pf(k, o.data(), x.data(), u.data(), w.data());       // (terminal objects see u of the stage size: ignored by them)
+            val[k].push_back(o);
+        }
+    }
+    dlclose(hl);
+    cleanup();
+    auto same = [&](int k, int e) { for (int p = 1; p < P; ++p) if (std::memcmp(&val[k][p][e], &val[k][0][e], 8) != 0) return false; return true; };
+    auto nonzero = [&](int k, int e) { for (int p = 0; p < P; ++p) if (val[k][p][e] != 0.0 || val[k][p][e] != val[k][p][e]) return true; return false; };
+    ms.fxc.assign(n * n, 0.0); ms.fuc.assign(n * m, 0.0);
+    for (int e = 0; e < n * n; ++e) { if (same(0, e)) ms.fxc[e] = val[0][0][e]; else ms.jac_var.push_back(e); }
+    for (int e = 0; e < n * m; ++e) { if (same(1, e)) ms.fuc[e] = val[1][0][e]; else ms.jac_var.push_back(n * n + e); }
+    // Hessian pattern: cost Hessians (stage and terminal share the row) and the Gauss-Newton terms of every constraint row
+    std::vector<char> pxx(n * n, 0), puu(m * m, 0), pux(m * n, 0);
+    for (int e = 0; e < n * n; ++e) pxx[e] = nonzero(2, e) || nonzero(5, e);
+    for (int e = 0; e < m * m; ++e) puu[e] = nonzero(3, e);
+    for (int e = 0; e < m * n; ++e) pux[e] = nonzero(4, e);
+    auto gauss_newton = [&](int kx, int ku, int nc) {
+        for (int i = 0; i < nc; ++i) {
+            std::vector<int> sx, su;
+            for (int j = 0; j < n; ++j) if (nonzero(kx, j * nc + i)) sx.push_back(j);
+            if (ku >= 0) for (int j = 0; j < m; ++j) if (nonzero(ku, j * nc + i)) su.push_back(j);
+            for (int a : sx) for (int b : sx) pxx[a * n + b] = 1;
+            for (int a : su) for (int b : su) puu[a * m + b] = 1;
+            for (int a : sx) for (int b : su) pux[a * m + b] = 1;         // gux(i2, j) at j * m + i2: column j = state, row i2 = action
+        }
+    };
+    if (ncs > 0) gauss_newton(6, 7, ncs);
+    if (nct > 0) gauss_newton(8, -1, nct);
+    const int TN = (n + 15) / 16;
+    for (int tile = 0; tile < TN * TN; ++tile) {
+        ms.tile_start.push_back((int)ms.hess_idx.size());
+        for (int idx = 0; idx < n * n; ++idx) {
+            const int col = idx / n, row = idx % n;
+            if (pxx[idx] && (row / 16) * TN + col / 16 == tile) ms.hess_idx.push_back(idx);
+        }
+    }
+    ms.tile_start.push_back((int)ms.hess_idx.size());
+    ms.nxx = (int)ms.hess_idx.size();
+    for (int e = 0; e < m * m; ++e) if (puu[e]) { ms.hess_idx.push_back(e); ms.nuu++; }
+    for (int e = 0; e < m * n; ++e) if (pux[e]) { ms.hess_idx.push_back(e); ms.nux++; }
+    ms.found = true;
+    return ms;
+}
+
 // Dynamics / Cost / Constraint constructors for hosts without Python: C source of the reference's callables -> model module.
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len) {
     if (!src || !src->name || !src->source || !registered_name || !library_path)
@@ -357,6 +481,8 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
 #ifdef ILQR_BUILD_HASH
     mix(ILQR_BUILD_HASH, std::strlen(ILQR_BUILD_HASH));
 #endif
+    const char* probe_off = std::getenv("ILQR_NO_STRUCTURE_PROBE");
+    mix(probe_off ? "dense" : "probed", 6);
     char tag[32];
     std::snprintf(tag, sizeof(tag), "%016llx", hsh);
     const std::string uname = std::string(src->name) + "_c" + tag;
@@ -389,11 +515,35 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
             if (have) std::fprintf(f, "    ILQR_MODEL_FN void %s(double* o, const double* x, const double* u, const double* w) { user_%s::%s(o, x, u, w); }\n", cnames[i], tag, cnames[i]);
             else std::fprintf(f, "    ILQR_MODEL_FN void %s(double*, const double*, const double*, const double*) {}\n", cnames[i]);
         }
-        // nx > 4 or nu > 4: the compact forms of the large path, dense (black-box callables carry no structure)
-        std::fprintf(f, "};\nstruct Model_%s : ilqr::%s<Fns_%s, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull> {\n"
+        std::fprintf(f, "};\n");
+        // nx > 4 or nu > 4: the compact forms of the large path — with the constant / zero entries found by probing the callables
+        // on the host (probe_model_structure), dense when that is not possible
+        const bool large = src->nx > 4 || src->nu > 4;
+        std::string tables;
+        if (large) {
+            const ModelStructure ms = probe_model_structure(src, dir, tag);
+            if (ms.found) {
+                const int nn = src->nx, mm = src->nu, TNt = (nn + 15) / 16;
+                auto ilist = [](const std::vector<int>& v, size_t lo, size_t hi) { std::string o; for (size_t i = lo; i < hi; ++i) o += std::to_string(v[i]) + ","; if (hi == lo) o = "0"; return o; };
+                auto dlist = [](const std::vector<double>& v) { std::string o; char b[40]; for (double d : v) { std::snprintf(b, sizeof(b), "%.17g,", d); o += b; } return o; };
+                const int hs = (int)ms.hess_idx.size(), jv = (int)ms.jac_var.size();
+                std::fprintf(f, "// structure found on the host: %d of %d Jacobian entries state-dependent, %d + %d + %d of %d Hessian entries structurally non-zero\n"
+                                "struct Tables_%s {\n    static constexpr int TN = %d, NXX = %d, NUU = %d, NUX = %d, HS = %d, JV = %d;\n"
+                                "    struct Tab { int hess_idx[%d]; int tile_start[%d]; int jac_idx[%d]; double fxc[%d]; double fuc[%d]; };\n"
+                                "    static constexpr Tab tab = {{%s}, {%s}, {%s}, {%s}, {%s}};\n};\n",
+                             jv, nn * nn + nn * mm, ms.nxx, ms.nuu, ms.nux, nn * nn + mm * mm + mm * nn, tag, TNt, ms.nxx, ms.nuu, ms.nux, hs, jv,
+                             hs > 0 ? hs : 1, TNt * TNt + 1, jv > 0 ? jv : 1, nn * nn, nn * mm,
+                             ilist(ms.hess_idx, 0, ms.hess_idx.size()).c_str(), ilist(ms.tile_start, 0, ms.tile_start.size()).c_str(),
+                             ilist(ms.jac_var, 0, ms.jac_var.size()).c_str(), dlist(ms.fxc).c_str(), dlist(ms.fuc).c_str());
+                tables = std::string(", Tables_") + tag;
+            } else {
+                std::fprintf(f, "// no structure found (%s): dense tables\n", ms.note.c_str());
+            }
+        }
+        std::fprintf(f, "struct Model_%s : ilqr::%s<Fns_%s, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull%s> {\n"
                         "    static constexpr const char* NAME = \"%s\";\n};\nILQR_DEFINE_MODEL(Model_%s)\n",
-                     uname.c_str(), (src->nx > 4 || src->nu > 4) ? "AdaptedLargeModel" : "AdaptedModel", tag, src->nx, src->nu, src->nw, src->nc_stage, src->nc_term,
-                     (unsigned long long)src->ineq_stage, (unsigned long long)src->ineq_term, uname.c_str(), uname.c_str());
+                     uname.c_str(), large ? "AdaptedLargeModel" : "AdaptedModel", tag, src->nx, src->nu, src->nw, src->nc_stage, src->nc_term,
+                     (unsigned long long)src->ineq_stage, (unsigned long long)src->ineq_term, tables.c_str(), uname.c_str(), uname.c_str());
         std::fclose(f);
         // hipcc as a child process (no shell): same flags as the built-in models
         const std::string tmp = so + ".tmp" + pid;
@@ -434,6 +584,13 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
 }
 const char* ilqr_model_name(int32_t i) {
     return (i >= 0 && i < (int)registry().size()) ? registry()[i]->name : nullptr;
+}
+int ilqr_model_compact_sizes(const char* model, int32_t* jac_nvar, int32_t* hess_nnz) {
+    const ilqr_model_vtable* vt = model ? find_model(model) : nullptr;
+    if (!vt) return fail(ILQR_ERR_MODEL, "unknown model");
+    if (jac_nvar) *jac_nvar = vt->jac_nvar;
+    if (hess_nnz) *hess_nnz = vt->hess_nnz;
+    return ILQR_OK;
 }
 
 int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {

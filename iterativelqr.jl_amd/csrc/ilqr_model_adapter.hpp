@@ -213,12 +213,17 @@ struct AdaptedModel {
     }
 };
 
-// Index tables of the dense compact forms: Jacobian entry q is entry q of [fx | fu]; the Hessian row is [gxx sorted by the
-// 16x16 tile an entry falls in | guu | gux], each in column-major order inside its matrix.
+// Index tables of the compact forms the large path streams. Jacobian entry q of the compact row is entry jac_idx[q] of [fx | fu]
+// (column-major inside each matrix); entries not listed are CONSTANTS taken from fxc / fuc. The Hessian row is
+// [gxx entries sorted by the 16x16 tile they fall in | guu | gux], hess_idx giving each one's column-major index inside its
+// matrix; entries not listed are structurally zero. DenseTables lists everything (black-box callables without structure);
+// ilqr_compile_model emits a table type of the same shape from what it finds by probing the callables on the host
+// (constant / zero Jacobian entries, structurally zero Hessian entries: the role Symbolics' sparse expressions play for the
+// reference, src/dynamics.jl:16-34, src/costs.jl:17-44).
 template <int NX, int NU>
 struct DenseTables {
     static constexpr int TN = (NX + 15) / 16, NXX = NX * NX, NUU = NU * NU, NUX = NU * NX, HS = NXX + NUU + NUX, JV = NX * NX + NX * NU;
-    struct Tab { int hess_idx[HS]; int tile_start[TN * TN + 1]; int jac_idx[JV]; };
+    struct Tab { int hess_idx[HS]; int tile_start[TN * TN + 1]; int jac_idx[JV]; double fxc[NX * NX]; double fuc[NX * NU]; };
     static constexpr Tab make() {
         Tab t{};
         int q = 0;
@@ -238,23 +243,43 @@ struct DenseTables {
     static constexpr Tab tab = make();
 };
 
-template <class F, int NX_, int NU_, int NW_, int NCS_, int NCT_, unsigned long long INEQ_S_, unsigned long long INEQ_T_>
+template <class F, int NX_, int NU_, int NW_, int NCS_, int NCT_, unsigned long long INEQ_S_, unsigned long long INEQ_T_,
+          class DT_ = DenseTables<NX_, NU_>>
 struct AdaptedLargeModel : AdaptedModel<F, NX_, NU_, NW_, NCS_, NCT_, INEQ_S_, INEQ_T_> {
     typedef AdaptedModel<F, NX_, NU_, NW_, NCS_, NCT_, INEQ_S_, INEQ_T_> Base;
-    typedef DenseTables<NX_, NU_> DT;
+    typedef DT_ DT;
     static constexpr int NX = NX_, NU = NU_, NW = NW_, NCS = NCS_, NCT = NCT_;
     static constexpr int W = cdim<NW>::v, CS = cdim<NCS>::v, CT = cdim<NCT>::v;
     static_assert(NX > 4 || NU > 4, "the compact forms are the large path's");
-    // ---- Jacobians: all entries state-dependent, no constant part
+    static constexpr int JVN = DT::JV > 0 ? DT::JV : 1, HSN = DT::HS > 0 ? DT::HS : 1;
+    // ---- Jacobians: the entries the table lists are evaluated per timestep, the others are its constants
     static constexpr int JAC_NVAR = DT::JV;
-    static constexpr double JAC_CONST_FX[1][NX * NX] = {};
-    static constexpr double JAC_CONST_FU[1][NX * NU] = {};
-    static constexpr const int (&JAC_VAR_IDX)[DT::JV] = DT::tab.jac_idx;
-    __device__ __forceinline__ static void dyn_jac_var(const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&v)[DT::JV]) {
+    template <int N> struct Row1 { double v[1][N]; };
+    template <int N> static constexpr Row1<N> row1(const double (&a)[N]) {
+        Row1<N> r{};
+        for (int i = 0; i < N; ++i) r.v[0][i] = a[i];
+        return r;
+    }
+    static constexpr Row1<NX * NX> FXC = row1(DT::tab.fxc);
+    static constexpr Row1<NX * NU> FUC = row1(DT::tab.fuc);
+    static constexpr const double (&JAC_CONST_FX)[1][NX * NX] = FXC.v;     // (the access form of the generated models: [0][e])
+    static constexpr const double (&JAC_CONST_FU)[1][NX * NU] = FUC.v;
+    static constexpr const int (&JAC_VAR_IDX)[JVN] = DT::tab.jac_idx;
+    __device__ __forceinline__ static void dyn_jac_var(const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double (&v)[JVN]) {
+        if constexpr (DT::JV == NX * NX + NX * NU) {             // dense: the callables write the compact row directly
 #pragma unroll
-        for (int i = 0; i < DT::JV; ++i) v[i] = 0.0;
-        F::dynamics_jacobian_state(v, x, u, w);
-        F::dynamics_jacobian_action(v + NX * NX, x, u, w);
+            for (int i = 0; i < JVN; ++i) v[i] = 0.0;
+            F::dynamics_jacobian_state(v, x, u, w);
+            F::dynamics_jacobian_action(v + NX * NX, x, u, w);
+        } else {
+            double full[NX * NX + NX * NU];
+#pragma unroll
+            for (int i = 0; i < NX * NX + NX * NU; ++i) full[i] = 0.0;
+            F::dynamics_jacobian_state(full, x, u, w);
+            F::dynamics_jacobian_action(full + NX * NX, x, u, w);
+#pragma unroll
+            for (int q = 0; q < DT::JV; ++q) v[q] = full[DT::tab.jac_idx[q]];
+        }
     }
     // ---- dynamics row form: no affine part known, the whole f is the "remainder", evaluated by every lane
     static constexpr double DYN_AFF[NX][NX + NU + 1] = {};
@@ -266,14 +291,14 @@ struct AdaptedLargeModel : AdaptedModel<F, NX_, NU_, NW_, NCS_, NCT_, INEQ_S_, I
     __device__ __forceinline__ static double dyn_rem_own(const double, const double (&)[NU], const double (&)[W]) { return 0.0; }
     // ---- Hessians: dense compact row
     static constexpr int HESS_NXX = DT::NXX, HESS_NUU = DT::NUU, HESS_NUX = DT::NUX;
-    static constexpr const int (&HESS_IDX)[DT::HS] = DT::tab.hess_idx;
+    static constexpr const int (&HESS_IDX)[HSN] = DT::tab.hess_idx;
     static constexpr const int (&HESS_XX_TILE_START)[DT::TN * DT::TN + 1] = DT::tab.tile_start;
     __device__ __forceinline__ static void cost_s_hess_c(const double (&x)[NX], const double (&u)[NU], const double (&w)[W], double* __restrict__ hs) {
         double hxx[NX * NX], huu[NU * NU], hux[NU * NX];
         Base::cost_s_hess(x, u, w, hxx, huu, hux);
         for (int q = 0; q < DT::NXX; ++q) hs[q] += hxx[DT::tab.hess_idx[q]];
-        for (int q = 0; q < DT::NUU; ++q) hs[DT::NXX + q] += huu[q];
-        for (int q = 0; q < DT::NUX; ++q) hs[DT::NXX + DT::NUU + q] += hux[q];
+        for (int q = 0; q < DT::NUU; ++q) hs[DT::NXX + q] += huu[DT::tab.hess_idx[DT::NXX + q]];
+        for (int q = 0; q < DT::NUX; ++q) hs[DT::NXX + DT::NUU + q] += hux[DT::tab.hess_idx[DT::NXX + DT::NUU + q]];
     }
     __device__ __forceinline__ static void cost_t_hess_c(const double (&x)[NX], const double (&w)[W], double* __restrict__ hs) {
         double hxx[NX * NX];
@@ -302,17 +327,17 @@ struct AdaptedLargeModel : AdaptedModel<F, NX_, NU_, NW_, NCS_, NCT_, INEQ_S_, I
                 for (int i = 0; i < NCS; ++i) acc += cx[i2 * NCS + i] * (ir[i] * cx[j * NCS + i]);
                 hs[q] += acc;
             }
-            for (int idx = 0; idx < DT::NUU; ++idx) {
-                const int j = idx / NU, i2 = idx % NU;
+            for (int q = 0; q < DT::NUU; ++q) {
+                const int idx = DT::tab.hess_idx[DT::NXX + q], j = idx / NU, i2 = idx % NU;
                 double acc = 0.0;
                 for (int i = 0; i < NCS; ++i) acc += cu[i2 * NCS + i] * (ir[i] * cu[j * NCS + i]);
-                hs[DT::NXX + idx] += acc;
+                hs[DT::NXX + q] += acc;
             }
-            for (int idx = 0; idx < DT::NUX; ++idx) {
-                const int j = idx / NU, i2 = idx % NU;
+            for (int q = 0; q < DT::NUX; ++q) {
+                const int idx = DT::tab.hess_idx[DT::NXX + DT::NUU + q], j = idx / NU, i2 = idx % NU;
                 double acc = 0.0;
                 for (int i = 0; i < NCS; ++i) acc += cu[i2 * NCS + i] * (ir[i] * cx[j * NCS + i]);
-                hs[DT::NXX + DT::NUU + idx] += acc;
+                hs[DT::NXX + DT::NUU + q] += acc;
             }
         }
     }

@@ -1441,3 +1441,42 @@ def test_dynamics_with_a_pole_against_the_oracle(pkg, oracle):
     assert np.array_equal(np.isfinite(x).all(axis=(1, 2)), ~dead)
     assert np.abs(x[~dead] - ref["x"][~dead]).max() < 1e-8 and np.abs(u[~dead] - ref["u"][~dead]).max() < 1e-8
     sol.close()
+
+
+def test_c_callables_synth32_with_probed_structure(pkg, oracle):
+    """BASELINE config 5's model handed over as C callables (examples/synth32_model.c): ilqr_compile_model finds the 32
+    state-dependent Jacobian entries of 1280 and the 40 structurally non-zero Hessian entries of 1344 by probing the callables on the
+    host (the sizes of the generated Model_synth32's tables) and the large kernels run on them; against the oracle and against the
+    generated model (the constants are the host libm's here and the device's there: last-bit differences only)."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "examples", "synth32_model.c"), "rb").read()
+
+    class Src(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+    L = pkg._ffi.lib()
+    ms = Src(b"synth32_c", 32, 8, 0, 16, 0, (1 << 16) - 1, 0, text)
+    name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
+    assert L.ilqr_compile_model(C.byref(ms), name, 128, path, 1024) == 0, L.ilqr_last_error().decode()
+    jv, hs = C.c_int32(), C.c_int32()
+    assert L.ilqr_model_compact_sizes(name.value, C.byref(jv), C.byref(hs)) == 0 and (jv.value, hs.value) == (32, 40)
+    B = 6
+    model, T, x1, ub = pkg.workloads.make_inputs("synth32", B)
+    ub = ub + 1.5 * np.sin(0.37 * np.arange(ub.size).reshape(ub.shape))     # start outside the action box
+    out = {}
+    for label, mdl in (("c", name.value.decode()), ("generated", model)):
+        sol = pkg.Solver(model=mdl, horizon=T, batch=B, options=pkg.Options(verbose=0))
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        out[label] = (sol.get_trajectory(), sol.get_policy(), sol.stats(), sol.buffer("jacobian_state"), sol.buffer("hessian_action_action"))
+        sol.close()
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=6)
+    (x, u), (K, _), st, fx, guu = out["c"]
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"]) & (st["outer_iterations"] == ref["stats"]["outer_iterations"])
+    assert same.all()
+    assert np.abs(x - ref["x"]).max() < 1e-7 and np.abs(u - ref["u"]).max() < 1e-7
+    assert np.abs(K - ref["K"]).max() <= 5e-7 * np.abs(ref["K"]).max()
+    (xg, ug), _, stg, fxg, guug = out["generated"]
+    assert np.array_equal(st["iterations"], stg["iterations"]) and np.abs(x - xg).max() < 1e-9
+    # the mirror of the compact rows reads like the reference's full buffers whichever way the tables were made
+    assert np.abs(fx - fxg).max() < 1e-13 and np.abs(guu - guug).max() <= 1e-12 * np.abs(guug).max()
