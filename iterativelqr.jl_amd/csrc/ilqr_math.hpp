@@ -101,8 +101,16 @@ ILQR_HD void sincos_reduced(double r, double& s, double& c) {
 // |x| >= 2^30 (1e9 rad: only diverged line-search trials get there, and those are
 // rejected) the argument is first folded coarsely by multiples of 2*pi; that path
 // is finite and deterministic but loses ~|x|*2^-52 rad of accuracy, unlike libm.
+// |x| >= 2^30 on SOME lane of the wave: a wave-uniform branch (v_cmp + s_cbranch_vccnz) around the rare coarse folding instead
+// of an exec-masked region (v_cmp, s_and_saveexec, s_cbranch_execz, s_or exec) on the serial rollout chain; the folding loop
+// itself stays per lane
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ILQR_ANY_HUGE(x) __builtin_expect(__builtin_amdgcn_ballot_w64(!(fabs(x) < 1073741824.0)) != 0, 0)
+#else
+#define ILQR_ANY_HUGE(x) (!(fabs(x) < 1073741824.0))
+#endif
 ILQR_HD void sincos_fast(double x, double& s, double& c) {
-    if (!(fabs(x) < 1073741824.0)) {
+    if (ILQR_ANY_HUGE(x)) {
 #pragma clang loop unroll(disable)
         for (int it = 0; it < 24 && !(fabs(x) < 1073741824.0) && x == x; ++it) {
             const double k = rint(x * 1.5915494309189535e-01);
@@ -153,7 +161,7 @@ ILQR_HD TrigPair trig_pair_constants(bool odd) {
 }
 // kernel value of this lane (sine kernel on even, cosine kernel on odd lanes) and the quadrant of the argument
 ILQR_HD double trig_pair_own(double x, const TrigPair& t, int& quadrant) {
-    if (!(fabs(x) < 1073741824.0)) {
+    if (ILQR_ANY_HUGE(x)) {
 #pragma clang loop unroll(disable)
         for (int it = 0; it < 24 && !(fabs(x) < 1073741824.0) && x == x; ++it) {
             const double k = rint(x * 1.5915494309189535e-01);
