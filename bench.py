@@ -266,9 +266,9 @@ def worker(args, solver_factory=None):
     sol = sols[0]
     for s_ in sols:
         s_.set_kernel_variant_(args.variant)
-    if len(sols) > 1 and args.variant == "auto":   # several batches in flight: which kernel fills the SIMDs freed by early finishers best
-        for s_ in sols:
-            s_.set_kernel_variant_(os.environ.get("ILQR_INFLIGHT_VARIANT", "latency"))
+    if len(sols) > 1 and args.variant == "auto":   # several batches in flight: the latency kernel fills the SIMDs freed by early finishers best
+        for s_ in sols:                            # (the secondary inflight_2 figure below pins the same kernel: set_kernel_variant_(args.variant) resolves to it at 1024 instances)
+            s_.set_kernel_variant_("latency")
     counter = [0]
 
     def step():

@@ -183,7 +183,11 @@ int ilqr_get_stats(ilqr_handle* h, ilqr_stats* stats);
  * "hessian_action_action","hessian_action_state","K","k","P","p",
  * "gradient_state_lagrangian"(Qx−p),"gradient_action_lagrangian"(Qu),
  * "violations","constraint_dual","constraint_penalty","active_set","parameters".
- * Layout: [B][per-instance length]; ilqr_buffer_len gives the per-instance length. */
+ * Layout: [B][per-instance length]; ilqr_buffer_len gives the per-instance length.
+ * Large models (nx > 4 or nu > 4): the kernels work on compact rows (state-dependent Jacobian entries, structurally non-zero
+ * Hessian entries); the full jacobian_* / hessian_* arrays are a mirror. A value written with ilqr_set_buffer at a constant
+ * Jacobian position or outside the Hessian pattern cannot be represented there and is dropped: ilqr_get_buffer afterwards
+ * returns what the kernels use (the constant, a zero), not what was written. */
 int ilqr_buffer_len(const ilqr_handle* h, const char* name, size_t* len);
 int ilqr_get_buffer(ilqr_handle* h, const char* name, double* out);
 int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in);
@@ -258,7 +262,8 @@ int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launch
  * source is compiled a second time with the host C++ compiler (ILQR_HOSTCXX, else g++ / c++ / clang++) and the Jacobian,
  * Hessian and constraint-Jacobian callables are evaluated at three points; an entry bitwise equal at all of them is a constant
  * (the role Symbolics' sparse expressions play in the reference, src/dynamics.jl:16-34). Source that does not compile for the
- * host, or ILQR_NO_STRUCTURE_PROBE in the environment, leaves every entry state-dependent / non-zero (correct, more traffic).
+ * host, or ILQR_NO_STRUCTURE_PROBE in the environment, leaves every entry state-dependent / non-zero (correct, more traffic;
+ * accepted up to nx = 16 only — beyond that the dense forms are refused with ILQR_ERR_MODEL).
  * The dynamics callable itself stays opaque: every lane of the rollout evaluates the whole vector function. */
 typedef struct {
     const char* name;        /* C identifier */

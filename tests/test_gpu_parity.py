@@ -1480,3 +1480,30 @@ def test_c_callables_synth32_with_probed_structure(pkg, oracle):
     assert np.array_equal(st["iterations"], stg["iterations"]) and np.abs(x - xg).max() < 1e-9
     # the mirror of the compact rows reads like the reference's full buffers whichever way the tables were made
     assert np.abs(fx - fxg).max() < 1e-13 and np.abs(guu - guug).max() <= 1e-12 * np.abs(guug).max()
+
+
+def test_large_model_setter_shows_what_the_kernels_will_use(pkg):
+    """Large path: the full jacobian_* / hessian_* arrays are a mirror of the compact rows the kernels stream. A host write at a
+    CONSTANT Jacobian position, or outside the structural Hessian pattern, cannot be represented in the compact form: it is
+    dropped, and a getter afterwards must return what the kernels will use — the generated constant, a zero — not the value
+    written (advisor finding, round 3: the getter kept returning the host's values). Entries inside the pattern round-trip."""
+    B = 2
+    model, T, x1, ub = pkg.workloads.make_inputs("synth32", B)
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.initialize_rollout_(x1, ub); sol.run_stage_("cost_nominal"); sol.run_stage_("gradients")
+    fx = sol.buffer("jacobian_state").reshape(B, T - 1, 32, 32).copy()        # [b][t][column][row]
+    gxx = sol.buffer("hessian_state_state").reshape(B, T, 32, 32).copy()
+    w = fx.copy()
+    w[:, :, 3, 5] += 7.0            # (row 5, column 3): a constant entry of A
+    w[:, :, 4, 4] += 0.25           # a diagonal entry: state-dependent, representable
+    sol.set_buffer("jacobian_state", w)
+    back = sol.buffer("jacobian_state").reshape(B, T - 1, 32, 32)
+    assert np.array_equal(back[:, :, 3, 5], fx[:, :, 3, 5])                   # the constant stands
+    assert np.array_equal(back[:, :, 4, 4], w[:, :, 4, 4])                    # the state-dependent entry took the write
+    h = gxx.copy()
+    h[:, :, 1, 2] = 3.0             # off the diagonal: outside the pattern of this model's Hessians
+    h[:, :, 6, 6] += 1.5
+    sol.set_buffer("hessian_state_state", h)
+    back = sol.buffer("hessian_state_state").reshape(B, T, 32, 32)
+    assert (back[:, :, 1, 2] == 0.0).all() and np.array_equal(back[:, :, 6, 6], h[:, :, 6, 6])
+    sol.close()
