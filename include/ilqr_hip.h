@@ -204,7 +204,10 @@ int ilqr_enable_action_value_buffers(ilqr_handle* h);
  * non-positive pivot and were repeated in LAPACK's literal arithmetic — 0 on healthy instances). -1 if unknown. */
 int ilqr_scalar_slot(const char* name);
 
-/* Kernel variant of ilqr_solve (small models, nx, nu <= 4; large models have one kernel family): 0 = auto — the latency kernel
+/* Kernel variant of ilqr_solve. Large models (nx > 4 or nu > 4): 0 = auto, 1 = four waves per instance (two instances per CU),
+ * 4 = ONE wave per instance (eight per CU) for models whose matrices are single 16x16 tiles (nx, nu <= 16) — the same phase
+ * functions with the four wave roles of a phase run in turn, bitwise the four-wave results; auto takes it once the batch exceeds
+ * 8 x CUs (an instance alone is faster on four waves; residency wins beyond that). Small models (nx, nu <= 4): 0 = auto — the latency kernel
  * (two waves per instance, all iteration state in LDS) while the batch fits the chip at one instance per SIMD (batch <= 4 x CUs),
  * the packed kernel beyond that and for horizons whose LDS-resident set exceeds the 160 KiB of a CU; 1 = latency; 2 = throughput
  * (one wave per instance, Jacobians in HBM / L2; superseded by the packed kernel, kept for A/B runs); 3 = packed — FOUR

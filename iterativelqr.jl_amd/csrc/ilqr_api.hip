@@ -109,7 +109,7 @@ struct ilqr_handle {
     int handover;         // straggler hand-over of the packed kernel: -1 auto (by head count), 0 off, k > 1 = instances entering outer iteration k
     int handover_live;    // head-count rule: survivors of the batch at which they all leave (-1 auto, 0 off)
     int* done_counter;    // device counter of finished instances for that rule
-    int variant;          // 0 auto, 1 latency kernel (all-LDS, 2 waves per instance), 2 throughput kernel (slim), 3 packed kernel (4 instances per wave, no LDS)
+    int variant;          // 0 auto, 1 latency kernel (all-LDS, 2 waves per instance; large models: four waves per instance), 2 throughput kernel (slim), 3 packed kernel (4 instances per wave, no LDS), 4 one wave per instance of a large model with nx, nu <= 16
     bool lds_fits;        // the LDS-resident kernels can hold this horizon (otherwise only the packed kernel runs it)
     int num_simds;
     double* qv;           // optional action-value buffers Qx, Qu, Qxx, Quu, Qux (allocated on first use by a getter)
@@ -799,6 +799,16 @@ int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u) {
     return ILQR_OK;
 }
 
+// Large models whose matrices are single tiles (nx, nu <= 16): the four-wave kernel holds 2 instances per CU, the one-wave kernel 8.
+// An instance alone is faster on four waves (its windows run their tiles side by side: 3.9 k against 5.3 k clk per Riccati step on
+// synth12, the rollout beside the sensitivity sweep instead of behind it), so auto takes one wave per instance only where residency
+// wins: beyond 8 instances per CU the four-wave kernel works in more than four rounds (tools/mid_bench.py: equal at 2048 instances
+// on 256 CUs, 1.28x at 4096, 1.47x at 8192).
+static bool use_mid(const ilqr_handle* h) {
+    if (h->vt->launch_solve_mid == nullptr) return false;
+    return h->variant == 4 || (h->variant == 0 && h->B > 2 * h->num_simds);
+}
+
 int ilqr_initialize_rollout_resident(ilqr_handle* h) {
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_initialize_rollout_resident(s); });
@@ -857,6 +867,8 @@ int ilqr_solve(ilqr_handle* h) {
     } else if (slim) {
         if (h->vt->launch_solve_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
             return drop(fail(ILQR_ERR_HIP, "solve (throughput variant) launch failed"));
+    } else if (use_mid(h)) {
+        if (h->vt->launch_solve_mid(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (one-wave variant) launch failed"));
     } else if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve launch failed"));
     if (hipEventRecord(e1, h->stream) != hipSuccess) return drop(fail(ILQR_ERR_HIP, "hipEventRecord failed"));
     h->timing.emplace_back(e0, e1);
@@ -882,6 +894,8 @@ int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t fl
     if (h->variant == 2 && h->vt->launch_stage_slim != nullptr) {
         if (h->vt->launch_stage_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
             return fail(ILQR_ERR_HIP, "stage (throughput variant) launch failed");
+    } else if (h->variant == 4 && h->vt->launch_stage_mid != nullptr) {
+        if (h->vt->launch_stage_mid(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "stage (one-wave variant) launch failed");
     } else if (h->vt->launch_stage(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "stage launch failed");
     if (h->vt->launch_mirror) h->full_stale = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1005,7 +1019,9 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
 
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
     if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_kernel_variant(s, variant); });
-    if (!h || variant < 0 || variant > 3) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency), 2 (throughput) or 3 (packed)");
+    if (!h || variant < 0 || variant > 4) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency), 2 (throughput), 3 (packed) or 4 (one wave per instance of a large model)");
+    if (variant == 4 && h->vt->launch_solve_mid == nullptr)
+        return fail(ILQR_ERR_INVALID, "the one-wave variant exists for large models with nx, nu <= 16 only");
     if (variant == 3 && h->vt->launch_solve_packed == nullptr)
         return fail(ILQR_ERR_INVALID, "the packed variant exists for small models (nx, nu <= 4) only");
     if ((variant == 1 || variant == 2) && !h->lds_fits)

@@ -107,7 +107,14 @@ template <class M> struct slim_of<M, decltype((void)M::SLIM)> { static constexpr
 // sensitivity sweep while wave 0 runs the first rollout; the small-model Riccati recursion stays on wave 0 (a
 // 1 k-cycle step cannot pay for a barrier), the large-model one splits its MFMA tiles. Scalars produced by one
 // wave are handed to the other through LDS.
-template <class M> struct waves_of { static constexpr int value = is_large<M>::value ? LARGE_WAVES : (slim_of<M>::value ? 1 : 2); };
+// One-wave ("mid") variant of a LARGE model whose matrices are single 16x16 tiles (nx <= 16): the same phase functions as the
+// four-wave large path, with the four wave roles of a phase executed one after the other by ONE wave per instance — four times
+// the instances per CU (two waves per SIMD all the same) for batches beyond what the four-wave kernel holds resident.
+template <class M> struct Mid : M { static constexpr bool MID = true; };
+template <class M, class = void> struct mid_of { static constexpr bool value = false; };
+template <class M> struct mid_of<M, decltype((void)M::MID)> { static constexpr bool value = M::MID; };
+template <class M> struct mid_ok { static constexpr bool value = is_large<M>::value && M::NX <= 16 && M::NU <= 16; };
+template <class M> struct waves_of { static constexpr int value = is_large<M>::value ? (mid_of<M>::value ? 1 : LARGE_WAVES) : (slim_of<M>::value ? 1 : 2); };
 // Two-wave latency kernel, models with one action: the Lagrangian gradient ∇L (src/solve.jl:67-83) is written straight to its place
 // in the instance's HBM block by the short Riccati form (backward_pass_m1) and never kept current in LDS — nothing reads it back
 // inside a launch (‖∇L‖∞ and ∇Lᵀ·Δz are carried in registers); the LDS copy a launch starts with (loaded with the rest of the set)
@@ -1914,7 +1921,7 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
 
 // solve!(solver) for every instance — src/solve.jl:137-143
 template <class M>
-__global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs a) {      // (second parameter: waves per SIMD -> 256 VGPRs)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -2127,7 +2134,7 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 7   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+#define ILQR_MODEL_ABI_VERSION 8   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against
@@ -2144,6 +2151,9 @@ extern "C" struct ilqr_model_vtable {
     // the kernel that writes the host-visible full arrays from it (dir 0) or reads them back (dir 1)
     int jac_nvar, hess_nnz;
     int (*launch_mirror)(const ilqr::KArgs* a, int dir, void* stream);
+    // large models whose matrices are single 16x16 tiles (nx, nu <= 16), null otherwise: the one-wave-per-instance variant
+    int (*launch_solve_mid)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);
+    int (*launch_stage_mid)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);
 };
 
 namespace ilqr {
@@ -2204,6 +2214,28 @@ struct ModelModule {
             return -1;
         }
     }
+    static int launch_solve_mid(const KArgs* a, size_t lds, void* stream) {
+        if constexpr (mid_ok<M>::value) {
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<Mid<M>>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+            hipLaunchKernelGGL(solve_kernel<Mid<M>>, dim3(a->B), dim3(64), lds, (hipStream_t)stream, *a);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        } else {
+            return -1;
+        }
+    }
+    static int launch_stage_mid(const KArgs* a, size_t lds, void* stream) {
+        if constexpr (mid_ok<M>::value) {
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<Mid<M>>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+            hipLaunchKernelGGL(stage_kernel<Mid<M>>, dim3(a->B), dim3(64), lds, (hipStream_t)stream, *a);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        } else {
+            return -1;
+        }
+    }
     static int launch_init(const KArgs* a, void* stream) {
         if constexpr (is_large<M>::value) hipLaunchKernelGGL(init_rollout_large_kernel<M>, dim3(a->B), dim3(64), 0, (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(init_rollout_kernel<M>, dim3((a->B + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
@@ -2226,7 +2258,8 @@ struct ModelModule {
                                              is_large<M>::value ? nullptr : &launch_solve_slim,
                                              is_large<M>::value ? nullptr : &launch_stage_slim,
                                              packed_ok<M>::value ? &launch_solve_packed : nullptr,
-                                             jac_nvar(), hess_nnz(), is_large<M>::value ? &launch_mirror : nullptr};
+                                             jac_nvar(), hess_nnz(), is_large<M>::value ? &launch_mirror : nullptr,
+                                             mid_ok<M>::value ? &launch_solve_mid : nullptr, mid_ok<M>::value ? &launch_stage_mid : nullptr};
         return &vt;
     }
 };

@@ -36,7 +36,7 @@ constexpr int r4(int v) { return (v + 3) & ~3; }
 
 template <class M>
 struct LargeDims {
-    static constexpr int n = M::NX, m = M::NU, W = LARGE_WAVES, NT = 64 * LARGE_WAVES;
+    static constexpr int n = M::NX, m = M::NU, W = waves_of<M>::value, NT = 64 * W;      // W = 4, or 1 for the one-wave variant (Mid<M>)
     static constexpr int NP = r16(n), MP = r16(m);          // whole 16x16 tiles; the padding is kept at zero
     static constexpr int TN = NP / 16;
     static constexpr int ld = NP + 1, ldm = MP + 1;         // odd leading dimensions: conflict-free LDS column walks
@@ -266,8 +266,9 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
     // of timestep t while waves 2, 3 do the rest of the same t (wave-uniform roles: no divergence; both halves read x̄_t, ū_t).
     // Hessians accumulate: each timestep exactly once.
     constexpr bool JE = M::JAC_VAR_ELEMENTWISE;
-    constexpr int NH = JE ? NT : NT / 2;
-    const int half = JE ? 1 : __builtin_amdgcn_readfirstlane(tid / NH);
+    constexpr bool ONE = LD::W == 1;                       // one wave: no roles, every thread does both halves of its timestep
+    constexpr int NH = (JE || ONE) ? NT : NT / 2;
+    const int half = (JE || ONE) ? 1 : __builtin_amdgcn_readfirstlane(tid / NH);
     if constexpr (JE) {
         constexpr int JV = LD::JV;
         for (int e = tid; e < N * JV; e += NT) {
@@ -284,7 +285,7 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = A.xb[t * n + i];
         if constexpr (!JE) {
-            if (half == 0) {
+            if (ONE || half == 0) {
                 if (t < N) {
                     double ut[m];
 #pragma unroll
@@ -295,7 +296,7 @@ __attribute__((noinline)) __device__ void gradients_large_fn(gdbl* base, int con
 #pragma unroll
                     for (int q = 0; q < LD::JV; ++q) A.fv[(size_t)t * LD::JVP + q] = v[q];
                 }
-                continue;
+                if (!ONE) continue;
             }
         }
         double* hrow = (double*)(A.hc + (size_t)t * LD::HSP);
@@ -555,6 +556,14 @@ __device__ __forceinline__ void wave_switch(int wave, F&& f) {
     }
 }
 
+// the four roles of a window: one per wave, or all of them in turn on the instance's only wave (one-wave variant: every tile list
+// of a window is independent of the others', and windows stay separated by the barriers, which a single wave passes at once)
+template <int NWAVES, class F>
+__device__ __forceinline__ void role_switch(int wave, F&& f) {
+    if constexpr (NWAVES == 1) static_for<0, 4>(f);
+    else wave_switch(wave, f);
+}
+
 struct RiccatiOut {
     double gradient_norm; int potrf_info;
 #if defined(ILQR_PROFILE) && defined(ILQR_PROFILE_SUB)
@@ -567,14 +576,16 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     typedef LargeDims<M> LD;
     constexpr int n = M::NX, m = M::NU, NP = LD::NP, ld = LD::ld, ldm = LD::ldm, TN = LD::TN, NT = LD::NT;
     constexpr int n4 = LD::n4, m4 = LD::m4, JV = LD::JV, JVP = LD::JVP, HXX = LD::HXX, HUU = LD::HUU, HUX = LD::HUX, HSP = LD::HSP;
-    constexpr int NS = NT - 64;                            // threads that fetch the next step's operands: waves 1..3 (wave 0 only stores)
+    constexpr int NWV = LD::W;                             // 4, or 1: the four roles of a window run one after the other on the instance's only wave
+    constexpr int NS = NWV == 1 ? 64 : NT - 64;            // threads that fetch the next step's operands: waves 1..3 (wave 0 only stores)
+    constexpr int FOFF = NWV == 1 ? 0 : 64;                // ... and the first of them
     constexpr int EJ = (JV + NS - 1) / NS > 0 ? (JV + NS - 1) / NS : 1;            // Jacobian patch entries per fetching thread
     constexpr int EU = (HUU + HUX + 63) / 64 > 0 ? (HUU + HUX + 63) / 64 : 1;      // guu / gux entries per lane of wave 0
     typedef RicSchedule<TN> RS;
     constexpr int SLOTS = RS::SLOTS;                       // Qxx / P tiles per wave (waves 1..3)
     static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
     static_assert(LD::total == large_lds_doubles(n, m, LD::HS), "LDS carve and host-side size disagree");
-    static_assert(waves_of<M>::value == LARGE_WAVES, "the Riccati step is scheduled over four waves per instance");
+    static_assert(NWV == LARGE_WAVES || (NWV == 1 && TN == 1), "the Riccati step is scheduled over four waves per instance, or run by one when every matrix is a single tile");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     const LargeArgs A = large_args_from_lds<M>(base);
     struct { double prof[6]; } I;
@@ -613,9 +624,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     int poff[EJ];
 #pragma unroll
     for (int j = 0; j < EJ; ++j) {
-        const int q = (tid - 64) + NS * j;
+        const int q = (tid - FOFF) + NS * j;
         poff[j] = -1;
-        if (tid >= 64 && q < JV) {
+        if (tid >= FOFF && q < JV) {
             const int idx = M::JAC_VAR_IDX[q];
             poff[j] = idx < n * n ? LD::oFx + (idx / n) * ld + idx % n : LD::oFu + ((idx - n * n) / n) * ld + (idx - n * n) % n;
         }
@@ -633,20 +644,25 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     // Qxx tiles of this wave in window C: slot s holds tile RS::tab.qxx[wave][s]; its gxx entries sit at
     // [HESS_XX_TILE_START[q], HESS_XX_TILE_START[q + 1]) of the compact row, lane x of them at +lane (+64, ...)
     constexpr int EXT = 4;                                 // a 16x16 tile has at most 256 entries
-    int xcnt[SLOTS], xbeg[SLOTS], xoff[SLOTS][EXT];
+    constexpr int XR = NWV == 1 ? 4 : 1;                   // one wave: it plays every role, so it keeps every role's table
+    int xoff[XR][SLOTS][EXT];
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int q = RS::tab.qxx[wave][s] < 0 ? -1 : (RS::tab.qxx[wave][s] & ~RS::RIC_WAIT_T);
-        const bool have = q >= 0;
-        xbeg[s] = have ? M::HESS_XX_TILE_START[have ? q : 0] : 0;
-        xcnt[s] = have ? M::HESS_XX_TILE_START[(have ? q : 0) + 1] - xbeg[s] : 0;
+    for (int rr = 0; rr < XR; ++rr) {
+        const int role = NWV == 1 ? rr : wave;
 #pragma unroll
-        for (int x = 0; x < EXT; ++x) {
-            xoff[s][x] = -1;
-            const int e = lane + 64 * x;
-            if (e < xcnt[s]) {
-                const int idx = M::HESS_IDX[xbeg[s] + e];
-                xoff[s][x] = oQ + (idx / n) * ld + idx % n;
+        for (int s = 0; s < SLOTS; ++s) {
+            const int q = RS::tab.qxx[role][s] < 0 ? -1 : (RS::tab.qxx[role][s] & ~RS::RIC_WAIT_T);
+            const bool have = q >= 0;
+            const int xbeg = have ? M::HESS_XX_TILE_START[have ? q : 0] : 0;
+            const int xcnt = have ? M::HESS_XX_TILE_START[(have ? q : 0) + 1] - xbeg : 0;
+#pragma unroll
+            for (int x = 0; x < EXT; ++x) {
+                xoff[rr][s][x] = -1;
+                const int e = lane + 64 * x;
+                if (e < xcnt) {
+                    const int idx = M::HESS_IDX[xbeg + e];
+                    xoff[rr][s][x] = oQ + (idx / n) * ld + idx % n;
+                }
             }
         }
     }
@@ -658,7 +674,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     if (N > 0) {
 #pragma unroll
         for (int j = 0; j < EJ; ++j)
-            if (poff[j] >= 0) S[poff[j]] = A.fv[(size_t)(N - 1) * JVP + (tid - 64) + NS * j];
+            if (poff[j] >= 0) S[poff[j]] = A.fv[(size_t)(N - 1) * JVP + (tid - FOFF) + NS * j];
     }
     // Compact operands of a step: the state-dependent Jacobian entries go straight into the LDS copies of fx, fu (pval), the
     // Hessian row and the cost gradients [hc | gx | gu] into an LDS staging row. Both are requested at the top of the PREVIOUS
@@ -677,11 +693,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     int rbase[ER], rstride[ER];
 #pragma unroll
     for (int j = 0; j < ER; ++j) {
-        const int e = (tid - 64) + NS * j;
+        const int e = (tid - FOFF) + NS * j;
         const int gx_rel = (int)(A.gx - A.hc), gu_rel = (int)(A.gu - A.hc);
         rstride[j] = e < HSP ? HSP : (e < HSP + n ? n : m);
         rbase[j] = e < HSP ? e : (e < HSP + n ? gx_rel + (e - HSP) : gu_rel + (e - HSP - n));
-        if (!(tid >= 64 && e < HSP + NG)) rstride[j] = 0;                  // (0 = no element; bases may be negative: gx, gu lie before hc)
+        if (!(tid >= FOFF && e < HSP + NG)) rstride[j] = 0;                  // (0 = no element; bases may be negative: gx, gu lie before hc)
     }
     auto stage_load = [&](int t, double (&R)[ER]) {
 #pragma unroll
@@ -693,9 +709,9 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     int soff[ER];
 #pragma unroll
     for (int j = 0; j < ER; ++j) {
-        const int e = (tid - 64) + NS * j;
+        const int e = (tid - FOFF) + NS * j;
         soff[j] = -1;
-        if (tid >= 64 && e < HSP + NG) {
+        if (tid >= FOFF && e < HSP + NG) {
             soff[j] = LD::oStg + e;
             if (e >= HXX && e < HXX + HUU + HUX) {
                 const int idx = M::HESS_IDX[e];
@@ -713,16 +729,17 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     __syncthreads();
     // wave 0 carries the step's critical path in every window (ûx, Qux, the chain, a P tile) and shares its SIMD with a wave of the
     // CU's other instance: its instructions go first whenever they can issue
-    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+    if (NWV > 1 && wave == 0) __builtin_amdgcn_s_setprio(3);
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
         ILQR_SUB_BEGIN();
         const int tn = t > 0 ? t - 1 : 0;                                 // (t = 0: a harmless re-read instead of a branch)
         // operands of the NEXT step, requested now (issuing them in the shadow of the window's first tile instead was measured:
         // the window got 450 clk longer)
-        if (wave != 0) {                                                  // (wave 0 requests nothing: a scalar branch past it all)
+        bool placed = false;                                              // (one wave: the next step's operands are put into LDS once, not once per role)
+        if (NWV == 1 || wave != 0) {                                      // (wave 0 requests nothing: a scalar branch past it all)
             if (STAGE) stage_load(tn, rval);
 #pragma unroll
-            for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[tn * JVP + (tid - 64) + NS * j] : 0.0;
+            for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[tn * JVP + (tid - FOFF) + NS * j] : 0.0;
         }
         // ------------------------------------------------ window A: ûx = fuᵀP′ (:57) | T = fxᵀP′ (:52)
         auto run_tiles = [&](auto Wc, auto WINc) {                        // window WIN's tasks of wave W, all compile-time
@@ -750,14 +767,14 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
             });
         };
-        wave_switch(wave, [&](auto Wc) { run_tiles(Wc, IntC<0>{}); });
+        role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<0>{}); });
         ILQR_SUB_MARK2(I, 0);
         __syncthreads();                                                  // (B1) ûx complete
         ILQR_SUB_MARK1(I, 0); ILQR_SUB_MARK2(I, 1);
         // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | T
-        wave_switch(wave, [&](auto Wc) { run_tiles(Wc, IntC<1>{}); });
+        role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<1>{}); });
         // wave 3 (no tile in this window when nx <= 32): the two matrix-vector products of the step
-        if (wave == 3) {
+        if (NWV == 1 || wave == 3) {
             {
                 // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum
                 constexpr int JP = (n + 3) / 4;
@@ -800,7 +817,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         ILQR_SUB_MARK1(I, 1); ILQR_SUB_MARK2(I, 3);
         // ------------------------------------------------ window C: the serial chain and p, ∇L | Qx, Qu, Qxx
         double pn = 0.0;
-        if (wave == 0) {
+        if (NWV == 1 || wave == 0) {
             double Lxv, Luv;
             // Quu += guu, Qux += gux (:59, :64): the structurally non-zero entries only
             // (with the staging row the producing waves have added them already)
@@ -900,7 +917,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 if (lane < m) A.Lu[t * m + lane] = Luv;
             }
             ILQR_SUB_MARK1(I, 3);
-        } else wave_switch(wave, [&](auto Wc) {
+        }
+        if (NWV == 1 || wave != 0) role_switch<NWV>(wave, [&](auto Wc) {
             constexpr int W = decltype(Wc)::value;
             if constexpr (W > 0 && RS::tab.ct[W][0] >= 0) {     // what is left of T; a Qxx tile on another wave may wait for it
                 run_tiles(Wc, IntC<2>{});
@@ -927,7 +945,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         wave_lds_fence();
 #pragma unroll
                         for (int x = 0; x < (xc + 63) / 64; ++x)
-                            if (xoff[s][x] >= 0) S[xoff[s][x]] += STAGE ? sH[xb + lane + 64 * x] : (double)A.hc[(size_t)t * HSP + xb + lane + 64 * x];
+                            if (xoff[NWV == 1 ? W : 0][s][x] >= 0) S[xoff[NWV == 1 ? W : 0][s][x]] += STAGE ? sH[xb + lane + 64 * x] : (double)A.hc[(size_t)t * HSP + xb + lane + 64 * x];
                     }
                     if (STORE_VALUE && Qv != nullptr) {
                         wave_lds_fence();
@@ -950,12 +968,14 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
         // (unconditional: at t = 0 it rewrites step 0's own values, and the loads must be consumed on every path through the loop —
         // a path that skipped them would leave them pending at the loop edge and every iteration would start by waiting)
         auto place_next = [&]() {
+            if (NWV == 1 && placed) return;
+            placed = true;
 #pragma unroll
             for (int j = 0; j < EJ; ++j)
                 if (poff[j] >= 0) S[poff[j]] = pval[j];
             if (STAGE) stage_store(rval);
         };
-        wave_switch(wave, [&](auto Wc) { static_for<0, SLOTS>([&](auto Sc) {
+        role_switch<NWV>(wave, [&](auto Wc) { static_for<0, SLOTS>([&](auto Sc) {
             constexpr int q = RS::tab.p[decltype(Wc)::value][decltype(Sc)::value];
             constexpr bool first = decltype(Sc)::value == 0;
             if constexpr (q < 0 && first) place_next();
@@ -996,7 +1016,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
             }
         }); });
-        if (wave == 0 && lane < n) sp[lane] = pn;                         // p' of the next step (its readers of this step are past B3)
+        if ((NWV == 1 || wave == 0) && lane < n) sp[lane] = pn;                         // p' of the next step (its readers of this step are past B3)
         __syncthreads();                                                  // (B0) P′, p′, patched fx, fu visible
         ILQR_SUB_MARK1(I, 5); ILQR_SUB_MARK2(I, 5);
     }
@@ -1121,6 +1141,32 @@ __device__ __forceinline__ double dyn_row(const DynAff<M>& aff, const double* sx
     return y;
 }
 
+// K, a, b of [c0, c0 + CH) into the ring half (c0 / CH) & 1 by `nthreads` threads (this one is number `me` of them): every load of
+// a thread is issued before its first LDS write (a load-store loop would pay one HBM round trip per element: seventeen in a row
+// made the stagers slower than the rollout)
+template <class M>
+__device__ __forceinline__ void fw_stage_chunk(const LargeArgs& A, double* ring, int c0, int nthreads, int me) {
+    typedef LargeDims<M> LD;
+    constexpr int m = M::NU, CH = LD::CH, KN = M::NU * M::NX;
+    constexpr int NE = LD::W == 1 ? (CH * LD::RSTEP + 63) / 64 : (CH * LD::RSTEP + 127) / 128;     // elements per thread with the fewest stagers (one wave / two waves)
+    const int N = A.N, steps = (N - c0) < CH ? (N - c0) : CH;
+    double* dst = ring + ((c0 / CH) & 1) * CH * LD::RSTEP;
+    const gdbl* srcK = A.K + (size_t)c0 * KN;
+    const long ab_rel = (A.ab + (size_t)c0 * 2 * m) - srcK;            // same instance block: one base, selected offsets
+    double v[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const int e = me + nthreads * q, st = e / LD::RSTEP, r = e % LD::RSTEP;
+        const long off = r < KN ? (long)st * KN + r : ab_rel + st * 2 * m + (r - KN);
+        v[q] = e < steps * LD::RSTEP ? (double)srcK[off] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const int e = me + nthreads * q;
+        if (e < steps * LD::RSTEP) dst[e] = v[q];
+    }
+}
+
 // wave 0: the closed-loop rollout, one chunk of the K ring per workgroup barrier
 template <class M>
 __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
@@ -1158,6 +1204,7 @@ __attribute__((noinline)) __device__ void fw_rollout_wave(gdbl* base) {
             if (lane < n) A.x[(t + 1) * n + lane] = y;
             wave_lds_fence();
         }
+        if (LD::W == 1 && c0 + CH < N) fw_stage_chunk<M>(A, ring, c0 + CH, 64, lane);     // one wave: it stages its own next chunk
         __syncthreads();
     }
 }
@@ -1238,6 +1285,7 @@ __attribute__((noinline)) __device__ double fw_delta_wave(gdbl* base) {
             kv = kv_n; Luv = Luv_n; Lxv = Lxv_n;
             wave_lds_fence();
         }
+        if (LD::W == 1 && c0 + CH < N) fw_stage_chunk<M>(A, ring, c0 + CH, 64, lane);
         __syncthreads();
     }
     return wave_sum(dpart);
@@ -1273,31 +1321,22 @@ __attribute__((noinline)) __device__ double forward_sweep_large_fn(gdbl* base, d
         for (int e = tid; e < n * n; e += NT) sFx[(e / n) * ld + e % n] = M::JAC_CONST_FX[0][e];
         for (int e = tid; e < n * m; e += NT) sFu[(e / n) * ld + e % n] = M::JAC_CONST_FU[0][e];
     }
-    // K, a, b of [c0, c0 + CH) into the ring half (c0 / CH) & 1: every load of a thread is issued before its first LDS write
-    // (a load-store loop would pay one HBM round trip per element: seventeen in a row made the stagers slower than the rollout)
-    auto stage = [&](int c0, int nthreads, int me) {
-        constexpr int NE = (CH * LD::RSTEP + 127) / 128;                  // elements per thread with the fewest stagers (two waves)
-        const int steps = (N - c0) < CH ? (N - c0) : CH;
-        double* dst = ring + ((c0 / CH) & 1) * CH * LD::RSTEP;
-        const gdbl* srcK = A.K + (size_t)c0 * KN;
-        const long ab_rel = (A.ab + (size_t)c0 * 2 * m) - srcK;            // same instance block: one base, selected offsets
-        double v[NE];
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = me + nthreads * q, st = e / LD::RSTEP, r = e % LD::RSTEP;
-            const long off = r < KN ? (long)st * KN + r : ab_rel + st * 2 * m + (r - KN);
-            v[q] = e < steps * LD::RSTEP ? (double)srcK[off] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = me + nthreads * q;
-            if (e < steps * LD::RSTEP) dst[e] = v[q];
-        }
-    };
+    auto stage = [&](int c0, int nthreads, int me) { fw_stage_chunk<M>(A, ring, c0, nthreads, me); };
     __syncthreads();                                                      // a_t, b_t (global, written and read by this workgroup only) visible
     if (N > 0) stage(0, NT, tid);
     __syncthreads();                                                      // ring half 0 ready
     double d = 0.0;
+    if constexpr (LD::W == 1) {
+        // one wave per instance: the rollout over the whole horizon (staging its own chunks), then — first trial — the
+        // sensitivity recursion the same way
+        fw_rollout_wave<M>(base);
+        if (want_delta) {
+            if (N > 0) stage(0, NT, tid);
+            __syncthreads();
+            d = fw_delta_wave<M>(base);
+        }
+        return d;
+    }
     if (wave == 0) fw_rollout_wave<M>(base);
     else if (wave == 1 && want_delta) d = fw_delta_wave<M>(base);
     else {

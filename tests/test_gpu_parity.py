@@ -1507,3 +1507,45 @@ def test_large_model_setter_shows_what_the_kernels_will_use(pkg):
     back = sol.buffer("hessian_state_state").reshape(B, T, 32, 32)
     assert (back[:, :, 1, 2] == 0.0).all() and np.array_equal(back[:, :, 6, 6], h[:, :, 6, 6])
     sol.close()
+
+
+def test_one_wave_variant_of_the_large_path_equals_the_four_wave_kernel(pkg, oracle):
+    """Large models whose matrices are single 16x16 tiles (4 < nx <= 16, nu <= 16 — the sizes most models have, and for which the
+    reference sizes its buffers at run time like for any other, /root/reference/src/data/policy.jl:44-78): `mid`, ONE wave per
+    instance running the four wave roles of every phase in turn (eight instances per CU instead of two). Same phase functions,
+    same arithmetic: stage results and whole solves BITWISE those of the four-wave kernel; against the oracle like it (`auto` takes
+    the variant beyond 8 instances per CU: tools/mid_bench.py)."""
+    T, B = 41, 96
+    mdl = pkg.models.synth12()
+    rng = np.random.default_rng(12)
+    x1 = 0.5 * rng.standard_normal((B, 12)); ub = 0.1 * rng.standard_normal((B, T - 1, 5))
+    kw = dict(max_iterations=15, max_dual_updates=3)
+    out = {}
+    for variant in ("latency", "mid"):
+        sol = pkg.Solver([mdl["dynamics"]] * (T - 1), [mdl["cost_stage"]] * (T - 1) + [mdl["cost_term"]],
+                         [mdl["con_stage"]] * (T - 1) + [mdl["con_term"]], batch=B, options=pkg.Options(verbose=0, **kw), name="synth12")
+        sol.set_kernel_variant_(variant)
+        sol.initialize_rollout_(x1, ub)
+        sol.run_stage_("cost_nominal"); sol.run_stage_("gradients"); sol.run_stage_("backward_pass")
+        stage = {k: sol.buffer(k) for k in ("jacobian_state", "hessian_action_action", "K", "k", "P", "p", "gradient_state_lagrangian")}
+        sol.run_stage_("forward_pass")
+        stage["x1"] = sol.buffer("nominal_states"); stage["delta"] = sol.scalar("delta_grad_product"); stage["alpha"] = sol.stats()["step_size"]
+        sol.reset_(); sol.initialize_rollout_(x1, ub); sol.enable_trace_(80); sol.solve_()
+        out[variant] = dict(stage=stage, x=sol.get_trajectory()[0], u=sol.get_trajectory()[1], K=sol.get_policy()[0], st=sol.stats(),
+                            tr=sol.trace(), lam=sol.buffer("constraint_dual"))
+        sol.close()
+    a, b = out["latency"], out["mid"]
+    for k in a["stage"]:
+        assert np.array_equal(a["stage"][k], b["stage"][k], equal_nan=True), k
+    for k in ("iterations", "outer_iterations", "rollouts", "status", "potrf_info", "objective", "max_violation"):
+        assert np.array_equal(a["st"][k], b["st"][k], equal_nan=True), k
+    for k in ("x", "u", "K", "lam", "tr"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    ref = oracle.solve_batch("synth12", T, x1, ub, options=oracle.default_options(**kw), nthreads=4)
+    same = (b["st"]["iterations"] == ref["stats"]["iterations"]) & (b["st"]["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.99 and np.abs(b["x"] - ref["x"])[same].max() < 1e-7
+    # the variant does not exist where a matrix needs more than one tile
+    big = pkg.Solver(model="synth32", horizon=11, batch=2, options=pkg.Options(verbose=0))
+    with pytest.raises(pkg._ffi.IlqrError):
+        big.set_kernel_variant_("mid")
+    big.close()
