@@ -74,7 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
-    ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed", "mid"])
     ap.add_argument("--shared-step", action="store_true",
                     help="optional mode, NOT the reference's behaviour and not the headline: one Armijo step size per inner iteration "
                          "for the whole (multi-GPU) batch, decided on the summed merit — one all-reduce (RCCL over xGMI) of three "
@@ -520,12 +520,13 @@ def worker(args, solver_factory=None):
             from oracle import oracle as O
             threads = host_cores()
             sample = min(B, 64 * threads)
+            oopt = O.default_options(**pkg.workloads.CONFIG_OPTIONS.get(args.config, {}))   # the same solver options as the GPU leg
             c0 = time.perf_counter()
-            O.solve_batch(model, T, x1[:sample], ub[:sample], nthreads=threads, want_policy=False)
+            O.solve_batch(model, T, x1[:sample], ub[:sample], options=oopt, nthreads=threads, want_policy=False)
             c1 = time.perf_counter() - c0
             one = min(sample, 48)
             c0 = time.perf_counter()
-            O.solve_batch(model, T, x1[:one], ub[:one], nthreads=1, want_policy=False)
+            O.solve_batch(model, T, x1[:one], ub[:one], options=oopt, nthreads=1, want_policy=False)
             c_one = time.perf_counter() - c0
             out["cpu_baseline"] = {"value": sample / c1, "unit": "trajectories/s", "cores": threads, "kind": "port",
                                    "single_thread_value": one / c_one,

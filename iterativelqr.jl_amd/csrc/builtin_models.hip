@@ -10,6 +10,7 @@
 #include "models/model_car_goal.h"
 #include "models/model_car_obs.h"
 #include "models/model_synth32.h"
+#include "models/model_synth12.h"
 
 ILQR_DEFINE_MODEL(Model_particle)
 ILQR_DEFINE_MODEL(Model_pendulum_euler)
@@ -18,3 +19,4 @@ ILQR_DEFINE_MODEL(Model_car)
 ILQR_DEFINE_MODEL(Model_car_goal)
 ILQR_DEFINE_MODEL(Model_car_obs)
 ILQR_DEFINE_MODEL(Model_synth32)
+ILQR_DEFINE_MODEL(Model_synth12)

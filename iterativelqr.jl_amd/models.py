@@ -279,6 +279,7 @@ BUILTIN = {
     "car_goal": lambda: car(goal_only=True),
     "car_obs": car_obs,
     "synth32": synth32,
+    "synth12": synth12,        # nx = 12, nu = 5: every matrix ONE 16x16 tile (the one-wave variant of the large path exists for it)
 }
 
 

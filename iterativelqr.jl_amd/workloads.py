@@ -17,12 +17,17 @@ CONFIGS = {
     # inner iterations on average, this one takes ~20 (4..50) — the workload on which the large-model kernels are profiled
     "synth32_tight": ("synth32", 101, True),
     "synth32_tight11": ("synth32", 101, True),     # tolerances 1e-11: ~76 iterations (17..104), few idle SIMDs at the end
+    # a mid-size model (nx = 12, nu = 5, 10 stage inequalities, 3 terminal equalities; oracle twin "synth12"): the sizes for which
+    # the large path has its one-wave-per-instance variant. Iteration caps as in the parity tests (the problem is hard for the
+    # reference's AL loop: parity and throughput, not convergence)
+    "synth12": ("synth12", 101, True),
 }
 # per-config solver options (src/options.jl:1-15 fields) that differ from the defaults
 CONFIG_OPTIONS = {"synth32_tight": dict(objective_tolerance=1.0e-9, lagrangian_gradient_tolerance=1.0e-9),
-                  "synth32_tight11": dict(objective_tolerance=1.0e-11, lagrangian_gradient_tolerance=1.0e-11)}
+                  "synth32_tight11": dict(objective_tolerance=1.0e-11, lagrangian_gradient_tolerance=1.0e-11),
+                  "synth12": dict(max_iterations=15, max_dual_updates=3)}
 DIMS = {"particle": (2, 1), "acrobot": (4, 1), "car": (3, 2), "car_goal": (3, 2), "car_obs": (3, 2),
-        "pendulum_euler": (2, 1), "synth32": (32, 8)}
+        "pendulum_euler": (2, 1), "synth32": (32, 8), "synth12": (12, 5)}
 
 
 def make_inputs(config, batch, seed=SEED, offset=0):
@@ -40,6 +45,9 @@ def make_inputs(config, batch, seed=SEED, offset=0):
             ub[b] = 1.0 * rng.standard_normal((T - 1, m))          # test/acrobot.jl:88
         elif model == "synth32":
             x1[b] = 0.5 * rng.standard_normal(n)                   # SURVEY.md §8(d) C5; ū = 0
+        elif model == "synth12":
+            x1[b] = 0.5 * rng.standard_normal(n)
+            ub[b] = 0.1 * rng.standard_normal((T - 1, m))
         elif model in ("car", "car_goal", "car_obs"):
             ub[b] = 1.0e-2 * np.array([1.0, 0.1])                  # test/car.jl:28
             if offset + b > 0:

@@ -647,6 +647,40 @@ def test_large_path_odd_dimensions_and_terminal_constraint(pkg, oracle):
     sol.close()
 
 
+def test_synth12_workload_builtin_equals_plugin_and_oracle(pkg, oracle):
+    """The mid-size workload of bench.py (`--config synth12`: nx = 12, nu = 5, T = 101, iteration caps of CONFIG_OPTIONS): the
+    builtin model (csrc/models/model_synth12.h, generated at build time) against the same functions passed as a user-defined model
+    at run time (bitwise: same generator, same kernels), both kernel variants, and against the oracle's twin."""
+    B = 48
+    model, T, x1, ub = pkg.workloads.make_inputs("synth12", B)
+    kw = pkg.workloads.CONFIG_OPTIONS["synth12"]
+    assert (model, T) == ("synth12", 101)
+    res = {}
+    for variant in ("latency", "mid"):
+        sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **kw))
+        sol.set_kernel_variant_(variant)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        res[variant] = dict(x=sol.get_trajectory()[0], u=sol.get_trajectory()[1], K=sol.get_policy()[0], st=sol.stats())
+        sol.close()
+    mdl = pkg.models.synth12()
+    sol = pkg.Solver([mdl["dynamics"]] * (T - 1), [mdl["cost_stage"]] * (T - 1) + [mdl["cost_term"]],
+                     [mdl["con_stage"]] * (T - 1) + [mdl["con_term"]], batch=B, options=pkg.Options(verbose=0, **kw), name="synth12_rt")
+    sol.set_kernel_variant_("latency")
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    res["plugin"] = dict(x=sol.get_trajectory()[0], u=sol.get_trajectory()[1], K=sol.get_policy()[0], st=sol.stats())
+    sol.close()
+    for other in ("mid", "plugin"):
+        for k in ("x", "u", "K"):
+            assert np.array_equal(res["latency"][k], res[other][k], equal_nan=True), (other, k)
+        for k in ("iterations", "outer_iterations", "rollouts", "status", "objective"):
+            assert np.array_equal(res["latency"]["st"][k], res[other]["st"][k], equal_nan=True), (other, k)
+    ref = oracle.solve_batch(model, T, x1, ub, options=oracle.default_options(**kw), nthreads=8)
+    st = res["mid"]["st"]
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.95, same.mean()
+    assert np.abs(res["mid"]["x"] - ref["x"])[same].max() < 1e-7 and np.abs(res["mid"]["u"] - ref["u"])[same].max() < 1e-7
+
+
 def test_time_varying_dimensions(pkg):
     """num_next_state != num_state along the horizon (src/dynamics.jl:5-7), lowered by zero padding (lowering.py).
     The oracle keeps uniform dimensions, so the check is direct: the Riccati recursion of src/backward_pass.jl:42-90
