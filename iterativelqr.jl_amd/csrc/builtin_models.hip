@@ -12,6 +12,10 @@
 #include "models/model_synth32.h"
 #include "models/model_synth12.h"
 
+#ifdef ILQR_BUILTIN_ONLY      // development builds (kernel experiments): one model, a quarter of a minute instead of a whole one
+#define ILQR_DEFINE_MODEL_X(M) ILQR_DEFINE_MODEL(M)         // -DILQR_BUILTIN_ONLY=Model_car
+ILQR_DEFINE_MODEL_X(ILQR_BUILTIN_ONLY)
+#else
 ILQR_DEFINE_MODEL(Model_particle)
 ILQR_DEFINE_MODEL(Model_pendulum_euler)
 ILQR_DEFINE_MODEL(Model_acrobot)
@@ -20,3 +24,4 @@ ILQR_DEFINE_MODEL(Model_car_goal)
 ILQR_DEFINE_MODEL(Model_car_obs)
 ILQR_DEFINE_MODEL(Model_synth32)
 ILQR_DEFINE_MODEL(Model_synth12)
+#endif

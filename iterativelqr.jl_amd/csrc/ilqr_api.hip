@@ -583,7 +583,7 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
             return fail(ILQR_ERR_MODEL, msg);
         }
         if (std::rename(tmp.c_str(), so.c_str()) != 0) return fail(ILQR_ERR_MODEL, "cannot move the model module into place");
-        std::remove(hip.c_str());
+        if (!std::getenv("ILQR_KEEP_MODEL_SOURCE")) std::remove(hip.c_str());      // (kept on request: the module's .hip next to its .so)
         std::remove(log.c_str());
     }
     if (!dlopen(so.c_str(), RTLD_NOW | RTLD_GLOBAL)) return fail(ILQR_ERR_MODEL, std::string("dlopen failed: ") + dlerror());
@@ -868,7 +868,11 @@ int ilqr_solve(ilqr_handle* h) {
         if (h->vt->launch_solve_slim(&a, (size_t)h->L.lds_doubles_slim * 8, h->stream) != 0)
             return drop(fail(ILQR_ERR_HIP, "solve (throughput variant) launch failed"));
     } else if (use_mid(h)) {
-        if (h->vt->launch_solve_mid(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (one-wave variant) launch failed"));
+        size_t lds_mid = h->lds_bytes;
+#ifdef ILQR_DBG_LDS_PAD_HOOK   // residency experiment of tools/mid_bench.py (more LDS per workgroup = fewer workgroups per CU); never in the product library
+        if (const char* pad = std::getenv("ILQR_DBG_LDS_PAD")) lds_mid += (size_t)std::atoi(pad);
+#endif
+        if (h->vt->launch_solve_mid(&a, lds_mid, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (one-wave variant) launch failed"));
     } else if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve launch failed"));
     if (hipEventRecord(e1, h->stream) != hipSuccess) return drop(fail(ILQR_ERR_HIP, "hipEventRecord failed"));
     h->timing.emplace_back(e0, e1);

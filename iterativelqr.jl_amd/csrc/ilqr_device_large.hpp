@@ -67,9 +67,9 @@ __device__ __forceinline__ void tile_store(double* D, double4_t acc, int I0, int
     for (int r = 0; r < 4; ++r) p[4 * r] = acc[r];
 }
 
-template <int LDD>
-__device__ __forceinline__ double4_t tile_load(const double* D, int I0, int J0, int li, int lk) {
-    const double* p = D + (J0 + li) * LDD + I0 + lk;
+template <int LDD, class PTR>         // PTR: const double* or its LDS-qualified form
+__device__ __forceinline__ double4_t tile_load(PTR D, int I0, int J0, int li, int lk) {
+    const auto p = D + (J0 + li) * LDD + I0 + lk;
     double4_t v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = p[4 * r];
@@ -153,6 +153,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), T = A.T, N = A.N;
     double Jp = 0.0, vp = 0.0;
     for (int t = tid; t < T; t += NT) {
+        double Jt = 0.0;                                  // this timestep's terms first: the sum then does not depend on how many waves share the walk
         double w[cdim<M::NW>::v];
         load_w<M::NW>((const double*)A.w, t, w);
         double xt[n];
@@ -162,7 +163,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
             double ut[m];
 #pragma unroll
             for (int i = 0; i < m; ++i) ut[i] = U[t * m + i];
-            if (upd_J) Jp += M::cost_s(xt, ut, w);
+            if (upd_J) Jt += M::cost_s(xt, ut, w);
             if constexpr (ncs > 0) {
                 if (constrained) {
                     double cv[ncs];
@@ -179,8 +180,8 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
                             dot += lam * cv[i];
                             if (!inactive) pen += 0.5 * A.rho[off + i] * (cv[i] * cv[i]);
                         }
-                        Jp += dot;
-                        Jp += pen;
+                        Jt += dot;
+                        Jt += pen;
                     }
                     if (upd_viol) {
 #pragma unroll
@@ -193,7 +194,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
                 }
             }
         } else {
-            if (upd_J) Jp += M::cost_t(xt, w);
+            if (upd_J) Jt += M::cost_t(xt, w);
             if constexpr (nct > 0) {
                 if (constrained) {
                     double cv[nct];
@@ -210,8 +211,8 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
                             dot += lam * cv[i];
                             if (!inactive) pen += 0.5 * A.rho[off + i] * (cv[i] * cv[i]);
                         }
-                        Jp += dot;
-                        Jp += pen;
+                        Jt += dot;
+                        Jt += pen;
                     }
                     if (upd_viol) {
 #pragma unroll
@@ -224,6 +225,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
                 }
             }
         }
+        Jp += Jt;
     }
     // combine the waves: every wave ends with the same two numbers (identical control flow afterwards)
     double* comb = lds_dyn;                               // 2 x W x 64 doubles at the head of the staging area (dead between phases)
@@ -597,7 +599,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     const int N = A.N, li = lane & 15, lk = lane >> 4;
     double* S = lds_dyn;
     double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *sP = S + LD::oP, *sT = S + LD::oT, *sUh = S + LD::oUh, *sQux = S + LD::oQux,
-           *sK = S + LD::oK, *sGux = S + LD::oGux, *sQuu = S + LD::oQuu, *sGuu = S + LD::oGuu;
+           *sK = S + LD::oK, *sQuu = S + LD::oQuu;
     double *sp = S + LD::oVec, *sQx = sp + NP, *sOut = sQx + NP;
     double* sQu = sQux + NP * ldm;                                   // Qu and k ride along as column NP of Qux and K
     double* sU = S + LD::oChol;                                            // the Cholesky factor, column c at sU + c m
@@ -719,10 +721,15 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             }
         }
     }
+    // (Guu / Gux go through an LDS-qualified pointer, here and in the tiles' epilogues: with the generic one hipcc merged the Quu
+    // and Qux roles' epilogues for nx = 5, nu = 1, left a constant flat -> LDS cast in the merged pointer and died on that cast's
+    // own null check, "Illegal instruction detected: Operand has incorrect register class")
+    typedef __attribute__((address_space(3))) double ldsd;
+    ldsd* const S3 = (ldsd*)lds_dyn;
     auto stage_store = [&](const double (&R)[ER]) {
 #pragma unroll
         for (int j = 0; j < ER; ++j)
-            if (soff[j] >= 0) S[soff[j]] = R[j];
+            if (soff[j] >= 0) S3[soff[j]] = R[j];
     };
     if (STAGE && N > 0) { stage_load(N - 1, rval); stage_store(rval); }
     double gmax = 0.0;
@@ -757,11 +764,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
                     } else if constexpr (kind == RIC_QUX) {                  // Qux = ûx fx + gux (:63-64)
                         double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
-                        if constexpr (STAGE) acc += tile_load<ldm>(sGux, 0, 16 * idx, li, lk);
+                        if constexpr (STAGE) acc += tile_load<ldm>(S3 + LD::oGux, 0, 16 * idx, li, lk);
                         tile_store<ldm>(sQux, acc, 0, 16 * idx, li, lk);
                     } else {                                                 // Quu = ûx fu + guu (:58-59)
                         double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
-                        if constexpr (STAGE) acc += tile_load<ldm>(sGuu, 0, 0, li, lk);
+                        if constexpr (STAGE) acc += tile_load<ldm>(S3 + LD::oGuu, 0, 0, li, lk);
                         tile_store<ldm>(sQuu, acc, 0, 0, li, lk);
                     }
                 }

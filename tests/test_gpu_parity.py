@@ -1028,6 +1028,43 @@ def test_large_path_beyond_32_states_against_the_independent_restatement(pkg, nm
     sol.close()
 
 
+@pytest.mark.parametrize("nm", [(1, 1), (2, 4), (4, 3), (3, 4), (5, 1), (9, 3), (16, 16), (17, 2)])
+def test_dimension_sweep_against_the_independent_restatement(pkg, nm):
+    """The reference sizes every buffer at run time (src/data/policy.jl:44-78, src/data/problem.jl:25-46); here the dimensions pick
+    the kernel family and the tile shapes. The synth family at the corners between the families — nx = 1; nu > nx on the small path
+    (latency, throughput and packed kernels); nx = 5 (first size of the large path), 9 x 3 and 16 x 16 (single 16x16 tiles: the
+    four-wave kernel and its one-wave variant), 17 (first size with two tile rows) — every kernel variant that takes the size,
+    against the second, independent restatement (numpy + sympy + scipy LAPACK) run live: control flow exact, x, u, K, J to rounding."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    (n, m), T, B = nm, 21, 5
+    rng = np.random.default_rng(100 * n + m)
+    x1 = 0.5 * rng.standard_normal((B, n)); ub = 0.4 * rng.standard_normal((B, T - 1, m)) + 0.9      # starts across the action box
+    mdl = pkg.models.synth_nm(n, m)
+    dyn, costs, cons = R.synth32_problem(T, n, m)
+    refs = []
+    for b in range(B):
+        s = R.Solver(dyn, costs, cons)
+        s.initialize_controls(ub[b]); s.initialize_states(R.rollout(dyn, x1[b], ub[b]))
+        s.solve()
+        refs.append(s)
+    variants = ("latency", "throughput", "packed") if (n <= 4 and m <= 4) else (("latency", "mid") if n <= 16 else ("latency",))
+    for v in variants:
+        sol = pkg.Solver([mdl["dynamics"]] * (T - 1), [mdl["cost_stage"]] * (T - 1) + [mdl["cost_term"]],
+                         [mdl["con_stage"]] * (T - 1) + [mdl["con_term"]], batch=B, options=pkg.Options(verbose=0), name="sweep%d_%d" % (n, m))
+        sol.set_kernel_variant_(v)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+        for b, s in enumerate(refs):
+            assert st["iterations"][b] == s.iterations and st["outer_iterations"][b] == s.outer_iterations, (v, b, st["iterations"][b], s.iterations)
+            assert np.abs(x[b] - np.stack(s.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s.nominal_actions[:-1])).max() < 1e-8, (v, b)
+            Kr = np.stack([Kt.T for Kt in s.K])
+            assert np.abs(K[b] - Kr).max() <= 1e-7 * max(1.0, np.abs(Kr).max()), (v, b)
+            assert abs(st["objective"][b] - s.objective) <= 1e-9 * max(1.0, abs(s.objective)), (v, b)
+        assert st["iterations"].min() >= 2
+        sol.close()
+
+
 def test_cooperative_rollout_with_non_affine_trig_arguments(pkg):
     """The generated cooperative rollout code forms AFFINE trig arguments from per-lane coefficients and falls back to one select
     per angle otherwise (codegen.py). No built-in model takes the fallback: a user model with sin(x0 x1), cos(x0 + 2 x1^2)
