@@ -97,11 +97,12 @@ def build(force=False):
 
 
 def device_source_hash():
-    """sha256 over the device sources a build of the library is made from (names and contents, sorted) — the stamp
+    """sha256 over the sources lib/builtin_models.o is made from (kernel headers, builtin_models.hip, model headers, the C header; names and
+    contents, sorted; ilqr_api.hip holds no kernel the model prices) — the stamp
     tools/issue_model.py puts on lib/issue_model.json at build time (the same function there; tests/test_abi.py compares them)."""
     import hashlib
     root = os.path.dirname(_HERE)
-    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))] +
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp") or f == "builtin_models.hip"] +
                    [os.path.join(CSRC, "models", f) for f in os.listdir(os.path.join(CSRC, "models")) if f.endswith(".h")] +
                    [os.path.join(INCLUDE, "ilqr_hip.h")])
     h = hashlib.sha256()

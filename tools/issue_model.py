@@ -38,7 +38,7 @@ CLOCK_GHZ = 2.38            # sustained shader clock with 1024 such workgroups r
 def device_source_hash():
     """sha256 over the device sources a build of the library is made from (names and contents, sorted)."""
     import hashlib
-    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))] +
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp") or f == "builtin_models.hip"] +
                    [os.path.join(CSRC, "models", f) for f in os.listdir(os.path.join(CSRC, "models")) if f.endswith(".h")] +
                    [os.path.join(ROOT, "include", "ilqr_hip.h")])
     h = hashlib.sha256()
