@@ -265,8 +265,8 @@ int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launch
  * source is compiled a second time with the host C++ compiler (ILQR_HOSTCXX, else g++ / c++ / clang++) and the Jacobian,
  * Hessian and constraint-Jacobian callables are evaluated at three points; an entry bitwise equal at all of them is a constant
  * (the role Symbolics' sparse expressions play in the reference, src/dynamics.jl:16-34). Source that does not compile for the
- * host, or ILQR_NO_STRUCTURE_PROBE in the environment, leaves every entry state-dependent / non-zero (correct, more traffic;
- * accepted up to nx = 16 only — beyond that the dense forms are refused with ILQR_ERR_MODEL).
+ * host, or ILQR_NO_STRUCTURE_PROBE in the environment, leaves every entry state-dependent / non-zero (correct at every size,
+ * but slow: all nx (nx + nu) Jacobian entries are evaluated, stored and patched per timestep).
  * The dynamics callable itself stays opaque: every lane of the rollout evaluates the whole vector function. */
 typedef struct {
     const char* name;        /* C identifier */

@@ -540,14 +540,10 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
                              ilist(ms.hess_idx, 0, ms.hess_idx.size()).c_str(), ilist(ms.tile_start, 0, ms.tile_start.size()).c_str(),
                              ilist(ms.jac_var, 0, ms.jac_var.size()).c_str(), dlist(ms.fxc).c_str(), dlist(ms.fuc).c_str());
                 tables = std::string(", Tables_") + tag;
-            } else if (src->nx <= 16) {
-                std::fprintf(f, "// no structure found (%s): dense tables\n", ms.note.c_str());
             } else {
-                // dense tables beyond nx = 16 mean kilobytes of per-thread arrays in the linearisation (hipcc 7.2 does not even get
-                // the nx = 32 gather through its backend): refuse instead of shipping something untested
-                std::fclose(f);
-                std::remove(hip.c_str());
-                return fail(ILQR_ERR_MODEL, "ilqr_compile_model: a model with nx > 16 needs the structure probe of its callables, which failed: " + ms.note);
+                // dense tables: every Jacobian entry evaluated and stored per timestep, every Hessian entry streamed (correct, slow:
+                // kilobytes of per-thread arrays in the linearisation beyond nx = 16)
+                std::fprintf(f, "// no structure found (%s): dense tables\n", ms.note.c_str());
             }
         }
         std::fprintf(f, "struct Model_%s : ilqr::%s<Fns_%s, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull%s> {\n"

@@ -1553,6 +1553,50 @@ def test_c_callables_synth32_with_probed_structure(pkg, oracle):
     assert np.abs(fx - fxg).max() < 1e-13 and np.abs(guu - guug).max() <= 1e-12 * np.abs(guug).max()
 
 
+def test_c_callables_synth32_without_the_structure_probe(pkg, oracle, monkeypatch):
+    """The same C source with ILQR_NO_STRUCTURE_PROBE (what a host without a C++ compiler gets): dense tables — all 1280 Jacobian
+    entries state-dependent, all 1344 Hessian entries streamed. Slow, but the reference takes any callable (src/dynamics.jl:55-60),
+    so it must run and agree: against the oracle and against the probed build of the same source."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "examples", "synth32_model.c"), "rb").read()
+
+    class Src(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+    L = pkg._ffi.lib()
+    names = {}
+    for label in ("dense", "probed"):
+        if label == "dense":
+            monkeypatch.setenv("ILQR_NO_STRUCTURE_PROBE", "1")
+        else:
+            monkeypatch.delenv("ILQR_NO_STRUCTURE_PROBE")
+        ms = Src(b"synth32_c", 32, 8, 0, 16, 0, (1 << 16) - 1, 0, text)
+        name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
+        assert L.ilqr_compile_model(C.byref(ms), name, 128, path, 1024) == 0, L.ilqr_last_error().decode()
+        jv, hs = C.c_int32(), C.c_int32()
+        assert L.ilqr_model_compact_sizes(name.value, C.byref(jv), C.byref(hs)) == 0
+        assert (jv.value, hs.value) == ((1280, 1344) if label == "dense" else (32, 40))
+        names[label] = name.value.decode()
+    B, T = 4, 21
+    model, _, x1, ub = pkg.workloads.make_inputs("synth32", B)
+    ub = ub[:, :T - 1] + 1.5 * np.sin(0.37 * np.arange(B * (T - 1) * 8).reshape(B, T - 1, 8))
+    out = {}
+    for label, mdl in names.items():
+        sol = pkg.Solver(model=mdl, horizon=T, batch=B, options=pkg.Options(verbose=0))
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        out[label] = (sol.get_trajectory(), sol.get_policy(), sol.stats(), sol.buffer("jacobian_action"), sol.buffer("hessian_state_state"))
+        sol.close()
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=4)
+    (x, u), (K, _), st, fu, gxx = out["dense"]
+    assert (st["iterations"] == ref["stats"]["iterations"]).all() and (st["rollouts"] == ref["stats"]["rollouts"]).all() and st["iterations"].min() >= 2
+    assert np.abs(x - ref["x"]).max() < 1e-7 and np.abs(u - ref["u"]).max() < 1e-7
+    assert np.abs(K - ref["K"]).max() <= 5e-7 * np.abs(ref["K"]).max()
+    (xp, up), (Kp, _), stp, fup, gxxp = out["probed"]
+    assert np.array_equal(st["iterations"], stp["iterations"]) and np.abs(x - xp).max() < 1e-10 and np.abs(K - Kp).max() <= 1e-9 * np.abs(Kp).max()
+    assert np.abs(fu - fup).max() < 1e-14 and np.abs(gxx - gxxp).max() <= 1e-12 * np.abs(gxxp).max()
+
+
 def test_large_model_setter_shows_what_the_kernels_will_use(pkg):
     """Large path: the full jacobian_* / hessian_* arrays are a mirror of the compact rows the kernels stream. A host write at a
     CONSTANT Jacobian position, or outside the structural Hessian pattern, cannot be represented in the compact form: it is
