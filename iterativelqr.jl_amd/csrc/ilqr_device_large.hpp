@@ -585,6 +585,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     constexpr int EU = (HUU + HUX + 63) / 64 > 0 ? (HUU + HUX + 63) / 64 : 1;      // guu / gux entries per lane of wave 0
     typedef RicSchedule<TN> RS;
     constexpr int SLOTS = RS::SLOTS;                       // Qxx / P tiles per wave (waves 1..3)
+#ifdef ILQR_MID_UNPAIRED                                   // A/B switch: the one-wave variant with the roles' tiles strictly in turn
+    constexpr bool PAIRED = false;
+#else
+    constexpr bool PAIRED = NWV == 1;                      // one wave: independent tiles of a window share their fragment reads and interleave their MFMAs
+#endif
     static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
     static_assert(LD::total == large_lds_doubles(n, m, LD::HS), "LDS carve and host-side size disagree");
     static_assert(NWV == LARGE_WAVES || (NWV == 1 && TN == 1), "the Riccati step is scheduled over four waves per instance, or run by one when every matrix is a single tile");
@@ -774,12 +779,73 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
             });
         };
-        role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<0>{}); });
+        if constexpr (PAIRED) {
+            // one wave, one tile per product: ûx = fuᵀP′ and T = fxᵀP′ share their B operand. Fragments of both tiles are read once,
+            // their MFMAs alternate (two independent accumulators keep the matrix pipe busy where one waits for itself); every
+            // accumulator still sees its own products in its own order: bitwise the tiles of the four-wave kernel
+            constexpr int KS = n4 / 4;
+            double fu_[KS], fx_[KS], fp_[KS];
+            const double *pu = sFu + ld * li + lk, *px = sFx + ld * li + lk, *pp = sP + lk + ld * li;
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) { fu_[sx] = pu[4 * sx]; fx_[sx] = px[4 * sx]; fp_[sx] = pp[4 * sx]; }
+            __builtin_amdgcn_sched_barrier(0);
+            double4_t au = double4_t{0, 0, 0, 0}, at = double4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) {
+                au = __builtin_amdgcn_mfma_f64_16x16x4f64(fu_[sx], fp_[sx], au, 0, 0, 0);
+                at = __builtin_amdgcn_mfma_f64_16x16x4f64(fx_[sx], fp_[sx], at, 0, 0, 0);
+            }
+            tile_store<ldm>(sUh, au, 0, 0, li, lk);
+            tile_store<ld>(sT, at, 0, 0, li, lk);
+        } else {
+            role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<0>{}); });
+        }
         ILQR_SUB_MARK2(I, 0);
         __syncthreads();                                                  // (B1) ûx complete
         ILQR_SUB_MARK1(I, 0); ILQR_SUB_MARK2(I, 1);
         // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | T
-        role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<1>{}); });
+        if constexpr (PAIRED) {
+            // Qux = ûx fx + gux and Quu = ûx fu + guu share their A operand; Qxx = T fx + gxx (window C's tile in the four-wave
+            // schedule) needs nothing later than T either and goes where P′ was, which nobody reads after window A: three
+            // independent accumulators, one LDS round trip
+            constexpr int KS = n4 / 4;
+            double fh_[KS], ft_[KS], fx_[KS], fu_[KS];
+            const double *ph = sUh + li + ldm * lk, *pt = sT + li + ld * lk, *px = sFx + lk + ld * li, *pu = sFu + lk + ld * li;
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) { fh_[sx] = ph[ldm * 4 * sx]; ft_[sx] = pt[ld * 4 * sx]; fx_[sx] = px[4 * sx]; fu_[sx] = pu[4 * sx]; }
+            double4_t gux_t = double4_t{0, 0, 0, 0}, guu_t = double4_t{0, 0, 0, 0};
+            if constexpr (STAGE) { gux_t = tile_load<ldm>(S3 + LD::oGux, 0, 0, li, lk); guu_t = tile_load<ldm>(S3 + LD::oGuu, 0, 0, li, lk); }
+            __builtin_amdgcn_sched_barrier(0);
+            double4_t aq = double4_t{0, 0, 0, 0}, auu = double4_t{0, 0, 0, 0}, axx = double4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) {
+                aq = __builtin_amdgcn_mfma_f64_16x16x4f64(fh_[sx], fx_[sx], aq, 0, 0, 0);
+                auu = __builtin_amdgcn_mfma_f64_16x16x4f64(fh_[sx], fu_[sx], auu, 0, 0, 0);
+                axx = __builtin_amdgcn_mfma_f64_16x16x4f64(ft_[sx], fx_[sx], axx, 0, 0, 0);
+            }
+            if constexpr (STAGE) { aq += gux_t; auu += guu_t; }
+            tile_store<ldm>(sQux, aq, 0, 0, li, lk);
+            tile_store<ldm>(sQuu, auu, 0, 0, li, lk);
+            tile_store<ld>(sQ, axx, 0, 0, li, lk);
+            constexpr int QW = 2, xb = M::HESS_XX_TILE_START[0], xc = M::HESS_XX_TILE_START[1] - xb;      // (RicSchedule<1>: the Qxx tile is role 2's)
+            static_assert(RS::tab.qxx[QW][0] == 0, "one-wave pairing: Qxx tile of RicSchedule<1>");
+            if constexpr (xc > 0) {
+                wave_lds_fence();
+#pragma unroll
+                for (int x = 0; x < (xc + 63) / 64; ++x)
+                    if (xoff[QW][0][x] >= 0) S[xoff[QW][0][x]] += STAGE ? sH[xb + lane + 64 * x] : (double)A.hc[(size_t)t * HSP + xb + lane + 64 * x];
+            }
+            if (STORE_VALUE && Qv != nullptr) {
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lk + 4 * r, col = li;
+                    if (row < n && col < n) Qv[QL.Qxx + (size_t)t * n * n + col * n + row] = sQ[col * ld + row];
+                }
+            }
+        } else {
+            role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<1>{}); });
+        }
         // wave 3 (no tile in this window when nx <= 32): the two matrix-vector products of the step
         if (NWV == 1 || wave == 3) {
             {
@@ -925,7 +991,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             }
             ILQR_SUB_MARK1(I, 3);
         }
-        if (NWV == 1 || wave != 0) role_switch<NWV>(wave, [&](auto Wc) {
+        if constexpr (!PAIRED) if (NWV == 1 || wave != 0) role_switch<NWV>(wave, [&](auto Wc) {
             constexpr int W = decltype(Wc)::value;
             if constexpr (W > 0 && RS::tab.ct[W][0] >= 0) {     // what is left of T; a Qxx tile on another wave may wait for it
                 run_tiles(Wc, IntC<2>{});

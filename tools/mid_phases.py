@@ -1,22 +1,17 @@
 """Per-phase shader-clock ticks (wave 0) of the large path on synth12, four-wave kernel against the one-wave variant.
-Needs a -DILQR_PROFILE build: ILQR_LIB=iterativelqr.jl_amd/lib_phase/libilqr_hip.so python tools/mid_phases.py [B]"""
+Needs a -DILQR_PROFILE build:  make -C iterativelqr.jl_amd/csrc LIBDIR=../lib_phase EXTRA="-DILQR_PROFILE -DILQR_BUILTIN_ONLY=Model_synth12"
+    ILQR_LIB=iterativelqr.jl_amd/lib_phase/libilqr_hip.so python tools/mid_phases.py [B]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ilqr_amd_loader import load_package
 pkg = load_package()
-T = 101
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-mdl = pkg.models.synth12()
-kw = dict(max_iterations=15, max_dual_updates=3)
-rng = np.random.default_rng(12)
-x1 = 0.5 * rng.standard_normal((B, 12)); ub = 0.1 * rng.standard_normal((B, T - 1, 5))
-# the generated model as a module compiled with -DILQR_PROFILE like the library (tools: hipcc ... -DILQR_PROFILE s12.hip -> lib_phase/)
-import ctypes
-ctypes.CDLL(os.path.join(os.path.dirname(os.environ["ILQR_LIB"]), "libmodel_synth12_prof.so"), mode=ctypes.RTLD_GLOBAL)
+model, T, x1, ub = pkg.workloads.make_inputs("synth12", B)
+kw = pkg.workloads.CONFIG_OPTIONS["synth12"]
 for variant in ("latency", "mid"):
-    s = pkg.Solver(model="synth12_midtest", horizon=T, batch=B, options=pkg.Options(verbose=0, **kw))
+    s = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **kw))
     s.set_kernel_variant_(variant)
     for _ in range(2):
         s.reset_(); s.initialize_rollout_(x1, ub); s.solve_()
