@@ -260,7 +260,7 @@ int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launch
  * The library wraps the source (csrc/ilqr_model_adapter.hpp), compiles it for gfx950 with hipcc as a child process (cached
  * by a hash of the source; ILQR_HIPCC / ILQR_CSRC_DIR override the tool and the kernel headers), loads the module and
  * returns the name to put into ilqr_problem_desc.model and the module path for ilqr_problem_desc.model_library.
- * nx <= 64, nu <= 16. Models with nx > 4 or nu > 4 run on the large path, which streams only the state-dependent Jacobian
+ * nx <= 64, nu <= 16, at most 64 constraint rows per stage here (ilqr_compile_model_rows: 256). Models with nx > 4 or nu > 4 run on the large path, which streams only the state-dependent Jacobian
  * entries and the structurally non-zero Hessian entries per timestep: for opaque callables these are found by PROBING — the
  * source is compiled a second time with the host C++ compiler (ILQR_HOSTCXX, else g++ / c++ / clang++) and the Jacobian,
  * Hessian and constraint-Jacobian callables are evaluated at three points; an entry bitwise equal at all of them is a constant
@@ -276,6 +276,14 @@ typedef struct {
     const char* source;
 } ilqr_model_source;
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len);
+/* The same for constraints with more than 64 rows per stage (the reference has no limit: Constraint(f, fx, fu, nc, ...;
+ * indices_inequality), src/constraints.jl:54-64): the inequality rows as arrays of 64-bit words, row i = bit i % 64 of word i / 64,
+ * ceil(nc_stage / 64) and ceil(nc_term / 64) words (NULL = the struct's mask, for a kind with at most 64 rows). Up to
+ * ILQR_MAX_CONSTRAINT_ROWS rows per stage; beyond 64 the per-timestep constraint values no longer fit a thread's registers
+ * (correct, slower). */
+#define ILQR_MAX_CONSTRAINT_ROWS 256
+int ilqr_compile_model_rows(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
+                            char* registered_name, size_t name_len, char* library_path, size_t path_len);
 
 /* Test hook: evaluates one of the device-side scalar routines of csrc/ilqr_math.hpp on cuda device 0 — "recip_fast",
  * "rsqrt_fast", "sqrt_fast" (the d of sqrt_rsqrt_fast), "sin_fast", "cos_fast" — elementwise, y[i] = f(x[i]). These replace

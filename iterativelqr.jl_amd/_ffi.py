@@ -74,6 +74,7 @@ SYMBOLS = {
     "ilqr_timing_reset": (C.c_int, [C.c_void_p]),
     "ilqr_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "ilqr_compile_model": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "ilqr_compile_model_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "ilqr_device_math": (C.c_int, [C.c_char_p, c_double_p, c_double_p, C.c_int32]),
     "ilqr_register_model": (C.c_int, [C.c_void_p]),
     "ilqr_model_count": (C.c_int, []),

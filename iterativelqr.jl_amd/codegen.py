@@ -169,6 +169,7 @@ def _extract_trig(exprs):
 # lanes that cooperate on one dependency level of trig arguments / reciprocals: a whole wave for large models, a 16-lane
 # row for small ones (so that the packed kernel can run their rollout with four instances per wave)
 COOP_GROUP = 64
+MAX_CONSTRAINT_ROWS = 256     # ILQR_MAX_CONSTRAINT_ROWS of include/ilqr_hip.h
 
 
 def _group_reciprocals(repl):
@@ -644,7 +645,7 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     assert cost_stage.num_state == n and cost_stage.num_action == m
     assert cost_term.num_state == n and cost_term.num_action == 0
     ncs, nct = con_stage.num_constraint, con_term.num_constraint
-    assert ncs <= 64 and nct <= 64, "at most 64 constraint rows per stage (64-bit inequality masks)"
+    assert ncs <= MAX_CONSTRAINT_ROWS and nct <= MAX_CONSTRAINT_ROWS, "at most %d constraint rows per stage" % MAX_CONSTRAINT_ROWS
     assert n <= 64 and m <= 16, "device kernels: nx <= 64 (one state component per lane on the large path), nu <= 16"
     ineq_s = sum(1 << (i - 1) for i in con_stage.indices_inequality)
     ineq_t = sum(1 << (i - 1) for i in con_term.indices_inequality)
@@ -656,7 +657,13 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
     L.append("// Device model functions (value + symbolic derivatives), column-major outputs.")
     L.append("struct %s {" % sname)
     L.append("    static constexpr int NX = %d, NU = %d, NW = %d, NCS = %d, NCT = %d;" % (n, m, nw, ncs, nct))
-    L.append("    static constexpr unsigned long long INEQ_S = 0x%xull, INEQ_T = 0x%xull;" % (ineq_s, ineq_t))
+    L.append("    static constexpr unsigned long long INEQ_S = 0x%xull, INEQ_T = 0x%xull;" % (ineq_s & (2 ** 64 - 1), ineq_t & (2 ** 64 - 1)))
+    if ncs > 64 or nct > 64:
+        # more rows than a 64-bit mask holds: the masks as words (ilqr::IneqMask picks them up; models with <= 64 rows keep their header)
+        nwords = (max(ncs, nct) + 63) // 64
+        words = lambda v: ", ".join("0x%xull" % ((v >> (64 * k)) & (2 ** 64 - 1)) for k in range(nwords))
+        L.append("    static constexpr int INEQ_WORDS = %d;" % nwords)
+        L.append("    static constexpr unsigned long long INEQ_S_W[%d] = {%s}, INEQ_T_W[%d] = {%s};" % (nwords, words(ineq_s), nwords, words(ineq_t)))
     L.append('    static constexpr const char* NAME = "%s";' % name)
 
     def rename(obj):

@@ -455,12 +455,34 @@ static ModelStructure probe_model_structure(const ilqr_model_source* src, const 
 }
 
 // Dynamics / Cost / Constraint constructors for hosts without Python: C source of the reference's callables -> model module.
+static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
+                              char* registered_name, size_t name_len, char* library_path, size_t path_len);
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len) {
+    if (src && (src->nc_stage > 64 || src->nc_term > 64))
+        return fail(ILQR_ERR_INVALID, "ilqr_compile_model: at most 64 constraint rows per stage fit the 64-bit inequality masks — "
+                                      "ilqr_compile_model_rows takes the masks as arrays of words");
+    return compile_model_impl(src, nullptr, nullptr, registered_name, name_len, library_path, path_len);
+}
+int ilqr_compile_model_rows(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
+                            char* registered_name, size_t name_len, char* library_path, size_t path_len) {
+    if (src && ((src->nc_stage > 64 && !ineq_stage_words) || (src->nc_term > 64 && !ineq_term_words)))
+        return fail(ILQR_ERR_INVALID, "ilqr_compile_model_rows: more than 64 rows need their inequality words");
+    return compile_model_impl(src, ineq_stage_words, ineq_term_words, registered_name, name_len, library_path, path_len);
+}
+static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
+                              char* registered_name, size_t name_len, char* library_path, size_t path_len) {
     if (!src || !src->name || !src->source || !registered_name || !library_path)
         return fail(ILQR_ERR_INVALID, "null argument");
-    if (src->nx < 1 || src->nx > 64 || src->nu < 1 || src->nu > 16 || src->nw < 0 || src->nc_stage < 0 || src->nc_stage > 64 ||
-        src->nc_term < 0 || src->nc_term > 64)
-        return fail(ILQR_ERR_INVALID, "ilqr_compile_model: 1 <= nx <= 64, 1 <= nu <= 16, at most 64 constraint rows per stage");
+    if (src->nx < 1 || src->nx > 64 || src->nu < 1 || src->nu > 16 || src->nw < 0 || src->nc_stage < 0 || src->nc_stage > ILQR_MAX_CONSTRAINT_ROWS ||
+        src->nc_term < 0 || src->nc_term > ILQR_MAX_CONSTRAINT_ROWS)
+        return fail(ILQR_ERR_INVALID, "ilqr_compile_model: 1 <= nx <= 64, 1 <= nu <= 16, at most 256 constraint rows per stage");
+    // inequality rows as words of 64 (the struct's masks are word 0 when no array is given)
+    const int nwords = std::max(1, (std::max(src->nc_stage, src->nc_term) + 63) / 64);
+    std::vector<uint64_t> iw_s(nwords, 0), iw_t(nwords, 0);
+    for (int k = 0; k < nwords; ++k) {
+        iw_s[k] = ineq_stage_words ? (k < (src->nc_stage + 63) / 64 ? ineq_stage_words[k] : 0) : (k == 0 ? src->ineq_stage : 0);
+        iw_t[k] = ineq_term_words ? (k < (src->nc_term + 63) / 64 ? ineq_term_words[k] : 0) : (k == 0 ? src->ineq_term : 0);
+    }
     for (const char* c = src->name; *c; ++c)
         if (!((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_'))
             return fail(ILQR_ERR_INVALID, "model name must be a C identifier");
@@ -479,9 +501,10 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
     unsigned long long hsh = 1469598103934665603ull;
     auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; ++i) { hsh ^= ((const unsigned char*)p)[i]; hsh *= 1099511628211ull; } };
     mix(src->source, std::strlen(src->source)); mix(src->name, std::strlen(src->name));
-    const long long dims[8] = {src->nx, src->nu, src->nw, src->nc_stage, src->nc_term, (long long)src->ineq_stage, (long long)src->ineq_term,
+    const long long dims[8] = {src->nx, src->nu, src->nw, src->nc_stage, src->nc_term, (long long)iw_s[0], (long long)iw_t[0],
                                ILQR_MODEL_ABI_VERSION * 1000 + (long long)sizeof(ilqr::KArgs)};
     mix(dims, sizeof(dims));
+    if (nwords > 1) { mix(iw_s.data(), sizeof(uint64_t) * nwords); mix(iw_t.data(), sizeof(uint64_t) * nwords); }
 #ifdef ILQR_BUILD_HASH
     mix(ILQR_BUILD_HASH, std::strlen(ILQR_BUILD_HASH));
 #endif
@@ -546,10 +569,16 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
                 std::fprintf(f, "// no structure found (%s): dense tables\n", ms.note.c_str());
             }
         }
+        std::string words;       // more than 64 rows: the masks as word arrays (ilqr::IneqMask picks them up)
+        if (nwords > 1) {
+            auto wl = [](const std::vector<uint64_t>& v) { std::string o; char b[32]; for (uint64_t x : v) { std::snprintf(b, sizeof(b), "0x%llxull,", (unsigned long long)x); o += b; } return o; };
+            words = "    static constexpr int INEQ_WORDS = " + std::to_string(nwords) + ";\n    static constexpr unsigned long long INEQ_S_W[" +
+                    std::to_string(nwords) + "] = {" + wl(iw_s) + "}, INEQ_T_W[" + std::to_string(nwords) + "] = {" + wl(iw_t) + "};\n";
+        }
         std::fprintf(f, "struct Model_%s : ilqr::%s<Fns_%s, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull%s> {\n"
-                        "    static constexpr const char* NAME = \"%s\";\n};\nILQR_DEFINE_MODEL(Model_%s)\n",
+                        "    static constexpr const char* NAME = \"%s\";\n%s};\nILQR_DEFINE_MODEL(Model_%s)\n",
                      uname.c_str(), large ? "AdaptedLargeModel" : "AdaptedModel", tag, src->nx, src->nu, src->nw, src->nc_stage, src->nc_term,
-                     (unsigned long long)src->ineq_stage, (unsigned long long)src->ineq_term, tables.c_str(), uname.c_str(), uname.c_str());
+                     (unsigned long long)iw_s[0], (unsigned long long)iw_t[0], tables.c_str(), uname.c_str(), words.c_str(), uname.c_str());
         std::fclose(f);
         // hipcc as a child process (no shell): same flags as the built-in models
         const std::string tmp = so + ".tmp" + pid;

@@ -89,6 +89,21 @@ __device__ __forceinline__ void bcast_array(double v, double (&out)[N]) {
 }
 
 template <int N_> struct cdim { static constexpr int v = N_ > 0 ? N_ : 1; };
+// Which constraint rows are inequalities (indices_inequality, src/constraints.jl:54-64): a 64-bit mask per stage kind for up to 64
+// rows (M::INEQ_S, M::INEQ_T), an array of such words beyond (M::INEQ_WORDS, M::INEQ_S_W[], M::INEQ_T_W[]: emitted by the generator
+// and by ilqr_compile_model_rows only when a model needs them, so that every other model's header stays what it was)
+template <class M, class = void>
+struct IneqMask {
+    static_assert(M::NCS <= 64 && M::NCT <= 64, "more than 64 constraint rows per stage need the word arrays (M::INEQ_WORDS)");
+    __host__ __device__ static constexpr bool s(int i) { return (M::INEQ_S >> i) & 1ull; }
+    __host__ __device__ static constexpr bool t(int i) { return (M::INEQ_T >> i) & 1ull; }
+};
+template <class...> struct ilqr_void { typedef void type; };
+template <class M>
+struct IneqMask<M, typename ilqr_void<decltype(M::INEQ_WORDS)>::type> {
+    __host__ __device__ static constexpr bool s(int i) { return (M::INEQ_S_W[i >> 6] >> (i & 63)) & 1ull; }
+    __host__ __device__ static constexpr bool t(int i) { return (M::INEQ_T_W[i >> 6] >> (i & 63)) & 1ull; }
+};
 
 template <class M> struct is_large { static constexpr bool value = (M::NX > 4 || M::NU > 4); };
 
@@ -243,7 +258,7 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
                             const double lam = I.lam[off + i];
-                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::s(i);
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             I.act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
@@ -256,7 +271,7 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
                             I.c[off + i] = cv[i];
-                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::s(i);
                             vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
                         }
                     }
@@ -274,7 +289,7 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {
                             const double lam = I.lam[off + i];
-                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::t(i);
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             I.act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
@@ -287,7 +302,7 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {
                             I.c[off + i] = cv[i];
-                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::t(i);
                             vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
                         }
                     }
@@ -1730,8 +1745,8 @@ __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
     for (int i = I.lane + 64 * I.wave; i < I.C; i += 64 * W) {            // read-modify-write: each index exactly once
         const int ns = I.N * ncs;
         bool ineq;
-        if (i < ns) ineq = ncs > 0 ? ((M::INEQ_S >> (i % (ncs > 0 ? ncs : 1))) & 1ull) : false;
-        else ineq = (M::INEQ_T >> (i - ns)) & 1ull;
+        if (i < ns) ineq = ncs > 0 ? IneqMask<M>::s(i % (ncs > 0 ? ncs : 1)) : false;
+        else ineq = IneqMask<M>::t(i - ns);
         double lam = I.lam[i] + I.rho[i] * I.c[i];
         if (ineq) lam = nanmax(0.0, lam);
         I.lam[i] = lam;

@@ -174,7 +174,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
                             const double lam = A.lam[off + i];
-                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::s(i);
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             A.act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
@@ -187,7 +187,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
                             A.c[off + i] = cv[i];
-                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::s(i);
                             vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
                         }
                     }
@@ -205,7 +205,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {
                             const double lam = A.lam[off + i];
-                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::t(i);
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             A.act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
@@ -218,7 +218,7 @@ __attribute__((noinline)) __device__ double cost_pass_large_fn(gdbl* base, int a
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {
                             A.c[off + i] = cv[i];
-                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::t(i);
                             vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
                         }
                     }

@@ -142,7 +142,7 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
                             const double lam = cur.lam[i];
-                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::s(i);
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
@@ -155,7 +155,7 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
                             cbuf[off + i] = cv[i];
-                            const bool ineq = (M::INEQ_S >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::s(i);
                             vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
                         }
                     }
@@ -173,7 +173,7 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {
                             const double lam = cur.lam[i];
-                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::t(i);
                             const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                             act[off + i] = inactive ? 0.0 : 1.0;
                             dot += lam * cv[i];
@@ -186,7 +186,7 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {
                             cbuf[off + i] = cv[i];
-                            const bool ineq = (M::INEQ_T >> i) & 1ull;
+                            const bool ineq = IneqMask<M>::t(i);
                             vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
                         }
                     }
@@ -747,8 +747,8 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
                     for (int i = I.j; i < C; i += 16) {
                         const int ns = N * ncs;
                         bool ineq;
-                        if (i < ns) ineq = ncs > 0 ? ((M::INEQ_S >> (i % (ncs > 0 ? ncs : 1))) & 1ull) : false;
-                        else ineq = (M::INEQ_T >> (i - ns)) & 1ull;
+                        if (i < ns) ineq = ncs > 0 ? IneqMask<M>::s(i % (ncs > 0 ? ncs : 1)) : false;
+                        else ineq = IneqMask<M>::t(i - ns);
                         double lam = g[L.lam + i] + g[L.rho + i] * g[L.c + i];
                         if (ineq) lam = nanmax(0.0, lam);
                         g[L.lam + i] = lam;

@@ -29,7 +29,7 @@ struct AdaptedModel {
     static constexpr int NX = NX_, NU = NU_, NW = NW_, NCS = NCS_, NCT = NCT_;
     static constexpr unsigned long long INEQ_S = INEQ_S_, INEQ_T = INEQ_T_;
     static_assert(NX >= 1 && NX <= 64 && NU >= 1 && NU <= 16, "ilqr_compile_model: nx <= 64, nu <= 16");
-    static_assert(NCS <= 64 && NCT <= 64, "at most 64 constraint rows per stage");
+    static_assert(NCS <= ILQR_MAX_CONSTRAINT_ROWS && NCT <= ILQR_MAX_CONSTRAINT_ROWS, "at most 256 constraint rows per stage");
     static constexpr int W = cdim<NW>::v, CS = cdim<NCS>::v, CT = cdim<NCT>::v;
 
     template <int N> __device__ __forceinline__ static void zero(double (&a)[N]) {

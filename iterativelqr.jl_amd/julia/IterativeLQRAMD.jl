@@ -225,7 +225,15 @@ struct ModelSource
     name::Cstring; nx::Int32; nu::Int32; nw::Int32; nc_stage::Int32; nc_term::Int32
     ineq_stage::UInt64; ineq_term::UInt64; source::Cstring
 end
-ineq_mask(idx) = reduce(|, (UInt64(1) << (i - 1) for i in idx); init = UInt64(0))
+ineq_mask(idx) = reduce(|, (UInt64(1) << (i - 1) for i in idx if i <= 64); init = UInt64(0))
+# rows beyond 64 (ilqr_compile_model_rows): row i = bit (i - 1) % 64 of word (i - 1) ÷ 64, at least one word
+function ineq_words(idx, num_constraint)
+    w = zeros(UInt64, max(1, cld(num_constraint, 64)))
+    for i in idx
+        w[(i - 1) ÷ 64 + 1] |= UInt64(1) << ((i - 1) % 64)
+    end
+    return w
+end
 
 """
     Solver(dynamics, costs, constraints; batch, options, name)
@@ -254,8 +262,10 @@ function Solver(dynamics::Vector{Dynamics}, costs::Vector{Cost}, constraints::Ve
         ms = ModelSource(Base.unsafe_convert(Cstring, name), d.num_state, d.num_action, d.num_parameter,
                          cs.num_constraint, ct.num_constraint, ineq_mask(cs.indices_inequality), ineq_mask(ct.indices_inequality),
                          Base.unsafe_convert(Cstring, source))
-        check(ccall((:ilqr_compile_model, LIB[]), Cint, (Ref{ModelSource}, Ptr{UInt8}, Csize_t, Ptr{UInt8}, Csize_t),
-                    ms, regname, length(regname), path, length(path)))
+        ws, wt = ineq_words(cs.indices_inequality, cs.num_constraint), ineq_words(ct.indices_inequality, ct.num_constraint)
+        check(ccall((:ilqr_compile_model_rows, LIB[]), Cint,
+                    (Ref{ModelSource}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt8}, Csize_t, Ptr{UInt8}, Csize_t),
+                    ms, ws, wt, regname, length(regname), path, length(path)))
     end
     Solver(unsafe_string(pointer(regname)); horizon = length(costs), batch = batch, constrained = constrained, options = options,
            device = device, devices = devices, model_library = unsafe_string(pointer(path)))

@@ -25,7 +25,7 @@ arrays (x1, ū, trajectories, gains) are then the padded ones, with `state_dims[
 import numpy as np
 import sympy as sp
 
-from .codegen import Constraint, Cost, Dynamics
+from .codegen import Constraint, Cost, Dynamics, MAX_CONSTRAINT_ROWS
 
 
 def _key(o):
@@ -126,7 +126,7 @@ def lower(dynamics, costs, constraints=None):
             row0.append(sum(q.num_constraint for q in kk[:k]))
             ineq += [row0[k] + i for i in c.indices_inequality]
         total = sum(q.num_constraint for q in kk)
-        assert total <= 64, "at most 64 stage constraint rows over all kinds"
+        assert total <= MAX_CONSTRAINT_ROWS, "at most %d stage constraint rows over all kinds" % MAX_CONSTRAINT_ROWS
         if total:
             con_stage = Constraint(lambda x, u, w: [gate("constraint", k, w, e) for k, c in enumerate(kk) for e in c.evaluate],
                                    n, m, indices_inequality=ineq, num_parameter=nw)

@@ -240,6 +240,16 @@ def synth_nm(n, m):
     )
 
 
+def synth_box(n, m, xmax=1.2):
+    """synth_nm with a state box on top of the action box: 2 nu + 2 nx stage inequalities — more than 64 rows from nx + nu > 32
+    (the reference has no row limit, src/constraints.jl:54-64; here the inequality masks become word arrays)."""
+    base = synth_nm(n, m)
+    rows = lambda x, u: ([-1.0 - u[j] for j in range(m)] + [u[j] - 1.0 for j in range(m)] +
+                         [x[i] - xmax for i in range(n)] + [-xmax - x[i] for i in range(n)])
+    base["con_stage"] = Constraint(rows, n, m, indices_inequality=list(range(1, 2 * m + 2 * n + 1)))
+    return base
+
+
 def synth12():
     """A second large-path model whose dimensions are NOT multiples of the MFMA tile (nx = 12, nu = 5), with a
     bilinear term (state-dependent fu entries) and a terminal equality; twin of oracle/models.cpp "synth12"."""

@@ -699,6 +699,15 @@ def synth32_problem(T=101, n=32, m=8):
     return [dyn] * (T - 1), [stage] * (T - 1) + [term], [box] * (T - 1) + [Constraint()]
 
 
+def synth_box_problem(T, n, m, xmax=1.2):
+    """synth32_problem with a state box |x_i| <= xmax on top of the action box: 2m + 2n stage inequalities."""
+    dyn, costs, cons = synth32_problem(T, n, m)
+    rows = lambda x, u: ([-1.0 - u[j] for j in range(m)] + [u[j] - 1.0 for j in range(m)] +
+                         [x[i] - xmax for i in range(n)] + [-xmax - x[i] for i in range(n)])
+    box = Constraint(rows, n, m, indices_inequality=list(range(1, 2 * m + 2 * n + 1)))
+    return dyn, costs, [box] * (T - 1) + [Constraint()]
+
+
 PROBLEMS = {
     "particle": particle_problem,
     "acrobot": acrobot_problem,

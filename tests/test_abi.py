@@ -111,6 +111,60 @@ def test_compile_model_from_c_source_without_python_codegen(pkg):
     assert L.ilqr_compile_model(C.byref(big), name2, 128, path, 1024) < 0
 
 
+def _rows70_source():
+    """pendulum (2, 1) with 70 stage rows: 34 nested action boxes (68 inequality rows), row 68 an EQUALITY that is identically
+    zero, row 69 an INEQUALITY that is identically -1 (inactive as an inequality, a violation of 1 if its bit were lost)."""
+    fn = "ILQR_MODEL_FN void %s(double* o, const double* x, const double* u, const double* w) { %s }\n"
+    return "".join(fn % kv for kv in [
+        ("dynamics", "o[0] = x[0] + 0.1 * x[1]; o[1] = x[1] + 0.1 * (u[0] - sin(x[0]));"),
+        ("dynamics_jacobian_state", "o[0] = 1.0; o[1] = -0.1 * cos(x[0]); o[2] = 0.1; o[3] = 1.0;"),
+        ("dynamics_jacobian_action", "o[1] = 0.1;"),
+        ("cost_stage", "o[0] = x[0] * x[0] + x[1] * x[1] + 0.1 * u[0] * u[0];"),
+        ("cost_stage_gradient_state", "o[0] = 2.0 * x[0]; o[1] = 2.0 * x[1];"),
+        ("cost_stage_gradient_action", "o[0] = 0.2 * u[0];"),
+        ("cost_stage_hessian_state_state", "o[0] = 2.0; o[3] = 2.0;"),
+        ("cost_stage_hessian_action_action", "o[0] = 0.2;"),
+        ("cost_stage_hessian_action_state", ""),
+        ("cost_terminal", "o[0] = 10.0 * ((x[0] - 1.0) * (x[0] - 1.0) + x[1] * x[1]);"),
+        ("cost_terminal_gradient_state", "o[0] = 20.0 * (x[0] - 1.0); o[1] = 20.0 * x[1];"),
+        ("cost_terminal_hessian_state_state", "o[0] = 20.0; o[3] = 20.0;"),
+        ("constraint_stage", "for (int i = 0; i < 34; ++i) { o[2 * i] = u[0] - (0.5 + 0.01 * i); o[2 * i + 1] = -(0.5 + 0.01 * i) - u[0]; } o[68] = 0.0; o[69] = -1.0;"),
+        ("constraint_stage_jacobian_state", ""),
+        ("constraint_stage_jacobian_action", "for (int i = 0; i < 34; ++i) { o[2 * i] = 1.0; o[2 * i + 1] = -1.0; }"),
+    ])
+
+
+ROWS70_WORDS = [(1 << 64) - 1, 0b101111]        # rows 0..67 and 69 inequalities, row 68 an equality
+
+
+def test_compile_model_with_more_than_64_constraint_rows(pkg):
+    """The reference's Constraint has no row limit (src/constraints.jl:54-64). Up to 64 rows the inequality set is a 64-bit mask in
+    ilqr_model_source; beyond, ilqr_compile_model_rows takes it as words and the generated wrapper carries INEQ_WORDS /
+    INEQ_S_W / INEQ_T_W for ilqr::IneqMask. ilqr_compile_model itself refuses such a model with a message that names the other
+    entry point; the Python generator emits the same members."""
+    L = pkg._ffi.lib()
+    ms = _ModelSource(b"abi_rows70", 2, 1, 0, 70, 0, 0, 0, _rows70_source().encode())
+    name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
+    assert L.ilqr_compile_model(C.byref(ms), name, 128, path, 1024) < 0 and b"ilqr_compile_model_rows" in L.ilqr_last_error()
+    assert L.ilqr_compile_model_rows(C.byref(ms), None, None, name, 128, path, 1024) < 0       # 70 rows and no words
+    words = (C.c_uint64 * 2)(*ROWS70_WORDS)
+    rc = L.ilqr_compile_model_rows(C.byref(ms), words, None, name, 128, path, 1024)
+    assert rc == 0, L.ilqr_last_error().decode()
+    assert name.value.startswith(b"abi_rows70_c") and os.path.exists(path.value.decode())
+    # other words, other module
+    words2 = (C.c_uint64 * 2)((1 << 64) - 1, 0b111111)
+    name2 = C.create_string_buffer(128)
+    assert L.ilqr_compile_model_rows(C.byref(ms), words2, None, name2, 128, path, 1024) == 0 and name2.value != name.value
+    too_many = _ModelSource(b"abi_rows300", 2, 1, 0, 300, 0, 0, 0, b"")
+    assert L.ilqr_compile_model_rows(C.byref(too_many), (C.c_uint64 * 5)(), None, name2, 128, path, 1024) < 0
+    # the symbolic generator: same members, from indices_inequality
+    mdl = pkg.models.synth_box(30, 5)
+    _, src = pkg.codegen.generate_model_source("box30", mdl["dynamics"], mdl["cost_stage"], mdl["cost_term"], mdl["con_stage"], mdl["con_term"])
+    assert "INEQ_WORDS = 2;" in src and "INEQ_S_W[2] = {0xffffffffffffffffull, 0x3full}" in src
+    _, src12 = pkg.codegen.generate_model_source("s12", **pkg.models.synth12())
+    assert "INEQ_WORDS" not in src12           # models with <= 64 rows keep their header
+
+
 def test_issue_model_is_a_product_of_the_build_and_goes_stale_with_the_sources(pkg, tmp_path, monkeypatch):
     """csrc/Makefile writes lib/issue_model.json from the assembly of the library's own compilation, stamped with the hash of
     the device sources; the loader refuses it once the sources differ (bench.py then reports why instead of comparing the

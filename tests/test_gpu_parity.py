@@ -1065,6 +1065,86 @@ def test_dimension_sweep_against_the_independent_restatement(pkg, nm):
         sol.close()
 
 
+def test_more_than_64_constraint_rows_small_path(pkg):
+    """70 stage rows on a (2, 1) model (tests/test_abi.py: 34 nested action boxes, an identically-zero equality, an identically -1
+    inequality in the SECOND mask word): the C-source route (ilqr_compile_model_rows) and the symbolic route (codegen word arrays)
+    against the independent restatement, on every small-path kernel. A lost inequality bit of row 69 would show as a violation of 1."""
+    import ctypes as C
+    import sympy as sp
+    from test_abi import _ModelSource, _rows70_source, ROWS70_WORDS
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    T, B = 21, 6
+    rng = np.random.default_rng(70)
+    x1 = 0.3 * rng.standard_normal((B, 2)); ub = 0.8 * rng.standard_normal((B, T - 1, 1))
+    f = lambda x, u: [x[0] + 0.1 * x[1], x[1] + 0.1 * (u[0] - sp.sin(x[0]))]
+    lst = lambda x, u: x[0] * x[0] + x[1] * x[1] + 0.1 * u[0] * u[0]
+    ltm = lambda x, u: 10.0 * ((x[0] - 1.0) * (x[0] - 1.0) + x[1] * x[1])
+    rows = lambda x, u: sum([[u[0] - (0.5 + 0.01 * i), -(0.5 + 0.01 * i) - u[0]] for i in range(34)], []) + [0.0 * u[0], -1.0 + 0.0 * u[0]]
+    ineq = list(range(1, 69)) + [70]
+    refs = []
+    dyn_r = R.Dynamics(f, 2, 1); con_r = R.Constraint(rows, 2, 1, indices_inequality=ineq)
+    for b in range(B):
+        s = R.Solver([dyn_r] * (T - 1), [R.Cost(lst, 2, 1)] * (T - 1) + [R.Cost(ltm, 2, 0)], [con_r] * (T - 1) + [R.Constraint()])
+        s.initialize_controls(ub[b]); s.initialize_states(R.rollout([dyn_r] * (T - 1), x1[b], ub[b]))
+        s.solve()
+        refs.append(s)
+    L = pkg._ffi.lib()
+    ms = _ModelSource(b"rows70", 2, 1, 0, 70, 0, 0, 0, _rows70_source().encode())
+    name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
+    assert L.ilqr_compile_model_rows(C.byref(ms), (C.c_uint64 * 2)(*ROWS70_WORDS), None, name, 128, path, 1024) == 0, L.ilqr_last_error().decode()
+    con = pkg.Constraint(rows, 2, 1, indices_inequality=ineq)
+    for route in ("c", "symbolic"):
+        for v in ("latency", "throughput", "packed"):
+            if route == "c":
+                sol = pkg.Solver(model=name.value.decode(), horizon=T, batch=B, options=pkg.Options(verbose=0))
+            else:
+                sol = pkg.Solver([pkg.Dynamics(f, 2, 1)] * (T - 1), [pkg.Cost(lst, 2, 1)] * (T - 1) + [pkg.Cost(ltm, 2, 0)],
+                                 [con] * (T - 1) + [pkg.Constraint()], batch=B, options=pkg.Options(verbose=0), name="rows70s")
+            assert sol.nc_stage == 70
+            sol.set_kernel_variant_(v)
+            sol.initialize_rollout_(x1, ub); sol.solve_()
+            x, u = sol.get_trajectory(); st = sol.stats()
+            assert (st["max_violation"] <= 5e-3).all(), (route, v, st["max_violation"])
+            assert (np.abs(u) <= 0.5 + 5e-3).all()                 # the innermost of the nested boxes binds
+            for b, s in enumerate(refs):
+                assert st["iterations"][b] == s.iterations and st["outer_iterations"][b] == s.outer_iterations, (route, v, b)
+                assert np.abs(x[b] - np.stack(s.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s.nominal_actions[:-1])).max() < 1e-8, (route, v, b)
+            sol.close()
+
+
+def test_more_than_64_constraint_rows_large_path(pkg):
+    """nx = 30, nu = 5 with an action box and a state box: 70 stage inequalities (synth_box) on the large path — four-wave kernel;
+    cost pass, linearisation with Gauss-Newton AL terms over 70 rows — against the independent restatement."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    n, m, T, B = 30, 5, 21, 3
+    rng = np.random.default_rng(3005)
+    x1 = 0.9 * rng.standard_normal((B, n)); ub = 0.4 * rng.standard_normal((B, T - 1, m)) + 0.9       # across both boxes
+    mdl = pkg.models.synth_box(n, m)
+    sol = pkg.Solver([mdl["dynamics"]] * (T - 1), [mdl["cost_stage"]] * (T - 1) + [mdl["cost_term"]],
+                     [mdl["con_stage"]] * (T - 1) + [mdl["con_term"]], batch=B, options=pkg.Options(verbose=0), name="box30")
+    assert (sol.nx, sol.nu, sol.nc_stage) == (n, m, 70)
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    dyn, costs, cons = R.synth_box_problem(T, n, m)
+    for b in range(B):
+        s = R.Solver(dyn, costs, cons)
+        s.initialize_controls(ub[b]); s.initialize_states(R.rollout(dyn, x1[b], ub[b]))
+        s.solve()
+        assert st["iterations"][b] == s.iterations and st["outer_iterations"][b] == s.outer_iterations, (b, st["iterations"][b], s.iterations)
+        assert st["iterations"][b] >= 2
+        # (tolerance of the synth32 oracle tests: with dozens of active rows at penalties up to 1e4 one instance needs 330 iterations
+        # and the last-bit differences between the two implementations' sums grow to a few 1e-8 in x; after ONE iteration and after
+        # one dual update the same three instances agree to 1e-14)
+        Kr = np.stack([Kt.T for Kt in s.K])
+        assert np.abs(x[b] - np.stack(s.nominal_states)).max() < 5e-7
+        assert np.abs(u[b] - np.stack(s.nominal_actions[:-1])).max() < 5e-7 * max(1.0, np.abs(Kr).max())      # u = ū + K (x − x̄): |K| up to 1e2 here
+        assert np.abs(K[b] - Kr).max() <= 5e-7 * max(1.0, np.abs(Kr).max())
+        assert abs(st["max_violation"][b] - s.max_violation) <= 1e-7
+    sol.close()
+
+
 def test_cooperative_rollout_with_non_affine_trig_arguments(pkg):
     """The generated cooperative rollout code forms AFFINE trig arguments from per-lane coefficients and falls back to one select
     per angle otherwise (codegen.py). No built-in model takes the fallback: a user model with sin(x0 x1), cos(x0 + 2 x1^2)
