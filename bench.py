@@ -372,6 +372,24 @@ def worker(args, solver_factory=None):
             secondary["inflight_2"] = {"value": world * B * 2 * k2 / el, "unit": "trajectories/s", "ms_per_batch": 1e3 * el / (2 * k2),
                                        "note": "two solver handles per GPU on separate streams, alternating batches"}
             extra.close()
+        if rank == 0 and not stub and world == 1:
+            # the batch's slowest instance ALONE on the chip, same kernel: what of the step is one instance's serial latency and
+            # what is the sharing of SIMDs with the other instances of the batch (tools/batch_latency.py has the whole curve)
+            st_ = sol.stats()
+            worst = int(np.argmax(st_["iterations"]))
+            lone = pkg.Solver(model=model, horizon=T, batch=1, device=gpu,
+                              options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
+            lone.set_kernel_variant_(args.variant)
+            lone_ms = []
+            for _ in range(3):
+                lone.reset_(); lone.initialize_rollout_(x1[worst:worst + 1], ub[worst:worst + 1]); lone.timing_reset(); lone.solve_(sync=True)
+                lone_ms.append(lone.timing()[0])
+            secondary["slowest_instance_alone"] = {"kernel_ms": min(lone_ms[1:]), "instance": worst, "iterations": int(lone.stats()["iterations"][0]),
+                                                   "batch_iterations_max": int(st_["iterations"].max()),
+                                                   "note": "one launch of the same kernel with only the batch's slowest instance on the GPU: "
+                                                           "the serial latency no batch size can go below; the step's kernel time minus this is "
+                                                           "what sharing the SIMDs with the rest of the batch costs that instance"}
+            lone.close()
     per_rank = pkg.distributed.gather_over_ranks([1e3 * my_elapsed / args.steps, kernel_ms, it_sum, it_max], dist, cdev)
     if rank != 0:
         for s_ in sols:
