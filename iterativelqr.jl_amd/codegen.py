@@ -707,8 +707,8 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         # per-lane constants of the cooperative code, built ONCE per kernel (not per timestep): the trig pair coefficients and
         # the coefficient columns of the affine trig arguments, indexed by the angle slot pq = (lane & 15) >> 1
         ctx = ["    struct WaveCtx { ilqr::TrigPair tp; double a[%d], k[%d]; };" % (max(1, len(_CTX)), max(1, len(consts))),
-               "    // PIN_CONSTANTS = true keeps the model's fp64 constants in VGPRs too (8 fewer scalar-pair moves per acrobot step, but the",
-               "    // forward pass then needs 248 VGPRs and its caller spills around the call: not used by the shipped kernels)",
+               "    // PIN_CONSTANTS = true makes the model's fp64 constants opaque scalar-register pairs: hipcc otherwise keeps halves of known",
+               "    // 64-bit constants and re-assembles aligned pairs with s_mov_b32 at every use (8 of 148.5 issue slots of an acrobot rollout step)",
                "    template <bool PIN_CONSTANTS = false> __device__ __forceinline__ static WaveCtx wave_ctx(const int lane) {",
                "        const int pq = (lane & 15) >> 1; (void)pq;",
                "        WaveCtx cx;",
@@ -723,7 +723,7 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
         if not consts:
             ctx.append("        cx.k[0] = 0.0;")
         for i, v in enumerate(consts):
-            ctx.append("        cx.k[%d] = %r; if (PIN_CONSTANTS) ILQR_OPAQUE(cx.k[%d]);" % (i, v, i))
+            ctx.append("        cx.k[%d] = %r; if (PIN_CONSTANTS) ILQR_OPAQUE_UNIFORM(cx.k[%d]);" % (i, v, i))
         ctx += ["        return cx;", "    }"]
         L[mark:mark] = ctx
     L.append("#endif")

@@ -88,6 +88,9 @@ __device__ __forceinline__ void bcast_array(double v, double (&out)[N]) {
         out[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
 }
 
+#ifndef ILQR_PIN_ROLLOUT_CONSTANTS
+#define ILQR_PIN_ROLLOUT_CONSTANTS true     // A/B switch (false: the compiler's own handling of the constants)
+#endif
 template <int N_> struct cdim { static constexpr int v = N_ > 0 ? N_ : 1; };
 // Which constraint rows are inequalities (indices_inequality, src/constraints.jl:54-64): a 64-bit mask per stage kind for up to 64
 // rows (M::INEQ_S, M::INEQ_T), an array of such words beyond (M::INEQ_WORDS, M::INEQ_S_W[], M::INEQ_T_W[]: emitted by the generator
@@ -1485,7 +1488,8 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     const bool vn1 = c == 0 && r < n, vm1 = c == 0 && r < m;
     double zx = 0.0, dacc = 0.0;
     (void)blk;
-    const typename M::WaveCtx wcx = M::template wave_ctx<false>(lane);               // per-lane constants of the cooperative dynamics, built once
+    const typename M::WaveCtx wcx = M::template wave_ctx<ILQR_PIN_ROLLOUT_CONSTANTS>(lane);   // per-lane constants of the cooperative dynamics, built once; the model's
+                                                                                            // wave-uniform constants as opaque scalar pairs (8 fewer s_mov_b32 per acrobot step)
     // LDS byte addresses of K_t, u[t], x[t] held in VGPRs (opaque to the compiler, which would otherwise rebuild every address
     // from scalar registers with shift / add / move triples); they advance by two steps per loop trip, all other offsets are
     // immediates. Operands of step t are fetched one step ahead; the loop is unrolled by two with ping-pong operand sets.

@@ -29,6 +29,9 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
 }
 // value made opaque to the optimiser at this point (keeps a cheap expression out of an exec-masked branch)
 #define ILQR_OPAQUE(v) asm volatile("" : "+v"(v))
+// a wave-uniform value the compiler must keep in a scalar register pair (it otherwise splits known 64-bit constants into halves and
+// re-assembles aligned pairs with s_mov_b32 at every use: 8 of the 148.5 issue slots of an acrobot rollout step)
+#define ILQR_OPAQUE_UNIFORM(v) asm volatile("" : "+s"(v))
 // 1 / x by v_rcp_f64 and two Newton steps (5 instructions; measured 0.5 ulp, correctly rounded for 99.98 % of arguments — one step
 // would leave 11 ulp, tools/probes/probe_rcp.hip) instead of the IEEE division sequence
 // (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: 11 instructions). Used on the serial rollout chain only.
@@ -70,6 +73,7 @@ ILQR_HD double rsqrt_fast(double a) { return 1.0 / sqrt(a); }
 ILQR_HD void sqrt_rsqrt_fast(double a, double& d, double& r) { d = sqrt(a); r = 1.0 / d; }
 ILQR_HD double fma3(double a, double b, double c) { return fma(a, b, c); }
 #define ILQR_OPAQUE(v) do {} while (0)
+#define ILQR_OPAQUE_UNIFORM(v) do {} while (0)
 ILQR_HD double recip_fast(double x) { return 1.0 / x; }
 #endif
 
@@ -229,9 +233,9 @@ __device__ __forceinline__ TrigPair make_trig_pair(int lane) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) ILQR_OPAQUE(t.c[i]);
     ILQR_OPAQUE(t.m); ILQR_OPAQUE(t.o);
-    if constexpr (PIN_UNIFORM) {        // wave-uniform constants: pinned too where VGPRs are plentiful (scalar-register pairs are not)
+    if constexpr (PIN_UNIFORM) {        // wave-uniform constants: opaque scalar-register pairs (pinned in VGPRs they cost the forward pass 32 registers and spills)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ILQR_OPAQUE(t.red[i]);
+        for (int i = 0; i < 4; ++i) ILQR_OPAQUE_UNIFORM(t.red[i]);
     }
     return t;
 }
