@@ -9,13 +9,14 @@ from oracle import oracle
 pkg = load_package()
 for cfg, B, variant in (("particle", 64, "auto"), ("acrobot", 1024, "auto"), ("acrobot", 1024, "packed"), ("acrobot", 4096, "auto"),
                         ("car", 4096, "auto"), ("car", 4096, "throughput"), ("car_goal", 1024, "auto"), ("car_goal", 2048, "auto"),
-                        ("synth32", 512, "auto")):
+                        ("synth32", 512, "auto"), ("synth12", 1024, "latency"), ("synth12", 4096, "auto"), ("acrobot", 8192, "auto")):
     model, T, x1, ub = pkg.workloads.make_inputs(cfg, B)
-    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    kw = pkg.workloads.CONFIG_OPTIONS.get(cfg, {})
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **kw))
     sol.set_kernel_variant_(variant)
     sol.initialize_rollout_(x1, ub); sol.solve_()
     x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
-    ref = oracle.solve_batch(model, T, x1, ub, nthreads=int(os.environ.get("ORACLE_THREADS", "16")))
+    ref = oracle.solve_batch(model, T, x1, ub, options=oracle.default_options(**kw), nthreads=int(os.environ.get("ORACLE_THREADS", "16")))
     rs = ref["stats"]
     same = (st["iterations"] == rs["iterations"]) & (st["rollouts"] == rs["rollouts"]) & (st["outer_iterations"] == rs["outer_iterations"])
     fin = np.isfinite(ref["x"]).reshape(B, -1).all(1)
