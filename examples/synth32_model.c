@@ -6,8 +6,8 @@
 #define S32_N 32
 #define S32_M 8
 #define S32_H 0.05
-static ILQR_MODEL_FN double s32_A(int i, int j) { return (i == j ? -1.0 : 0.0) + 0.3 * cos((double)((i + 1) + 2 * (j + 1))) / 32.0; }
-static ILQR_MODEL_FN double s32_B(int i, int j) { return sin((double)(3 * (i + 1) + (j + 1))) / sqrt(32.0); }
+static ILQR_MODEL_FN double s32_A(int i, int j) { return (i == j ? -1.0 : 0.0) + 0.3 * cos((double)((i + 1) + 2 * (j + 1))) / (double)S32_N; }
+static ILQR_MODEL_FN double s32_B(int i, int j) { return sin((double)(3 * (i + 1) + (j + 1))) / sqrt((double)S32_N); }
 ILQR_MODEL_FN void dynamics(double* y, const double* x, const double* u, const double* w) {
     for (int i = 0; i < S32_N; ++i) {
         double acc = 0.0;

@@ -1677,6 +1677,49 @@ def test_c_callables_synth32_without_the_structure_probe(pkg, oracle, monkeypatc
     assert np.abs(fu - fup).max() < 1e-14 and np.abs(gxx - gxxp).max() <= 1e-12 * np.abs(gxxp).max()
 
 
+@pytest.mark.parametrize("probe", [True, False])
+def test_c_callables_at_the_size_limits(pkg, probe, monkeypatch):
+    """ilqr_compile_model at nx = 64, nu = 16, 32 stage rows (the limits it advertises; advisor finding of round 3: only nx = 12 had
+    ever run): examples/synth32_model.c with its two size macros changed, with the structure probe (64 of 5120 Jacobian entries
+    state-dependent, 80 of 5376 Hessian entries) and without it (dense tables: every entry through per-thread arrays — tens of KB of
+    scratch per thread, slow, but it must run), against the independent restatement of the same family."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import reference_restatement as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "examples", "synth32_model.c"), "rb").read()
+    text = text.replace(b"#define S32_N 32", b"#define S32_N 64").replace(b"#define S32_M 8", b"#define S32_M 16")
+
+    class Src(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+    if not probe:
+        monkeypatch.setenv("ILQR_NO_STRUCTURE_PROBE", "1")
+    L = pkg._ffi.lib()
+    ms = Src(b"synth64_c", 64, 16, 0, 32, 0, (1 << 32) - 1, 0, text)
+    name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
+    assert L.ilqr_compile_model(C.byref(ms), name, 128, path, 1024) == 0, L.ilqr_last_error().decode()
+    jv, hs = C.c_int32(), C.c_int32()
+    assert L.ilqr_model_compact_sizes(name.value, C.byref(jv), C.byref(hs)) == 0
+    assert (jv.value, hs.value) == ((64, 80) if probe else (64 * 80, 64 * 64 + 16 * 16 + 16 * 64))
+    n, m, T, B = 64, 16, 11, 2
+    rng = np.random.default_rng(64)
+    x1 = 0.5 * rng.standard_normal((B, n)); ub = 0.4 * rng.standard_normal((B, T - 1, m)) + 0.8
+    sol = pkg.Solver(model=name.value.decode(), horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.initialize_rollout_(x1, ub); sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    dyn, costs, cons = R.synth32_problem(T, n, m)
+    for b in range(B):
+        s = R.Solver(dyn, costs, cons)
+        s.initialize_controls(ub[b]); s.initialize_states(R.rollout(dyn, x1[b], ub[b]))
+        s.solve()
+        assert st["iterations"][b] == s.iterations and st["outer_iterations"][b] == s.outer_iterations and s.iterations >= 2
+        assert np.abs(x[b] - np.stack(s.nominal_states)).max() < 1e-8 and np.abs(u[b] - np.stack(s.nominal_actions[:-1])).max() < 1e-8
+        Kr = np.stack([Kt.T for Kt in s.K])
+        assert np.abs(K[b] - Kr).max() <= 1e-7 * max(1.0, np.abs(Kr).max())
+    sol.close()
+
+
 def test_large_model_setter_shows_what_the_kernels_will_use(pkg):
     """Large path: the full jacobian_* / hessian_* arrays are a mirror of the compact rows the kernels stream. A host write at a
     CONSTANT Jacobian position, or outside the structural Hessian pattern, cannot be represented in the compact form: it is
