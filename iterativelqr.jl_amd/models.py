@@ -250,6 +250,76 @@ def synth_box(n, m, xmax=1.2):
     return base
 
 
+def synth_c_source(n=32, m=8):
+    """The synth family (synth_nm) as C source of the reference's callables (src/dynamics.jl:55-60, src/costs.jl:1-15,
+    src/constraints.jl:54-64) for ilqr_compile_model — what a host without the symbolic generator hands over. The coefficient
+    matrices are literal tables, as Symbolics' build_function would print them (an earlier version computed every entry with
+    cos / sin at run time: 1280 libm calls per dynamics evaluation, 15 ms per rollout of BASELINE config 5's shard). The Jacobian
+    callables stay dense loops: finding the 2 nx constant-free entries is the library's job (probe_model_structure).
+    examples/synth32_model.c is synth_c_source(32, 8) (tests/test_structure_probe.py keeps it so)."""
+    h = 0.05
+    A = [[(-1.0 if i == j else 0.0) + 0.3 * math.cos(float((i + 1) + 2 * (j + 1))) / float(n) for j in range(n)] for i in range(n)]
+    Bm = [[math.sin(float(3 * (i + 1) + (j + 1))) / math.sqrt(float(n)) for j in range(m)] for i in range(n)]
+    tab = lambda rows: ",\n".join("    " + ", ".join("%.17g" % v for v in r) for r in rows)
+    return """/* GENERATED by iterativelqr.jl_amd/models.py:synth_c_source(%(n)d, %(m)d) - the reference's callable contract (src/dynamics.jl:55-60,
+ * src/costs.jl:1-15, src/constraints.jl:54-64) for the synth family: x+ = x + h (A x + B u + 0.1 sin x), l = 0.1 |x - 0.5|^2 + 0.01 |u|^2,
+ * l_T = 10 |x - 0.5|^2, action box as 2 nu stage inequalities; nx = %(n)d, nu = %(m)d is BASELINE config 5's model for (32, 8) - the twin
+ * of models.py:synth_nm and of oracle/models.cpp "synth32". Handed to ilqr_compile_model as text: the Jacobians are dense loops, the
+ * library finds the constant entries and the structurally non-zero Hessian entries by probing them on the host. `out` arrives zeroed. */
+#define SN %(n)d
+#define SM %(m)d
+#define SH %(h)r
+static const double S_A[SN * SN] = {   /* row-major */
+%(A)s};
+static const double S_B[SN * SM] = {   /* row-major */
+%(B)s};
+ILQR_MODEL_FN void dynamics(double* y, const double* x, const double* u, const double* w) {
+    for (int i = 0; i < SN; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < SN; ++j) acc += S_A[i * SN + j] * x[j];
+        for (int j = 0; j < SM; ++j) acc += S_B[i * SM + j] * u[j];
+        acc += 0.1 * sin(x[i]);
+        y[i] = x[i] + SH * acc;
+    }
+}
+ILQR_MODEL_FN void dynamics_jacobian_state(double* fx, const double* x, const double* u, const double* w) {   /* column-major n x n */
+    for (int j = 0; j < SN; ++j)
+        for (int i = 0; i < SN; ++i)
+            fx[j * SN + i] = (i == j ? 1.0 : 0.0) + SH * (S_A[i * SN + j] + (i == j ? 0.1 * cos(x[i]) : 0.0));
+}
+ILQR_MODEL_FN void dynamics_jacobian_action(double* fu, const double* x, const double* u, const double* w) {  /* column-major n x m */
+    for (int j = 0; j < SM; ++j)
+        for (int i = 0; i < SN; ++i) fu[j * SN + i] = SH * S_B[i * SM + j];
+}
+ILQR_MODEL_FN void cost_stage(double* l, const double* x, const double* u, const double* w) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < SN; ++i) a += (x[i] - 0.5) * (x[i] - 0.5);
+    for (int j = 0; j < SM; ++j) b += u[j] * u[j];
+    l[0] = 0.1 * a + 0.01 * b;
+}
+ILQR_MODEL_FN void cost_stage_gradient_state(double* g, const double* x, const double* u, const double* w) { for (int i = 0; i < SN; ++i) g[i] = 0.2 * (x[i] - 0.5); }
+ILQR_MODEL_FN void cost_stage_gradient_action(double* g, const double* x, const double* u, const double* w) { for (int j = 0; j < SM; ++j) g[j] = 0.02 * u[j]; }
+ILQR_MODEL_FN void cost_stage_hessian_state_state(double* h, const double* x, const double* u, const double* w) { for (int i = 0; i < SN; ++i) h[i * SN + i] = 0.2; }
+ILQR_MODEL_FN void cost_stage_hessian_action_action(double* h, const double* x, const double* u, const double* w) { for (int j = 0; j < SM; ++j) h[j * SM + j] = 0.02; }
+ILQR_MODEL_FN void cost_stage_hessian_action_state(double* h, const double* x, const double* u, const double* w) { }
+ILQR_MODEL_FN void cost_terminal(double* l, const double* x, const double* u, const double* w) {
+    double a = 0.0;
+    for (int i = 0; i < SN; ++i) a += (x[i] - 0.5) * (x[i] - 0.5);
+    l[0] = 10.0 * a;
+}
+ILQR_MODEL_FN void cost_terminal_gradient_state(double* g, const double* x, const double* u, const double* w) { for (int i = 0; i < SN; ++i) g[i] = 20.0 * (x[i] - 0.5); }
+ILQR_MODEL_FN void cost_terminal_hessian_state_state(double* h, const double* x, const double* u, const double* w) { for (int i = 0; i < SN; ++i) h[i * SN + i] = 20.0; }
+/* stage: the action box -1 <= u <= 1 as 2 m inequalities */
+ILQR_MODEL_FN void constraint_stage(double* c, const double* x, const double* u, const double* w) {
+    for (int j = 0; j < SM; ++j) { c[j] = -1.0 - u[j]; c[SM + j] = u[j] - 1.0; }
+}
+ILQR_MODEL_FN void constraint_stage_jacobian_state(double* cx, const double* x, const double* u, const double* w) { }
+ILQR_MODEL_FN void constraint_stage_jacobian_action(double* cu, const double* x, const double* u, const double* w) {   /* column-major 2m x m */
+    for (int j = 0; j < SM; ++j) { cu[j * 2 * SM + j] = -1.0; cu[j * 2 * SM + SM + j] = 1.0; }
+}
+""" % dict(n=n, m=m, h=h, A=tab(A), B=tab(Bm))
+
+
 def synth12():
     """A second large-path model whose dimensions are NOT multiples of the MFMA tile (nx = 12, nu = 5), with a
     bilinear term (state-dependent fu entries) and a terminal equality; twin of oracle/models.cpp "synth12"."""

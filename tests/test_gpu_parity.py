@@ -1680,15 +1680,13 @@ def test_c_callables_synth32_without_the_structure_probe(pkg, oracle, monkeypatc
 @pytest.mark.parametrize("probe", [True, False])
 def test_c_callables_at_the_size_limits(pkg, probe, monkeypatch):
     """ilqr_compile_model at nx = 64, nu = 16, 32 stage rows (the limits it advertises; advisor finding of round 3: only nx = 12 had
-    ever run): examples/synth32_model.c with its two size macros changed, with the structure probe (64 of 5120 Jacobian entries
+    ever run): the synth family's C source (models.synth_c_source, what examples/synth32_model.c is for 32 x 8), with the structure probe (64 of 5120 Jacobian entries
     state-dependent, 80 of 5376 Hessian entries) and without it (dense tables: every entry through per-thread arrays — tens of KB of
     scratch per thread, slow, but it must run), against the independent restatement of the same family."""
     import ctypes as C
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import reference_restatement as R
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    text = open(os.path.join(root, "examples", "synth32_model.c"), "rb").read()
-    text = text.replace(b"#define S32_N 32", b"#define S32_N 64").replace(b"#define S32_M 8", b"#define S32_M 16")
+    text = pkg.models.synth_c_source(64, 16).encode()
 
     class Src(C.Structure):
         _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),

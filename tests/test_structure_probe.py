@@ -56,3 +56,10 @@ def test_constant_and_zero_entries_of_c_callables_are_found_by_probing():
         if False else text + b"\n/* device-only */ static ILQR_MODEL_FN double only_on_device(double v) { return __builtin_amdgcn_rcp(v); }\n"
     name_b, jv_b, hs_b = _compile(L, b"synth12_probe_dev", bad, dims)
     assert jv_b == 12 * 12 + 12 * 5 and hs_b == 12 * 12 + 5 * 5 + 5 * 12
+
+
+def test_the_c_example_is_the_generators_output():
+    """examples/synth32_model.c is models.synth_c_source(32, 8) (literal coefficient tables, dense Jacobian loops): the file a C or
+    Julia host reads and the text the size-limit GPU test generates for 64 x 16 cannot drift apart."""
+    pkg = load_package()
+    assert open(os.path.join(ROOT, "examples", "synth32_model.c")).read() == pkg.models.synth_c_source(32, 8)

@@ -58,3 +58,19 @@ for label in ("C callables, probed", "C callables, dense"):
     r = res[label]
     same = (r[1]["iterations"] == g[1]["iterations"]) & (r[1]["rollouts"] == g[1]["rollouts"])
     print("%s vs generated: control flow identical on %.1f %%, max |dx| %.3e" % (label, 100 * same.mean(), np.abs(r[0] - g[0])[same].max()))
+
+# where the C-callable model's time goes: wall time of single stage launches (synchronous calls), generated model beside it
+print("stage times (ms per launch, %d instances):" % B)
+for label, mdl in (("generated", model), ("C callables, probed", compile_c(False))):
+    s = pkg.Solver(model=mdl, horizon=T, batch=B, options=pkg.Options(verbose=0, **opts))
+    s.initialize_rollout_(x1, ub)
+    out = []
+    for stage in ("cost_nominal", "gradients", "backward_pass", "forward_pass"):
+        best = 1e9
+        for rep in range(3):
+            t0 = time.perf_counter(); s.run_stage_(stage); s.synchronize(); best = min(best, time.perf_counter() - t0)
+        out.append("%s %.2f" % (stage, 1e3 * best))
+    t0 = time.perf_counter(); s.reset_(); s.initialize_rollout_(x1, ub); s.synchronize()
+    out.append("reset + initial rollout %.2f" % (1e3 * (time.perf_counter() - t0)))
+    print("   %-22s %s" % (label, "  ".join(out)))
+    s.close()
