@@ -1293,6 +1293,7 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             oxx -= dxx; oux -= dux; ouu -= 32u;
             ast += par ? dB : dA;
             par ^= 1;
+            asm volatile("" : "+v"(afx), "+v"(afu), "+v"(ast));          // (see the vector chain: no re-basing onto negative DS offsets)
             ILQR_BAR_BEGIN();
             __syncthreads();                                            // hand the chunk over (the other half of the ring is free again)
             ILQR_BAR_END(I, PROF_DELTA);
@@ -1309,6 +1310,9 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
         unsigned arq = vr ? lds(I.ring + M1_RQ + r) : zero;            const unsigned dq = vr ? 32u * n : 0u;
         unsigned asa = lds(I.ring + M1_RS);
         unsigned ak = lds(I.k + tl);
+        // (the three wave-uniform LDS addresses in VGPRs: left to itself the compiler keeps them in scalar registers and moves them
+        // to a vector register in front of every access, 10 of the chunk's 148 issue slots)
+        asm volatile("" : "+v"(agu), "+v"(asa), "+v"(ak));
         // the Lagrangian gradient goes straight to its place in the instance's HBM block (plain stores, nobody in the workgroup
         // reads it back during a solve: ‖∇L‖∞ and ∇Lᵀ·Δz are carried in registers) — an LDS store costs the wave 25 clk with the
         // CUs busy (profiles/r02_probe_lds.txt), a global one its issue slot
@@ -1375,6 +1379,9 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             arq += par ? (0u - dq) : dq;
             asa += par ? (unsigned)(-32 * n) : 32u * n;
             par ^= 1;
+            // (the walking LDS addresses are opaque from here on: re-based on ONE induction variable by the compiler, the accesses of a
+            // chunk end up at negative offsets, which a DS instruction cannot encode — an add in front of every access, 20 per chunk)
+            asm volatile("" : "+v"(afx), "+v"(afu), "+v"(agx), "+v"(agu), "+v"(aK), "+v"(ak), "+v"(arq), "+v"(asa));
             if (t < 0) break;
         }
         I.gradient_norm = wave_max(nanmask != 0 ? __builtin_nan("") : gmax);
