@@ -769,12 +769,15 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                         tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
                     } else if constexpr (kind == RIC_QUX) {                  // Qux = ûx fx + gux (:63-64)
                         double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
-                        if constexpr (STAGE) acc += tile_load<ldm>(S3 + LD::oGux, 0, 16 * idx, li, lk);
-                        tile_store<ldm>(sQux, acc, 0, 16 * idx, li, lk);
+                        const int eo = (16 * idx + li) * ldm + lk;       // ONE element offset for the staged tile and the result, both through the LDS-qualified base
+                                                                         // (tile_load on it beside tile_store on the generic pointer computed the offset twice: 1 % of the pass)
+                        if constexpr (STAGE) { for (int r4 = 0; r4 < 4; ++r4) acc[r4] += S3[LD::oGux + eo + 4 * r4]; }
+                        for (int r4 = 0; r4 < 4; ++r4) S3[LD::oQux + eo + 4 * r4] = acc[r4];
                     } else {                                                 // Quu = ûx fu + guu (:58-59)
                         double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
-                        if constexpr (STAGE) acc += tile_load<ldm>(S3 + LD::oGuu, 0, 0, li, lk);
-                        tile_store<ldm>(sQuu, acc, 0, 0, li, lk);
+                        const int eo = li * ldm + lk;
+                        if constexpr (STAGE) { for (int r4 = 0; r4 < 4; ++r4) acc[r4] += S3[LD::oGuu + eo + 4 * r4]; }
+                        for (int r4 = 0; r4 < 4; ++r4) S3[LD::oQuu + eo + 4 * r4] = acc[r4];
                     }
                 }
             });
