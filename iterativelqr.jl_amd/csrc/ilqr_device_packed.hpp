@@ -27,6 +27,9 @@ namespace ilqr {
 
 template <class M> struct packed_ok { static constexpr bool value = (M::NX <= 4 && M::NU <= 4); };
 
+#ifndef ILQR_PIN_PACKED_CONSTANTS
+#define ILQR_PIN_PACKED_CONSTANTS true      // the model's wave-uniform constants as opaque scalar pairs in the rollout (see ilqr_device.hpp)
+#endif
 #ifndef ILQR_PK_TRIALS
 #define ILQR_PK_TRIALS 4      // line-search trials per cycle of the packed kernel's state machine (1 = the first version: one)
 #endif
@@ -541,7 +544,10 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
     // offset and neighbouring doubles merge into one wide load; a 32-bit add could wrap, so hipcc would keep it)
     auto GL = [&](unsigned off, int idx) -> double { return ((const double*)(wb + off))[idx]; };
     auto GS = [&](unsigned off, int idx, double v) { ((double*)(const_cast<char*>(wb) + off))[idx] = v; };
-    const unsigned otrash = og + 8u * (L.gzero + 1);
+    // lanes that store nothing aim at the block's trash REGION with stride 0 and use the same constant index as the writers (a
+    // lane-dependent index cannot fold into the instruction's immediate: a 64-bit address add in front of every store)
+    const unsigned otrash = og + 8u * (L.gzero + 2 + GZERO_REGION);
+    static_assert(n <= GTRASH_REGION && m <= GTRASH_REGION, "trash region holds a row of x or u");
     const bool wr = act && I.j == 0;
     double xt[n];
 #pragma unroll
@@ -550,7 +556,7 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) g[L.x + i] = xt[i];
     }
-    const typename M::WaveCtx wcx = M::template wave_ctx<false>(I.j);   // per-lane constants of the cooperative dynamics (I.j: lane of the row)
+    const typename M::WaveCtx wcx = M::template wave_ctx<ILQR_PIN_PACKED_CONSTANTS>(I.j);   // per-lane constants of the cooperative dynamics (I.j: lane of the row)
     // loads on every lane of the row (all lanes evaluate the policy), stores on the row's lane 0 only (trash slot, stride 0 elsewhere)
     unsigned oK = og + 8u * L.K, ok_ = og + 8u * L.k, oub = og + 8u * L.ub, oxb = og + 8u * L.xb;
     unsigned wU = wr ? og + 8u * L.u : otrash, wX = wr ? og + 8u * L.x : otrash;
@@ -582,9 +588,9 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
         load_w<M::NW>(g + L.w, t, w);
         M::template dyn_wave<Row16BC>(wcx, I.j, xin, ut, w, xout);      // (:29)
 #pragma unroll
-        for (int i = 0; i < m; ++i) GS(wU + d * sU, wr ? i : 0, ut[i]);
+        for (int i = 0; i < m; ++i) GS(wU + d * sU, i, ut[i]);
 #pragma unroll
-        for (int i = 0; i < n; ++i) GS(wX + (d + 1) * sX, wr ? i : 0, xout[i]);
+        for (int i = 0; i < n; ++i) GS(wX + (d + 1) * sX, i, xout[i]);
     };
     // operands are fetched TWO steps ahead (three rotating register sets): they come from HBM / L2 here, and at one wave per
     // SIMD nothing else hides their latency
