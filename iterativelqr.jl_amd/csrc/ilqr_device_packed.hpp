@@ -508,14 +508,25 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         int sl = cnt - 1;
         afx = bfx + sl * sfx; afu = bfu + sl * sfu; agx = bgx + sl * sgx; agu = bgu + sl * sgu;   // LDS operands of the chunk's last step
         fetch(A);
-        for (; sl >= 1; sl -= 2) {
+        // pairs of steps while a whole pair follows (both sets refilled unconditionally: a fetch behind a branch costs a copy of the
+        // seven operands at the loop edge), then the chunk's last one to three steps; nothing is fetched across the chunk boundary
+        // (the next chunk's Hessians are accumulated by its linearisation first)
+        for (; sl >= 3; sl -= 2) {
             fetch(B);
             riccati_step(A, t0 + sl);
-            if (sl >= 2) fetch(A);
-            else mfma_block_boundary_guard();         // (see ilqr_device.hpp: a step entered through a taken branch)
+            fetch(A);
             riccati_step(B, t0 + sl - 1);
         }
-        if (sl == 0) { mfma_block_boundary_guard(); riccati_step(A, t0); }
+        if (sl == 2) {
+            fetch(B); mfma_block_boundary_guard(); riccati_step(A, t0 + 2);
+            fetch(A); riccati_step(B, t0 + 1);
+            riccati_step(A, t0);
+        } else if (sl == 1) {
+            fetch(B); mfma_block_boundary_guard(); riccati_step(A, t0 + 1);
+            riccati_step(B, t0);
+        } else {
+            mfma_block_boundary_guard(); riccati_step(A, t0);
+        }
         __syncthreads();                      // the chunk buffer is free again
     }
     double gm = (on && c == 0) ? (gnan ? __builtin_nan("") : gmax) : 0.0;
