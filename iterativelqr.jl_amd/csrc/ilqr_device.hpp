@@ -192,6 +192,9 @@ enum { PROF_COST = 0, PROF_GRAD, PROF_BACKWARD, PROF_DELTA, PROF_ROLLOUT, PROF_O
 // the build keeps (-save-temps, csrc/Makefile) and reads their per-step instruction counts off it. An empty asm statement: it
 // emits no instruction (same-box A/B of the library with and without the markers: profiles/r03_ab_markers.txt).
 #define ILQR_ISA_MARK(name, role) asm volatile("; ILQR_MARK " name " %0" ::"i"(role))
+// a rarely taken straight-line region inside a serial loop (tools/issue_model.py leaves what lies between the two out of the step's list)
+#define ILQR_ISA_COLD_BEGIN() asm volatile("; ILQR_COLD_BEGIN")
+#define ILQR_ISA_COLD_END() asm volatile("; ILQR_COLD_END")
 
 // Per-instance context. LDS pointers first, then HBM pointers, then the
 // wave-uniform SolverData scalars (src/data/solver.jl:4-18) kept in registers.
@@ -536,6 +539,33 @@ __device__ __forceinline__ int potrf_U(double (&A)[m * m]) {
     double R[m];
     return potrf_U<m>(A, R);
 }
+// The same factorisation WITHOUT the failure handling: no select, no exec-masked division — for a matrix whose pivots all come out
+// positive, operation for operation what potrf_U computes (the selects there only choose between these values and the failure
+// path's). Returns whether a pivot was not positive (or NaN): the caller then repeats the step's factorisation with potrf_U behind
+// one wave-uniform branch (a select on a double is two instructions; potrf_U<2> carried 14 of them and two masked regions).
+template <int m>
+__device__ __forceinline__ bool potrf_U_nofail(double (&A)[m * m], double (&R)[m]) {
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+        double ajj = A[j * m + j];
+#pragma unroll
+        for (int l = 0; l < j; ++l) ajj -= A[j * m + l] * A[j * m + l];
+        bad |= !(ajj > 0.0);
+        double dq, rq;
+        sqrt_rsqrt_fast(ajj, dq, rq);
+        A[j * m + j] = dq;
+        R[j] = rq;
+#pragma unroll
+        for (int c = j + 1; c < m; ++c) {
+            double v = A[c * m + j];
+#pragma unroll
+            for (int l = 0; l < j; ++l) v -= A[j * m + l] * A[c * m + l];
+            A[c * m + j] = v * rq;
+        }
+    }
+    return bad;
+}
 // potrs('U') with the inverted diagonal R
 template <int m, int nrhs>
 __device__ __forceinline__ void potrs_U_rdiag(const double (&U)[m * m], const double (&R)[m], double (&B)[m * nrhs]) {
@@ -811,7 +841,15 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         int info = 0;
         double Ur[m];                                                   // inverted diagonal of the factor
         if (m == 1) info = (Uc[0] > 0.0) ? 0 : 1;
-        else info = potrf_U<m>(Uc, Ur);
+        else if (__builtin_expect(__any(potrf_U_nofail<m>(Uc, Ur)), 0)) {     // a pivot failed somewhere in the wave: LAPACK's sequence with its failure handling
+            ILQR_ISA_COLD_BEGIN();
+#pragma unroll
+            for (int j = 0; j < m; ++j)
+#pragma unroll
+                for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
+            info = potrf_U<m>(Uc, Ur);
+            ILQR_ISA_COLD_END();
+        }
         if (m == 1 && info != 0) potrf_U<m>(Uc, Ur);
         if (MAT && info != 0 && I.potrf_info == 0) I.potrf_info = info;
         if constexpr (ROLE == 0) {
@@ -1045,7 +1083,16 @@ __device__ void backward_pass_split(Inst<M>& I) {
                 for (int j = 0; j < m; ++j)
 #pragma unroll
                     for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
-                const int info = potrf_U<m>(Uc, Ur);                    // (:68-69) upper triangle only, info ignored
+                int info = 0;                                           // (:68-69) upper triangle only, info ignored
+                if (__builtin_expect(__any(potrf_U_nofail<m>(Uc, Ur)), 0)) {         // a failed pivot: LAPACK's sequence with its failure handling
+                    ILQR_ISA_COLD_BEGIN();
+#pragma unroll
+                    for (int j = 0; j < m; ++j)
+#pragma unroll
+                        for (int i = 0; i < m; ++i) Uc[j * m + i] = (i <= j) ? lane_bcast(Quu, j + 16 * i) : 0.0;
+                    info = potrf_U<m>(Uc, Ur);
+                    ILQR_ISA_COLD_END();
+                }
                 if (info != 0 && I.potrf_info == 0) I.potrf_info = info;
                 K = solve(Qux, Uc, Ur);
                 int q_ = 0;

@@ -450,7 +450,16 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
 #pragma unroll
                 for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;   // (:68-69)
             double Ur[m];
-            const int info = potrf_U<m>(Uc, Ur);
+            int info = 0;
+            if (__builtin_expect(__any(potrf_U_nofail<m>(Uc, Ur)), 0)) {    // (ilqr_device.hpp) a pivot failed in one of the wave's instances
+                ILQR_ISA_COLD_BEGIN();
+#pragma unroll
+                for (int jj = 0; jj < m; ++jj)
+#pragma unroll
+                    for (int i = 0; i < m; ++i) Uc[jj * m + i] = (i <= jj) ? shfl_d(Quu, blk0 + jj + 16 * i) : 0.0;
+                info = potrf_U<m>(Uc, Ur);
+                ILQR_ISA_COLD_END();
+            }
             if (info != 0 && pinfo == 0) pinfo = info;
             if constexpr (SHARE) {
                 // right-hand sides: Qux in rows 0..m-1, Qu (column 0) moved down into rows m..2m-1: ONE solve for K and k

@@ -150,6 +150,17 @@ def marked_loop(body, marker):
     loop = max((owner[i] for i in marks), key=lambda o: o[1])
     k = sum(1 for i in marks if owner[i] == loop)
     lines = [body[i] for i in range(len(body)) if owner[i] == loop]
+    # rarely taken straight-line regions (ILQR_ISA_COLD_BEGIN / _END in the kernels: the repeat of a factorisation after a failed
+    # pivot) are not part of the step's list either; the compiler may place such a block anywhere inside the loop's blocks
+    kept, cold = [], 0
+    for ln in lines:
+        if "ILQR_COLD_BEGIN" in ln:
+            cold += 1
+        elif "ILQR_COLD_END" in ln:
+            cold = max(0, cold - 1)
+        elif cold == 0:
+            kept.append(ln)
+    lines = kept
     c = classify(lines, (0, len(lines) - 1))
     c["chain"] = recurrence_chain(lines)
     return c, k
