@@ -205,7 +205,7 @@ int ilqr_enable_action_value_buffers(ilqr_handle* h);
 int ilqr_scalar_slot(const char* name);
 
 /* Kernel variant of ilqr_solve. Large models (nx > 4 or nu > 4): 0 = auto, 1 = four waves per instance (two instances per CU),
- * 4 = ONE wave per instance (eight per CU) for models whose matrices are single 16x16 tiles (nx, nu <= 16) — the same phase
+ * 4 = ONE wave per instance (six per CU: 25 KB of LDS each) for models whose matrices are single 16x16 tiles (nx, nu <= 16) — the same phase
  * functions with the four wave roles of a phase run in turn, bitwise the four-wave results; auto takes it once the batch exceeds
  * 8 x CUs (an instance alone is faster on four waves; residency wins beyond that). Small models (nx, nu <= 4): 0 = auto — the latency kernel
  * (two waves per instance, all iteration state in LDS) while the batch fits the chip at one instance per SIMD (batch <= 4 x CUs),
