@@ -281,8 +281,8 @@ class Solver:
             _ffi.check(_ffi.lib().ilqr_set_buffer(self._h, name.encode(), _p(v)))
 
     def set_kernel_variant_(self, variant):
-        """"auto" | "latency" | "throughput" | "packed" | "mid" (see ilqr_set_kernel_variant)."""
-        v = {"auto": 0, "latency": 1, "throughput": 2, "packed": 3, "mid": 4}.get(variant, variant)
+        """"auto" | "latency" | "throughput" | "packed" | "mid" | "packed1" | "packed2" (see ilqr_set_kernel_variant)."""
+        v = {"auto": 0, "latency": 1, "throughput": 2, "packed": 3, "mid": 4, "packed1": 5, "packed2": 6}.get(variant, variant)
         _ffi.check(_ffi.lib().ilqr_set_kernel_variant(self._h, int(v)))
 
     def set_handover_(self, outer):

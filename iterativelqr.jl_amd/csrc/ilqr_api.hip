@@ -859,7 +859,7 @@ int ilqr_solve(ilqr_handle* h) {
     // the throughput kernel otherwise.
     // Horizons whose LDS-resident set exceeds 160 KiB run on the packed kernel only.
     const bool can_pack = h->vt->launch_solve_packed != nullptr;
-    const bool packed = can_pack && (h->variant == 3 || !h->lds_fits || (h->variant == 0 && h->B > h->num_simds));
+    const bool packed = can_pack && (h->variant == 3 || h->variant == 5 || h->variant == 6 || !h->lds_fits || (h->variant == 0 && h->B > h->num_simds));
     const bool slim = !packed && h->vt->launch_solve_slim != nullptr &&
                       (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
     if (!packed && !h->lds_fits) return drop(fail(ILQR_ERR_LDS, "this horizon only runs on the packed kernel"));
@@ -883,7 +883,13 @@ int ilqr_solve(ilqr_handle* h) {
 #ifdef ILQR_PK_DEBUG_HOOK      // phase-timing hook of tools/packed_phases.py (see ilqr_device_packed.hpp); never compiled into the product library
         if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);
 #endif
+        // two waves per pack (a linearisation server beside the solver wave) while the batch leaves every SIMD at most two waves and
+        // a CU's LDS holds the second chunk buffers: up to 4 workgroups per CU (variant 5 = one wave per pack, 6 = two where they fit)
+        const int packs = (h->B + 3) / 4, cus = std::max(1, h->num_simds / 4), per_cu = (packs + cus - 1) / cus;
+        a.stage_flag = (h->variant != 5 && per_cu <= 4) ? 2 : 0;
+        a.stage_param = (double)per_cu;
         if (h->vt->launch_solve_packed(&a, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (packed variant) launch failed"));
+        a.stage_flag = 0; a.stage_param = 0.0;
         if (ho > 0 || live > 0) {
             ilqr::KArgs r = a;
             r.resume = 1; r.stage = 0;
@@ -1048,10 +1054,10 @@ int ilqr_set_buffer(ilqr_handle* h, const char* name, const double* in) {
 
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
     if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_kernel_variant(s, variant); });
-    if (!h || variant < 0 || variant > 4) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency), 2 (throughput), 3 (packed) or 4 (one wave per instance of a large model)");
+    if (!h || variant < 0 || variant > 6) return fail(ILQR_ERR_INVALID, "variant must be 0 (auto), 1 (latency), 2 (throughput), 3 (packed), 4 (one wave per instance of a large model), 5 / 6 (packed with one / two waves per pack)");
     if (variant == 4 && h->vt->launch_solve_mid == nullptr)
         return fail(ILQR_ERR_INVALID, "the one-wave variant exists for large models with nx, nu <= 16 only");
-    if (variant == 3 && h->vt->launch_solve_packed == nullptr)
+    if ((variant == 3 || variant == 5 || variant == 6) && h->vt->launch_solve_packed == nullptr)
         return fail(ILQR_ERR_INVALID, "the packed variant exists for small models (nx, nu <= 4) only");
     if ((variant == 1 || variant == 2) && !h->lds_fits)
         return fail(ILQR_ERR_LDS, "this horizon exceeds the LDS-resident kernels: only the packed variant can run it");

@@ -2279,9 +2279,21 @@ struct ModelModule {
             return -1;
         }
     }
+    // KArgs::stage_flag == 2 asks for the two-wave form (a linearisation server beside the solver wave, ilqr_device_packed.hpp) with
+    // KArgs::stage_param = workgroups per CU at this batch size: taken when its two chunk buffers fit a CU's LDS at that residency
     static int launch_solve_packed(const KArgs* a, void* stream) {
         if constexpr (packed_ok<M>::value) {
-            hipLaunchKernelGGL(solve_kernel_packed<M>, dim3((a->B + 3) / 4), dim3(64), sizeof(double) * pk::PkLds<M>::total, (hipStream_t)stream, *a);
+            constexpr size_t lds1 = sizeof(double) * pk::PkLds<M, false>::total, lds2 = sizeof(double) * pk::PkLds<M, true>::total;
+            const double per_cu = a->stage_param >= 1.0 ? a->stage_param : 1.0;
+            if (a->stage_flag == 2 && per_cu * (double)(lds2 + 512) <= 160.0 * 1024.0 && per_cu <= 4.0) {
+                KArgs b = *a;
+                b.stage_flag = 0; b.stage_param = 0.0;
+                hipLaunchKernelGGL((solve_kernel_packed<M, true>), dim3((a->B + 3) / 4), dim3(128), lds2, (hipStream_t)stream, b);
+            } else {
+                KArgs b = *a;
+                b.stage_flag = 0; b.stage_param = 0.0;
+                hipLaunchKernelGGL((solve_kernel_packed<M, false>), dim3((a->B + 3) / 4), dim3(64), lds1, (hipStream_t)stream, b);
+            }
             return hipGetLastError() == hipSuccess ? 0 : -1;
         } else {
             return -1;

@@ -235,12 +235,14 @@ __device__ void cost_bang(PInst<M>& I, bool act, bool mode_current, bool constra
 // sensitivity recursion — with  w_t = ∇L_u,t + fu_tᵀ ν_{t+1},  ν_t = ∇L_x,t + fx_tᵀ ν_{t+1} + K_tᵀ w_t,  ν_H = 0:
 // Δ = Σ_t w_tᵀ k_t  — the same bilinear form summed in the opposite order (four MFMAs per step on operands that are in
 // registers anyway), which saves the forward sweep over fx, fu, K, k, ∇L altogether.
-template <class M>
+// TWO: the two-wave form of the kernel (below) — a second chunk buffer, so that a helper wave linearises chunk ch - 1 while the
+// Riccati steps of chunk ch run, and a mailbox through which the solver wave tells it what to linearise.
+template <class M, bool TWO = false>
 struct PkLds {
     static constexpr int n = M::NX, m = M::NU;
     static constexpr int SFX = (n * n) | 1, SFU = (n * m) | 1, SGX = n | 1, SGU = m | 1;      // odd strides: conflict-free lane-per-step writes
     static constexpr int FX = 0, FU = FX + 16 * SFX, GX = FU + 16 * SFU, GU = GX + 16 * SGX, IB = GU + 16 * SGU;
-    static constexpr int TERM = 4 * IB, ZERO = TERM + 4 * n, total = ZERO + 2;
+    static constexpr int BUF = 4 * IB, TERM = (TWO ? 2 : 1) * BUF, ZERO = TERM + 4 * n, MBOX = ZERO + 2, total = MBOX + (TWO ? 2 : 0);
 };
 
 // One stage timestep of gradients!: a real function, so that the (large) symbolic Jacobian code gets its own register
@@ -291,11 +293,11 @@ __attribute__((noinline)) __device__ void linearise_stage(LinArgs a) {
     for (int i = 0; i < m; ++i) lrow[LD::GU + a.j * LD::SGU + i] = gu[i];
 }
 
-template <class M>
+template <class M, bool TWO>
 __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool constrained,
                                   double& gnorm_row, int& info_row, double& delta_row) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
-    typedef PkLds<M> LD;
+    typedef PkLds<M, TWO> LD;
     static_assert(n <= 4 && m <= 4, "packed Riccati step: nx, nu <= 4");
     constexpr bool SHARE = 2 * m <= 4;      // k's right-hand side fits into the spare rows m..2m-1 of the block and shares K's solve
     extern __shared__ __attribute__((aligned(16))) double pk_lds[];
@@ -331,6 +333,13 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         }
 #pragma unroll
         for (int i = 0; i < n; ++i) { pk_lds[LD::TERM + I.q * n + i] = gx[i]; gr[L.gx + N * n + i] = gx[i]; }
+    }
+    if constexpr (TWO) {                    // the helper wave's order: which instances, constrained or not (pk_helper)
+        if (lane == 0) {
+            volatile int* mb = (volatile int*)(pk_lds + LD::MBOX);
+            mb[1] = (int)mask; mb[2] = constrained ? 1 : 0;
+            mb[0] = mb[0] + 1;
+        }
     }
     __syncthreads();
     const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n, vmm = on && r < m && c < m;
@@ -504,18 +513,23 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     };
     for (int ch = (N + 15) / 16 - 1; ch >= 0; --ch) {
         const int t0 = 16 * ch, cnt = (N - t0) < 16 ? (N - t0) : 16;
-        // ---- linearise timesteps t0 .. t0 + cnt - 1, one per lane of a row
-        if (act_row && I.j < cnt) {
-            LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + I.j, I.q * LD::IB, I.j, constrained ? 1 : 0};
+        // ---- linearise timesteps t0 .. t0 + cnt - 1, one per lane of a row (two-wave form: the helper wave has done it, into
+        // buffer ch & 1, while the previous chunk's steps ran here)
+        if constexpr (!TWO) {
+            if (act_row && I.j < cnt) {
+                LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + I.j, I.q * LD::IB, I.j, constrained ? 1 : 0};
 #ifndef PK_X_NOLIN
-            linearise_stage<M>(la);
+                linearise_stage<M>(la);
 #endif
+            }
         }
         __syncthreads();
         // ---- Riccati steps of the chunk, last timestep first   (:42)
         Opnd A, B;
         int sl = cnt - 1;
-        afx = bfx + sl * sfx; afu = bfu + sl * sfu; agx = bgx + sl * sgx; agu = bgu + sl * sgu;   // LDS operands of the chunk's last step
+        const unsigned buf = TWO ? (unsigned)(ch & 1) * 8u * LD::BUF : 0u;                         // (lzero lies behind both buffers: no offset for padding lanes)
+        afx = bfx + sl * sfx + (vnn ? buf : 0u); afu = bfu + sl * sfu + (vnm ? buf : 0u);         // LDS operands of the chunk's last step
+        agx = bgx + sl * sgx + (vn1 ? buf : 0u); agu = bgu + sl * sgu + (vm1 ? buf : 0u);
         fetch(A);
         // pairs of steps while a whole pair follows (both sets refilled unconditionally: a fetch behind a branch costs a copy of the
         // seven operands at the loop edge), then the chunk's last one to three steps; nothing is fetched across the chunk boundary
@@ -536,7 +550,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         } else {
             mfma_block_boundary_guard(); riccati_step(A, t0);
         }
-        __syncthreads();                      // the chunk buffer is free again
+        if constexpr (!TWO) __syncthreads();  // the chunk buffer is free again (two buffers: the next chunk's barrier says so)
     }
     double gm = (on && c == 0) ? (gnan ? __builtin_nan("") : gmax) : 0.0;
     { double w_; w_ = __shfl_xor(gm, 16); gm = nanmax(gm, w_); w_ = __shfl_xor(gm, 32); gm = nanmax(gm, w_); }
@@ -688,15 +702,63 @@ __device__ __forceinline__ void row_copy(PInst<M>& I, bool act, int dst, int src
 
 }  // namespace pk
 
-// solve!(solver) for four instances per wave — src/solve.jl:1-54, 88-143 as a per-instance state machine
+// Two-wave form (solve_kernel_packed<M, true>, 128 threads): wave 1 is a LINEARISATION SERVER. The chunk linearisations are 40 % of
+// the instructions of a linearise + Riccati pass and depend on nothing the Riccati steps produce: while wave 0 takes the steps of
+// chunk ch out of one LDS buffer, wave 1 linearises chunk ch - 1 into the other (one workgroup barrier per chunk). Everything else
+// of the state machine stays on wave 0; wave 1 sits in a barrier loop and looks into its mailbox after every barrier of the
+// workgroup (wave 0's own barriers, which a lone wave passes at once, are met by that loop). Same functions on the same inputs in
+// the same order per instance: results bitwise those of the one-wave form. Used where the second buffer fits the CU's LDS at the
+// batch's residency (ilqr_api.hip).
+namespace pk {
 template <class M>
-__global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
+__device__ void pk_helper(const KArgs& a) {
+    constexpr int n = M::NX, m = M::NU;
+    (void)n; (void)m;
+    typedef PkLds<M, true> LD;
+    extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+    const Layout& L = a.L;
+    const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, N = L.T - 1;
+    const int b_row = blockIdx.x * 4 + q;
+    const bool valid_row = b_row < a.B;
+    double* gr = a.ws + (size_t)(valid_row ? b_row : a.B - 1) * (size_t)L.stride;
+    volatile int* mb = (volatile int*)(pk_lds + LD::MBOX);
+    int seen = 0;
+    for (;;) {
+        __syncthreads();
+        const int seq = __builtin_amdgcn_readfirstlane(mb[0]);
+        if (seq == seen) continue;
+        seen = seq;
+        if (seq < 0) return;
+        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(mb[1]);
+        const int constrained = __builtin_amdgcn_readfirstlane(mb[2]);
+        const bool act_row = valid_row && ((mask >> q) & 1u);
+        for (int ch = (N + 15) / 16 - 1; ch >= 0; --ch) {
+            const int t0 = 16 * ch, cnt = (N - t0) < 16 ? (N - t0) : 16;
+            if (act_row && j < cnt) {
+                LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + j, q * LD::IB + (ch & 1) * LD::BUF, j, constrained};
+                linearise_stage<M>(la);
+            }
+            __syncthreads();
+        }
+    }
+}
+}  // namespace pk
+
+// solve!(solver) for four instances per wave — src/solve.jl:1-54, 88-143 as a per-instance state machine
+template <class M, bool TWO = false>
+__global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS;
     using namespace pk;
+    if constexpr (TWO) {
+        extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+        if (threadIdx.x == 0) { volatile int* mb = (volatile int*)(pk_lds + PkLds<M, true>::MBOX); mb[0] = 0; mb[1] = 0; mb[2] = 0; }
+        __syncthreads();
+        if (threadIdx.x >= 64) { pk_helper<M>(a); return; }
+    }
     PInst<M> I;
     const Layout& L = a.L;
     I.L = L;
-    I.lane = threadIdx.x; I.q = I.lane >> 4; I.j = I.lane & 15; I.beta = (I.lane >> 2) & 3; I.r = I.lane >> 4; I.c = I.lane & 3;
+    I.lane = threadIdx.x & 63; I.q = I.lane >> 4; I.j = I.lane & 15; I.beta = (I.lane >> 2) & 3; I.r = I.lane >> 4; I.c = I.lane & 3;
     const int b_row = blockIdx.x * 4 + I.q, b_blk = blockIdx.x * 4 + I.beta;
     I.valid_row = b_row < a.B; I.valid_blk = b_blk < a.B;
     I.g = a.ws + (size_t)(I.valid_row ? b_row : a.B - 1) * (size_t)L.stride;
@@ -854,7 +916,7 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
             const unsigned bmask = row_mask(lin);
             if (bmask) {
                 double gn = 0.0, dn = 0.0; int info = 0;
-                if (!(dbg & 8)) linearise_riccati<M>(I, lin, bmask, constrained, gn, info, dn);
+                if (!(dbg & 8)) linearise_riccati<M, TWO>(I, lin, bmask, constrained, gn, info, dn);
                 if (lin) I.delta_next = dn;
                 if (lin) {
                     I.gradient_norm = gn;
@@ -906,6 +968,10 @@ __global__ __launch_bounds__(64, 2) void solve_kernel_packed(KArgs a) {
         }
     }
     if (a.handover_live > 0 && !ho_now && al_outer && n_prev > 0 && (threadIdx.x & 63) == 0) atomicAdd(a.done_counter, n_prev);
+    if constexpr (TWO) {                    // the helper wave's leave
+        extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+        if (I.lane == 0) ((volatile int*)(pk_lds + PkLds<M, true>::MBOX))[0] = -1;
+    }
     __syncthreads();
     if (live && I.j == 0) write_scalars();
 }
