@@ -74,7 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
-    ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed", "mid"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed", "mid", "packed1", "packed2"])
     ap.add_argument("--shared-step", action="store_true",
                     help="optional mode, NOT the reference's behaviour and not the headline: one Armijo step size per inner iteration "
                          "for the whole (multi-GPU) batch, decided on the summed merit — one all-reduce (RCCL over xGMI) of three "

@@ -212,7 +212,10 @@ int ilqr_scalar_slot(const char* name);
  * the packed kernel beyond that and for horizons whose LDS-resident set exceeds the 160 KiB of a CU; 1 = latency; 2 = throughput
  * (one wave per instance, Jacobians in HBM / L2; superseded by the packed kernel, kept for A/B runs); 3 = packed — FOUR
  * instances per wave on the four blocks of v_mfma_f64_4x4x4, workspace streamed from HBM / L2 through a 13 KB LDS chunk buffer
- * per wave, no horizon limit. All run the same arithmetic up to the association of a few sums. */
+ * per wave, no horizon limit — with a SECOND wave per pack as linearisation server (chunk ch - 1 linearised into a second LDS buffer
+ * while the Riccati steps of chunk ch run; bitwise the one-wave results) wherever the buffers fit the CU's LDS at the batch's
+ * residency (up to 4 packs per CU, i.e. batch <= 16 x CUs); 5 = packed, one wave per pack always; 6 = packed, two waves where they
+ * fit (= 3; kept distinct for A/B runs). All run the same arithmetic up to the association of a few sums. */
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);
 /* Straggler hand-over of the packed kernel (no counterpart in the reference, which is one trajectory per Solver): a batched
  * launch lasts as long as its slowest instance, and in the packed kernel a straggler keeps a whole wave at 120-240 us per

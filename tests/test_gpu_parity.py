@@ -778,6 +778,45 @@ def test_packed_kernel_ragged_batches(pkg, oracle, config, B):
     sol.close()
 
 
+@pytest.mark.parametrize("config,B", [("particle", 9), ("car", 37), ("acrobot51", 45), ("car_obs", 21), ("car_goal", 130)])
+def test_packed_kernel_with_a_linearisation_server_equals_the_one_wave_form(pkg, oracle, config, B):
+    """Two waves per pack: wave 1 linearises chunk ch - 1 into a second LDS buffer while wave 0 takes the Riccati steps of chunk ch
+    (`packed2`; what `packed` / `auto` pick where the buffers fit the CU). Same functions on the same inputs in the same order per
+    instance: trajectories, policies, duals, the workspace's last linearisation and every statistic BITWISE those of the one-wave
+    form (`packed1`), with and without the straggler hand-over; against the oracle like any kernel."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B)
+    w = pkg.workloads.make_parameters(config, B) if config == "car_obs" else None
+    out = {}
+    for v, ho in (("packed1", 0), ("packed2", 0), ("packed2", -1)):
+        sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+        sol.set_kernel_variant_(v); sol.set_handover_(ho)
+        if w is not None:
+            sol.set_parameters_(w)
+        sol.enable_trace_(1100)
+        sol.initialize_rollout_(x1, ub); sol.solve_()
+        st = sol.stats()
+        out[(v, ho)] = dict(x=sol.get_trajectory()[0], u=sol.get_trajectory()[1], K=sol.get_policy()[0], k=sol.get_policy()[1],
+                            lam=sol.buffer("constraint_dual"), fx=sol.buffer("jacobian_state"), gxx=sol.buffer("hessian_state_state"),
+                            it=st["iterations"], ro=st["rollouts"], oi=st["outer_iterations"], viol=st["max_violation"], tr=sol.trace())
+        sol.close()
+    a = out[("packed1", 0)]
+    for key in (("packed2", 0), ("packed2", -1)):
+        b = out[key]
+        for f in a:
+            if key[1] == -1 and f == "tr":
+                continue            # (the objective REPORTED in a trace row by an instance that changed kernels is summed in that kernel's order)
+            if key[1] == -1 and config == "car_obs":
+                # the two-wave latency kernel that finishes handed-over instances is not bitwise the packed kernel on THIS model (a few
+                # instances 5e-14 apart in x, control flow identical; one-wave and two-wave packed forms agree with each other under
+                # hand-over too): compared to rounding here
+                assert np.allclose(a[f], b[f], rtol=1e-9, atol=1e-11, equal_nan=True), (key, f)
+                continue
+            assert np.array_equal(a[f], b[f], equal_nan=True), (key, f)
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=8, w=w)
+    same = (a["it"] == ref["stats"]["iterations"]) & (a["ro"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.99 and np.abs(out[("packed2", 0)]["x"] - ref["x"])[same].max() < 1e-7
+
+
 def test_packed_kernel_leaves_the_last_linearisation(pkg):
     """The packed kernel keeps fx, fu, gx, gu on chip while it iterates; when an instance leaves its inner loop they are
     written out, so the workspace reads like after the LDS-resident kernels (solver.problem.model.jacobian_state ...)."""

@@ -8,7 +8,7 @@ import numpy as np
 from ilqr_amd_loader import load_package
 pkg = load_package()
 bad = 0
-for cfg, B, variants in (("acrobot", 1024, ("latency", "packed", "throughput")), ("car", 2048, ("latency", "packed")), ("synth32_tight", 256, ("auto",)),
+for cfg, B, variants in (("acrobot", 1024, ("latency", "packed", "throughput")), ("car", 2048, ("latency", "packed1", "packed2")), ("synth32_tight", 256, ("auto",)),
                          ("synth12", 2048, ("latency", "mid")), ("particle", 64, ("latency", "packed"))):
     model, T, x1, ub = pkg.workloads.make_inputs(cfg, B)
     kw = pkg.workloads.CONFIG_OPTIONS.get(cfg, {})
