@@ -92,110 +92,122 @@ struct PInst {
 
 // ------------------------------------------------------------------ cost! (row mapping, one timestep per lane of a row)
 // X / U: offsets of the trajectory inside the instance block. upd_J / upd_viol are per-lane (per-instance) predicates.
+// The work of ONE timestep is split into its operand loads and its evaluation (cost_load / cost_eval), so that cost_pass can
+// request a lane's next timestep before evaluating the current one — and so that the two-wave form's helper can evaluate the
+// timesteps of a trial trajectory segment by segment behind the rollout (cost_follow), with the very same code.
+template <class M>
+struct CostIn {
+    static constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, NCM = ncs > nct ? ncs : nct, NC = NCM > 0 ? NCM : 1;
+    double x[n], u[m > 0 ? m : 1], w[cdim<M::NW>::v], lam[NC], rho[NC];
+};
+template <class M>
+__device__ __forceinline__ void cost_load(const double* g, const Layout& L, int Xo, int Uo, bool duals, int t, CostIn<M>& o) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT, NCM = CostIn<M>::NCM;
+    const int N = L.T - 1;
+    load_w<M::NW>(g + L.w, t, o.w);
+#pragma unroll
+    for (int i = 0; i < n; ++i) o.x[i] = g[Xo + t * n + i];
+    if (t < N) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) o.u[i] = g[Uo + t * m + i];
+    }
+    if (duals) {
+        const int off = t < N ? t * ncs : N * ncs, cnt = t < N ? ncs : nct;
+#pragma unroll
+        for (int i = 0; i < NCM; ++i)
+            if (i < cnt) { o.lam[i] = g[L.lam + off + i]; o.rho[i] = g[L.rho + off + i]; }
+    }
+}
+template <class M>
+__device__ __forceinline__ void cost_eval(double* g, const Layout& L, const CostIn<M>& cur, int t, bool upd_J, bool upd_viol, bool constrained,
+                                          double& Jp, double& vp) {
+    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
+    const int N = L.T - 1;
+    double* cbuf = g + L.c; double* act = g + L.act;
+    const double (&xt)[n] = cur.x;
+    const double (&w)[cdim<M::NW>::v] = cur.w;
+    if (t < N) {
+        double ut[m];
+#pragma unroll
+        for (int i = 0; i < m; ++i) ut[i] = cur.u[i];
+        if (upd_J) Jp += M::cost_s(xt, ut, w);
+        if constexpr (ncs > 0) {
+            if (constrained) {
+                double cv[ncs];
+                M::con_s(xt, ut, w, cv);
+                const int off = t * ncs;
+                if (upd_J) {
+                    double dot = 0.0, pen = 0.0;
+#pragma unroll
+                    for (int i = 0; i < ncs; ++i) {
+                        const double lam = cur.lam[i];
+                        const bool ineq = IneqMask<M>::s(i);
+                        const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
+                        act[off + i] = inactive ? 0.0 : 1.0;
+                        dot += lam * cv[i];
+                        if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
+                    }
+                    Jp += dot;
+                    Jp += pen;
+                }
+                if (upd_viol) {
+#pragma unroll
+                    for (int i = 0; i < ncs; ++i) {
+                        cbuf[off + i] = cv[i];
+                        const bool ineq = IneqMask<M>::s(i);
+                        vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
+                    }
+                }
+            }
+        }
+    } else {
+        if (upd_J) Jp += M::cost_t(xt, w);
+        if constexpr (nct > 0) {
+            if (constrained) {
+                double cv[nct];
+                M::con_t(xt, w, cv);
+                const int off = N * ncs;
+                if (upd_J) {
+                    double dot = 0.0, pen = 0.0;
+#pragma unroll
+                    for (int i = 0; i < nct; ++i) {
+                        const double lam = cur.lam[i];
+                        const bool ineq = IneqMask<M>::t(i);
+                        const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
+                        act[off + i] = inactive ? 0.0 : 1.0;
+                        dot += lam * cv[i];
+                        if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
+                    }
+                    Jp += dot;
+                    Jp += pen;
+                }
+                if (upd_viol) {
+#pragma unroll
+                    for (int i = 0; i < nct; ++i) {
+                        cbuf[off + i] = cv[i];
+                        const bool ineq = IneqMask<M>::t(i);
+                        vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
+                    }
+                }
+            }
+        }
+    }
+}
 template <class M>
 __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol, bool constrained, double& J_out, double& viol_out) {
-    constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
-    constexpr int NCM = ncs > nct ? ncs : nct, NC = NCM > 0 ? NCM : 1;
     const Layout& L = I.L;
-    const int T = L.T, N = T - 1;
-    const double* X = I.g + Xo; const double* U = I.g + Uo;
-    double* cbuf = I.g + L.c; double* act = I.g + L.act;
-    const double* lamb = I.g + L.lam; const double* rho = I.g + L.rho;
-    const double* W = I.g + L.w;
+    const int T = L.T;
     double Jp = 0.0, vp = 0.0;
     // A lane walks its timesteps t = j, j + 16, ...; every pass needs x_t, u_t, λ_t, ρ_t from HBM / L2 and nothing hides that
     // round trip at one wave per SIMD (the pass used to cost one round trip per 16 timesteps: 9 of the 80 µs of a car cycle).
     // The operands of the NEXT pass are requested before the current one is evaluated.
-    struct In { double x[n], u[m > 0 ? m : 1], w[cdim<M::NW>::v], lam[NC], rho[NC]; };
-    auto load = [&](In& o, int t) {
-        load_w<M::NW>(W, t, o.w);
-#pragma unroll
-        for (int i = 0; i < n; ++i) o.x[i] = X[t * n + i];
-        if (t < N) {
-#pragma unroll
-            for (int i = 0; i < m; ++i) o.u[i] = U[t * m + i];
-        }
-        if (constrained && upd_J) {
-            const int off = t < N ? t * ncs : N * ncs, cnt = t < N ? ncs : nct;
-#pragma unroll
-            for (int i = 0; i < NCM; ++i)
-                if (i < cnt) { o.lam[i] = lamb[off + i]; o.rho[i] = rho[off + i]; }
-        }
-    };
-    const bool any = upd_J || upd_viol;
-    In cur, nxt;
+    const bool any = upd_J || upd_viol, duals = constrained && upd_J;
+    CostIn<M> cur, nxt;
     int t = any ? I.j : T;
-    if (t < T) load(cur, t);
+    if (t < T) cost_load<M>(I.g, L, Xo, Uo, duals, t, cur);
     for (; t < T; t += 16) {
-        if (t + 16 < T) load(nxt, t + 16);
-        const double (&xt)[n] = cur.x;
-        const double (&w)[cdim<M::NW>::v] = cur.w;
-        if (t < N) {
-            double ut[m];
-#pragma unroll
-            for (int i = 0; i < m; ++i) ut[i] = cur.u[i];
-            if (upd_J) Jp += M::cost_s(xt, ut, w);
-            if constexpr (ncs > 0) {
-                if (constrained) {
-                    double cv[ncs];
-                    M::con_s(xt, ut, w, cv);
-                    const int off = t * ncs;
-                    if (upd_J) {
-                        double dot = 0.0, pen = 0.0;
-#pragma unroll
-                        for (int i = 0; i < ncs; ++i) {
-                            const double lam = cur.lam[i];
-                            const bool ineq = IneqMask<M>::s(i);
-                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
-                            act[off + i] = inactive ? 0.0 : 1.0;
-                            dot += lam * cv[i];
-                            if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
-                        }
-                        Jp += dot;
-                        Jp += pen;
-                    }
-                    if (upd_viol) {
-#pragma unroll
-                        for (int i = 0; i < ncs; ++i) {
-                            cbuf[off + i] = cv[i];
-                            const bool ineq = IneqMask<M>::s(i);
-                            vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
-                        }
-                    }
-                }
-            }
-        } else {
-            if (upd_J) Jp += M::cost_t(xt, w);
-            if constexpr (nct > 0) {
-                if (constrained) {
-                    double cv[nct];
-                    M::con_t(xt, w, cv);
-                    const int off = N * ncs;
-                    if (upd_J) {
-                        double dot = 0.0, pen = 0.0;
-#pragma unroll
-                        for (int i = 0; i < nct; ++i) {
-                            const double lam = cur.lam[i];
-                            const bool ineq = IneqMask<M>::t(i);
-                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
-                            act[off + i] = inactive ? 0.0 : 1.0;
-                            dot += lam * cv[i];
-                            if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
-                        }
-                        Jp += dot;
-                        Jp += pen;
-                    }
-                    if (upd_viol) {
-#pragma unroll
-                        for (int i = 0; i < nct; ++i) {
-                            cbuf[off + i] = cv[i];
-                            const bool ineq = IneqMask<M>::t(i);
-                            vp = nanmax(vp, ineq ? nanmax(0.0, cv[i]) : fabs(cv[i]));
-                        }
-                    }
-                }
-            }
-        }
+        if (t + 16 < T) cost_load<M>(I.g, L, Xo, Uo, duals, t + 16, nxt);
+        cost_eval<M>(I.g, L, cur, t, upd_J, upd_viol, constrained, Jp, vp);
         cur = nxt;
     }
     J_out = row_sum(Jp);
