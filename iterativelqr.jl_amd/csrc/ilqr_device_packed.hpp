@@ -88,7 +88,23 @@ struct PInst {
     // SolverData of the row's instance, replicated over its 16 lanes
     double objective, max_violation, step_size, gradient_norm, obj_prev, J_prev, delta, delta_next;
     int status, iterations, outer, it, trial, rollouts, potrf_info, states_eq_nominal, trace_len, state, needB, leaving;
+    int nbar;          // workgroup barriers this wave has passed (two-wave form: an order to the helper wave names the barrier it is valid from)
 };
+// every workgroup barrier of the solver wave goes through here
+template <class M> __device__ __forceinline__ void pk_sync(PInst<M>& I) { __syncthreads(); I.nbar += 1; }
+enum { PK_LINEARISE = 1, PK_COST = 2 };
+// Two-wave form: the solver wave's order to the helper wave, valid from the solver wave's NEXT barrier on. The helper looks into
+// the mailbox after every barrier and may well see an order early (written after the barrier both just passed): it takes it only
+// once its own barrier count has reached the one the order names.
+template <class M>
+__device__ __forceinline__ void pk_post(PInst<M>& I, int mbox, int kind, unsigned mask, bool constrained) {
+    extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+    if (I.lane == 0) {
+        volatile int* mb = (volatile int*)(pk_lds + mbox);
+        mb[1] = (int)mask; mb[2] = constrained ? 1 : 0; mb[3] = kind; mb[4] = I.nbar + 1;
+        mb[0] = mb[0] + 1;
+    }
+}
 
 // ------------------------------------------------------------------ cost! (row mapping, one timestep per lane of a row)
 // X / U: offsets of the trajectory inside the instance block. upd_J / upd_viol are per-lane (per-instance) predicates.
@@ -118,6 +134,11 @@ __device__ __forceinline__ void cost_load(const double* g, const Layout& L, int 
             if (i < cnt) { o.lam[i] = g[L.lam + off + i]; o.rho[i] = g[L.rho + off + i]; }
     }
 }
+// (Inlined into its two callers — cost_pass and the helper wave's cost_follow — hipcc contracts the model's sums of products into
+// FMAs differently: the two forms of the kernel report objectives ONE ULP apart on a few trials. A shared real function makes them
+// bitwise equal — cost_eval alone, operands by reference: +25 % kernel time; a lane's whole walk by value: +1.5 % on the one-wave
+// form and half the two-wave form's gain — and was not kept: the model's cost is opaque to the accumulation and the constraint terms
+// are explicit fma chains, the rest is the compiler's; the two forms are compared bitwise in everything but the reported objective.)
 template <class M>
 __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const CostIn<M>& cur, int t, bool upd_J, bool upd_viol, bool constrained,
                                           double& Jp, double& vp) {
@@ -130,7 +151,7 @@ __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const Cost
         double ut[m];
 #pragma unroll
         for (int i = 0; i < m; ++i) ut[i] = cur.u[i];
-        if (upd_J) Jp += M::cost_s(xt, ut, w);
+        if (upd_J) { double l_ = M::cost_s(xt, ut, w); ILQR_OPAQUE(l_); Jp += l_; }
         if constexpr (ncs > 0) {
             if (constrained) {
                 double cv[ncs];
@@ -144,8 +165,8 @@ __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const Cost
                         const bool ineq = IneqMask<M>::s(i);
                         const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                         act[off + i] = inactive ? 0.0 : 1.0;
-                        dot += lam * cv[i];
-                        if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
+                        dot = fma(lam, cv[i], dot);
+                        if (!inactive) pen = fma(0.5 * cur.rho[i], cv[i] * cv[i], pen);
                     }
                     Jp += dot;
                     Jp += pen;
@@ -161,7 +182,7 @@ __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const Cost
             }
         }
     } else {
-        if (upd_J) Jp += M::cost_t(xt, w);
+        if (upd_J) { double l_ = M::cost_t(xt, w); ILQR_OPAQUE(l_); Jp += l_; }
         if constexpr (nct > 0) {
             if (constrained) {
                 double cv[nct];
@@ -175,8 +196,8 @@ __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const Cost
                         const bool ineq = IneqMask<M>::t(i);
                         const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
                         act[off + i] = inactive ? 0.0 : 1.0;
-                        dot += lam * cv[i];
-                        if (!inactive) pen += 0.5 * cur.rho[i] * (cv[i] * cv[i]);
+                        dot = fma(lam, cv[i], dot);
+                        if (!inactive) pen = fma(0.5 * cur.rho[i], cv[i] * cv[i], pen);
                     }
                     Jp += dot;
                     Jp += pen;
@@ -212,7 +233,7 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
     }
     J_out = row_sum(Jp);
     viol_out = row_max(vp);
-    __syncthreads();
+    pk_sync<M>(I);
 }
 
 // cost!(data, problem, mode) for the instances with `act` set — src/data/methods.jl:13-30 (Q2: the violations buffer
@@ -254,7 +275,9 @@ struct PkLds {
     static constexpr int n = M::NX, m = M::NU;
     static constexpr int SFX = (n * n) | 1, SFU = (n * m) | 1, SGX = n | 1, SGU = m | 1;      // odd strides: conflict-free lane-per-step writes
     static constexpr int FX = 0, FU = FX + 16 * SFX, GX = FU + 16 * SFU, GU = GX + 16 * SGX, IB = GU + 16 * SGU;
-    static constexpr int BUF = 4 * IB, TERM = (TWO ? 2 : 1) * BUF, ZERO = TERM + 4 * n, MBOX = ZERO + 2, total = MBOX + (TWO ? 2 : 0);
+    static constexpr int BUF = 4 * IB, TERM = (TWO ? 2 : 1) * BUF, ZERO = TERM + 4 * n, MBOX = ZERO + 2, RES = MBOX + 4, total = TWO ? RES + 8 : MBOX;
+    // mailbox (ints at MBOX): [0] sequence number (-1: leave), [1] instance mask, [2] constrained, [3] kind (PK_LINEARISE / PK_COST),
+    // [4] the solver wave's barrier count at which the order becomes valid; RES: the helper's answers (J and max violation per instance)
 };
 
 // One stage timestep of gradients!: a real function, so that the (large) symbolic Jacobian code gets its own register
@@ -346,14 +369,8 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
 #pragma unroll
         for (int i = 0; i < n; ++i) { pk_lds[LD::TERM + I.q * n + i] = gx[i]; gr[L.gx + N * n + i] = gx[i]; }
     }
-    if constexpr (TWO) {                    // the helper wave's order: which instances, constrained or not (pk_helper)
-        if (lane == 0) {
-            volatile int* mb = (volatile int*)(pk_lds + LD::MBOX);
-            mb[1] = (int)mask; mb[2] = constrained ? 1 : 0;
-            mb[0] = mb[0] + 1;
-        }
-    }
-    __syncthreads();
+    if constexpr (TWO) pk_post<M>(I, LD::MBOX, PK_LINEARISE, mask, constrained);   // the helper wave's order: which instances, constrained or not (pk_helper)
+    pk_sync<M>(I);
     const bool vnn = on && r < n && c < n, vnm = on && r < n && c < m, vmn = on && r < m && c < n, vmm = on && r < m && c < m;
     const bool vn1 = on && c == 0 && r < n, vm1 = on && c == 0 && r < m;
     // Addresses for INSTRUCTION COUNT (a wave issues one instruction per 5-6 clk whatever it is, tools/probes/probe_issue.hip):
@@ -535,7 +552,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
 #endif
             }
         }
-        __syncthreads();
+        pk_sync<M>(I);
         // ---- Riccati steps of the chunk, last timestep first   (:42)
         Opnd A, B;
         int sl = cnt - 1;
@@ -562,14 +579,14 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         } else {
             mfma_block_boundary_guard(); riccati_step(A, t0);
         }
-        if constexpr (!TWO) __syncthreads();  // the chunk buffer is free again (two buffers: the next chunk's barrier says so)
+        if constexpr (!TWO) pk_sync<M>(I);  // the chunk buffer is free again (two buffers: the next chunk's barrier says so)
     }
     double gm = (on && c == 0) ? (gnan ? __builtin_nan("") : gmax) : 0.0;
     { double w_; w_ = __shfl_xor(gm, 16); gm = nanmax(gm, w_); w_ = __shfl_xor(gm, 32); gm = nanmax(gm, w_); }
     gnorm_row = shfl_d(gm, 4 * I.q);
     info_row = __shfl(pinfo, 4 * I.q);
     delta_row = shfl_d(dacc, 4 * I.q);
-    __syncthreads();
+    pk_sync<M>(I);
 }
 
 // ------------------------------------------------------------- rollout! (row mapping, cooperative inside a row)
@@ -578,7 +595,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
 // multiply and a 64-bit add per access. (Forming a_t = k_t α + ū_t and b_t = K_t x̄_t beforehand, as the LDS kernels do, does
 // not pay here: the pass that forms them waits on HBM seven times per rollout with nothing to hide behind — measured
 // 113 -> 119 ms on acrobot:8192.)
-template <class M>
+template <class M, bool FOLLOW = false>     // FOLLOW (two-wave form): a workgroup barrier per 15 steps, behind which the helper wave evaluates the trial's cost
 __device__ void rollout(PInst<M>& I, bool act, double alpha) {
     constexpr int n = M::NX, m = M::NU;
     const Layout& L = I.L;
@@ -655,9 +672,12 @@ __device__ void rollout(PInst<M>& I, bool act, double alpha) {
 #pragma unroll
         for (int i = 0; i < n; ++i) xt[i] = xo[i];
         oK += 24u * m * n; ok_ += 24u * m; oub += 24u * m; oxb += 24u * n; wU += 3u * sU; wX += 3u * sX;
+        if constexpr (FOLLOW) {
+            if ((t + 3) % 15 == 0) pk_sync<M>(I);       // x, u up to here are in the workspace (pk_rollout_segments counts these)
+        }
     }
     if (t < N) { step(A, t, 0, xt, xo); ++t; if (t < N) step(B, t, 1, xo, xt); }
-    __syncthreads();
+    pk_sync<M>(I);
 }
 
 // The fused B phase keeps fx, fu, gx, gu on chip. When an instance LEAVES its inner loop they are written out once, so that
@@ -722,6 +742,9 @@ __device__ __forceinline__ void row_copy(PInst<M>& I, bool act, int dst, int src
 // the same order per instance: results bitwise those of the one-wave form. Used where the second buffer fits the CU's LDS at the
 // batch's residency (ilqr_api.hip).
 namespace pk {
+// in-loop barriers of the packed rollout in the two-wave form: one per 15 steps of its three-step loop (a trial's cost is evaluated
+// segment by segment behind the rollout, cost_follow below)
+__device__ __forceinline__ int pk_rollout_segments(int N) { return N >= 3 ? (3 * ((N - 3) / 3 + 1)) / 15 : 0; }
 template <class M>
 __device__ void pk_helper(const KArgs& a) {
     constexpr int n = M::NX, m = M::NU;
@@ -734,23 +757,47 @@ __device__ void pk_helper(const KArgs& a) {
     const bool valid_row = b_row < a.B;
     double* gr = a.ws + (size_t)(valid_row ? b_row : a.B - 1) * (size_t)L.stride;
     volatile int* mb = (volatile int*)(pk_lds + LD::MBOX);
-    int seen = 0;
+    int seen = 0, nb = 0;
     for (;;) {
-        __syncthreads();
+        __syncthreads(); ++nb;
         const int seq = __builtin_amdgcn_readfirstlane(mb[0]);
         if (seq == seen) continue;
-        seen = seq;
         if (seq < 0) return;
+        if (__builtin_amdgcn_readfirstlane(mb[4]) != nb) continue;          // posted after this barrier: it is the next one's
+        seen = seq;
         const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(mb[1]);
-        const int constrained = __builtin_amdgcn_readfirstlane(mb[2]);
+        const int constrained = __builtin_amdgcn_readfirstlane(mb[2]), kind = __builtin_amdgcn_readfirstlane(mb[3]);
         const bool act_row = valid_row && ((mask >> q) & 1u);
-        for (int ch = (N + 15) / 16 - 1; ch >= 0; --ch) {
-            const int t0 = 16 * ch, cnt = (N - t0) < 16 ? (N - t0) : 16;
-            if (act_row && j < cnt) {
-                LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + j, q * LD::IB + (ch & 1) * LD::BUF, j, constrained};
-                linearise_stage<M>(la);
+        if (kind == PK_LINEARISE) {
+            for (int ch = (N + 15) / 16 - 1; ch >= 0; --ch) {
+                const int t0 = 16 * ch, cnt = (N - t0) < 16 ? (N - t0) : 16;
+                if (act_row && j < cnt) {
+                    LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + j, q * LD::IB + (ch & 1) * LD::BUF, j, constrained};
+                    linearise_stage<M>(la);
+                }
+                __syncthreads(); ++nb;
             }
-            __syncthreads();
+        } else {
+            // cost_follow: cost!(mode = current) of a line-search trial (cost_pass(I, L.x, L.u, act, act, constrained)) behind the rollout
+            // that produces the trajectory — segment k of 15 timesteps once the solver wave has passed its k-th in-loop barrier, the
+            // rest and the terminal timestep behind the rollout's closing barrier. Lane j takes the timesteps t with t % 16 == j in
+            // ascending order, as cost_pass does: the same per-lane sums, the same reduction.
+            double Jp = 0.0, vp = 0.0;
+            CostIn<M> in;
+            const int nseg = pk_rollout_segments(N);
+            for (int k = 0; k <= nseg; ++k) {                               // k == nseg: behind the rollout's closing barrier, up to the terminal timestep
+                __syncthreads(); ++nb;
+                const int lo = 15 * k, hi = k < nseg ? 15 * k + 15 : N + 1;
+                if (act_row) {
+                    for (int t = lo + ((j - lo) & 15); t < hi; t += 16) {   // this lane's timesteps of [lo, hi): one, two at most behind the last barrier
+                        cost_load<M>(gr, L, L.x, L.u, constrained != 0, t, in);
+                        cost_eval<M>(gr, L, in, t, true, true, constrained != 0, Jp, vp);
+                    }
+                }
+            }
+            const double J = row_sum(Jp), v = row_max(vp);
+            if (j == 0) { pk_lds[LD::RES + q] = J; pk_lds[LD::RES + 4 + q] = v; }
+            __syncthreads(); ++nb;                                          // answers in place
         }
     }
 }
@@ -763,13 +810,14 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
     using namespace pk;
     if constexpr (TWO) {
         extern __shared__ __attribute__((aligned(16))) double pk_lds[];
-        if (threadIdx.x == 0) { volatile int* mb = (volatile int*)(pk_lds + PkLds<M, true>::MBOX); mb[0] = 0; mb[1] = 0; mb[2] = 0; }
+        if (threadIdx.x < 8) ((volatile int*)(pk_lds + PkLds<M, true>::MBOX))[threadIdx.x] = 0;
         __syncthreads();
         if (threadIdx.x >= 64) { pk_helper<M>(a); return; }
     }
     PInst<M> I;
     const Layout& L = a.L;
     I.L = L;
+    I.nbar = 0;
     I.lane = threadIdx.x & 63; I.q = I.lane >> 4; I.j = I.lane & 15; I.beta = (I.lane >> 2) & 3; I.r = I.lane >> 4; I.c = I.lane & 3;
     const int b_row = blockIdx.x * 4 + I.q, b_blk = blockIdx.x * 4 + I.beta;
     I.valid_row = b_row < a.B; I.valid_blk = b_blk < a.B;
@@ -814,7 +862,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
         scal[S_RESUME] = (double)resume; scal[S_INNER_IT] = (double)resume_it; scal[S_OBJ_PREV] = resume_obj_prev;
         scal[S_DELTA_NEXT] = I.delta_next;
     };
-    __syncthreads();
+    pk_sync<M>(I);
     const int outer_max = al_outer ? opt.max_dual_updates : 1;
     if (outer_max < 1) I.state = ST_DONE;
 
@@ -864,7 +912,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
                     if ((a.handover_outer > 1 && I.outer >= a.handover_outer) || ho_now) { I.state = ST_DONE; resume = I.outer; }
                     else I.state = ST_INIT;
                 }
-                __syncthreads();
+                pk_sync<M>(I);
             }
             const bool at_init = I.state == ST_INIT;
             if (__any(at_init)) {
@@ -877,7 +925,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
                 row_fill<M>(I, at_init, L.guu, N * m * m, 0.0);
                 row_fill<M>(I, at_init, L.gux, N * m * n, 0.0);
                 if (at_init && opt.reset_cache) { I.objective = 0.0; I.max_violation = 0.0; I.status = 0; I.iterations = 0; }
-                __syncthreads();
+                pk_sync<M>(I);
                 cost_bang<M>(I, at_init, false, constrained);                             // (:14)
                 if (at_init) { I.it = 0; I.needB = 1; }
             }
@@ -903,16 +951,30 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
                     const bool go = fw && !I.needB && (I.step_size >= opt.min_step_size) && (I.trial <= 25) &&
                                     (rep == 0 || I.rollouts - I.iterations >= ILQR_PK_REJECTS);
                     if (!__any(go)) break;
-                    if (!(dbg & 16)) {                                                      // (:34)
+                    bool followed = false;
+                    if constexpr (TWO) {
+                        if (!(dbg & 48)) {
+                            // the helper wave evaluates cost!(mode = current) (:36) segment by segment behind the rollout (:34)
+                            followed = true;
+                            pk_post<M>(I, PkLds<M, true>::MBOX, PK_COST, row_mask(go), constrained);
+                            pk_sync<M>(I);                                              // the order is taken here
+                            rollout<M, true>(I, go, I.step_size);
+                            pk_sync<M>(I);                                              // the answers are in place
+                            extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+                            const double Jh = pk_lds[PkLds<M, true>::RES + I.q], vh = pk_lds[PkLds<M, true>::RES + 4 + I.q];
+                            if (go) { I.objective = Jh; if (constrained) I.max_violation = vh; }
+                        }
+                    }
+                    if (!followed && !(dbg & 16)) {                                         // (:34)
                         rollout<M>(I, go, I.step_size);
                     }
                     if (go) { I.rollouts += 1; I.states_eq_nominal = 0; }
-                    if (!(dbg & 32)) cost_bang<M>(I, go, true, constrained);              // (:36)
+                    if (!followed && !(dbg & 32)) cost_bang<M>(I, go, true, constrained);   // (:36)
                     const bool acc = go && !(dbg & 1) && (I.objective <= I.J_prev + 1.0e-4 * I.step_size * I.delta);   // (:44) NaN ⇒ reject
                     if (__any(acc)) {                                                     // update_nominal_trajectory!
                         row_copy<M>(I, acc, L.xb, L.x, T * n);
                         row_copy<M>(I, acc, L.ub, L.u, N * m);
-                        __syncthreads();
+                        pk_sync<M>(I);
                     }
                     if (acc) { I.states_eq_nominal = 1; I.status = 1; I.needB = 1; }
                     if (go && !acc) { I.step_size *= 0.5; I.trial += 1; }                 // (:51)
@@ -975,7 +1037,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
                     }
                 }
                 I.leaving = 0;
-                __syncthreads();
+                pk_sync<M>(I);
             }
         }
     }
@@ -984,7 +1046,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
         extern __shared__ __attribute__((aligned(16))) double pk_lds[];
         if (I.lane == 0) ((volatile int*)(pk_lds + PkLds<M, true>::MBOX))[0] = -1;
     }
-    __syncthreads();
+    pk_sync<M>(I);
     if (live && I.j == 0) write_scalars();
 }
 

@@ -803,13 +803,19 @@ def test_packed_kernel_with_a_linearisation_server_equals_the_one_wave_form(pkg,
     for key in (("packed2", 0), ("packed2", -1)):
         b = out[key]
         for f in a:
-            if key[1] == -1 and f == "tr":
-                continue            # (the objective REPORTED in a trace row by an instance that changed kernels is summed in that kernel's order)
             if key[1] == -1 and config == "car_obs":
                 # the two-wave latency kernel that finishes handed-over instances is not bitwise the packed kernel on THIS model (a few
                 # instances 5e-14 apart in x, control flow identical; one-wave and two-wave packed forms agree with each other under
                 # hand-over too): compared to rounding here
                 assert np.allclose(a[f], b[f], rtol=1e-9, atol=1e-11, equal_nan=True), (key, f)
+                continue
+            if f == "tr":
+                # the objective REPORTED in a trace row: the helper wave's cost code is the one-wave form's source inlined in another
+                # place, and hipcc contracts the model's sums of products differently there (one ulp on a few trials); an instance that
+                # changed kernels reports the latency kernel's summation order. Everything the solve computes WITH is compared bitwise.
+                cols = [c for c in range(a[f].shape[-1]) if c != 2]
+                assert np.array_equal(a[f][..., cols], b[f][..., cols], equal_nan=True), (key, f)
+                assert np.allclose(a[f][..., 2], b[f][..., 2], rtol=4e-16, atol=0.0, equal_nan=True), (key, f, "objective")
                 continue
             assert np.array_equal(a[f], b[f], equal_nan=True), (key, f)
     ref = oracle.solve_batch(model, T, x1, ub, nthreads=8, w=w)
