@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_IN
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/mfma -o r1 -- python3 $SHORT > $OUT/mfma.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/tcc -o r1 -- python3 $SHORT > $OUT/tcc.log 2>&1
 DB() { find $OUT/$1 -name "*results.db" | head -1; }
-( echo "# $TAG: python3 $ARGS   (commit $(cat $GRAFT_REPO_ROOT/.commit_id 2>/dev/null))"
+( echo "# $TAG: python3 $ARGS   (tree $(cat $GRAFT_REPO_ROOT/.tree_id 2>/dev/null || echo unstamped: run through tools/grun))"
   python3 tools/rocprof_summary.py $(DB kt) $(DB fetch) $(DB write) $(DB sq) $(DB mfma) $(DB tcc)
   echo; echo "# bench line under the kernel-trace pass"; grep "^{\"metric\"" $OUT/kt.log | tail -1 ) > $OUT/summary.txt 2>&1
 rm -rf $OUT/kt $OUT/fetch $OUT/write $OUT/sq $OUT/mfma $OUT/tcc
