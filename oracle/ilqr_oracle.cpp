@@ -20,7 +20,13 @@ static inline double jl_max(double a, double b) { return (a != a || b != b) ? st
 static inline double jl_min(double a, double b) { return (a != a || b != b) ? std::numeric_limits<double>::quiet_NaN() : (a < b ? a : b); }
 
 struct OrcSolver {
-    int T, n, m, nw;
+    int T, n, m, nw;                                // n, m: the LARGEST num_state / num_action of the horizon
+    // per-timestep dimensions (src/dynamics.jl:5-7: num_next_state may differ from num_state; every buffer of
+    // src/data/{model,objective,policy,problem,solver}.jl is sized per timestep) and the offsets of block t in the flat arrays:
+    // xo — x_t in states / gx / p / Qx and in `gradient` / `trajectory` (data.indices_state, src/data/solver.jl:23-35);
+    // uo — u_t in actions / gu / k / Qu (data.indices_action = X + uo); fxo, fuo — jacobian_state[t] (nx[t+1] x nx[t]),
+    // jacobian_action[t] (nx[t+1] x nu[t]); xxo — nx[t] x nx[t] blocks (gxx, P, Qxx); uuo — nu[t] x nu[t]; uxo — nu[t] x nx[t] (gux, K, Qux)
+    std::vector<int> nx, nu, xo, uo, fxo, fuo, xxo, uuo, uxo;
     bool constrained;
     std::vector<const OrcDynamics*> dynamics;     // T-1
     std::vector<const OrcCost*> costs;            // T
@@ -85,52 +91,71 @@ extern "C" OrcSolver* orc_solver_create(int T, const OrcDynamics* const* dynamic
                                         const double* w, const OrcOptions* opts) {
     OrcSolver* s = new OrcSolver();
     s->T = T;
-    s->n = dynamics[0]->num_state;
-    s->m = dynamics[0]->num_action;
     s->nw = dynamics[0]->num_parameter;
-    const int n = s->n, m = s->m, N = T - 1;
+    const int N = T - 1;
+    // dimensions along the horizon — src/data/problem.jl:32-38: states[t] has dynamics[t].num_state entries, the last one
+    // dynamics[end].num_next_state; the chain must be consistent (x[t+1] .= dynamics!(d, ...) would throw otherwise, src/rollout.jl:29)
+    s->nx.assign(T, 0); s->nu.assign(N, 0);
     for (int t = 0; t < N; ++t) {
-        if (dynamics[t]->num_state != n || dynamics[t]->num_next_state != n || dynamics[t]->num_action != m) {
-            delete s; return nullptr;   // uniform dimensions only (see header)
-        }
+        s->nx[t] = dynamics[t]->num_state; s->nu[t] = dynamics[t]->num_action;
+        if (t + 1 < N && dynamics[t]->num_next_state != dynamics[t + 1]->num_state) { delete s; return nullptr; }
+        if (costs[t]->num_state != s->nx[t] || costs[t]->num_action != s->nu[t]) { delete s; return nullptr; }
         s->dynamics.push_back(dynamics[t]);
     }
+    s->nx[N] = dynamics[N - 1]->num_next_state;
+    if (costs[N]->num_state != s->nx[N]) { delete s; return nullptr; }
+    s->n = 0; s->m = 0;
+    for (int t = 0; t < T; ++t) if (s->nx[t] > s->n) s->n = s->nx[t];
+    for (int t = 0; t < N; ++t) if (s->nu[t] > s->m) s->m = s->nu[t];
+    s->xo.assign(T + 1, 0); s->uo.assign(N + 1, 0); s->fxo.assign(N + 1, 0); s->fuo.assign(N + 1, 0);
+    s->xxo.assign(T + 1, 0); s->uuo.assign(N + 1, 0); s->uxo.assign(N + 1, 0);
+    for (int t = 0; t < T; ++t) { s->xo[t + 1] = s->xo[t] + s->nx[t]; s->xxo[t + 1] = s->xxo[t] + s->nx[t] * s->nx[t]; }
+    for (int t = 0; t < N; ++t) {
+        s->uo[t + 1] = s->uo[t] + s->nu[t];
+        s->fxo[t + 1] = s->fxo[t] + s->nx[t + 1] * s->nx[t];
+        s->fuo[t + 1] = s->fuo[t] + s->nx[t + 1] * s->nu[t];
+        s->uuo[t + 1] = s->uuo[t] + s->nu[t] * s->nu[t];
+        s->uxo[t + 1] = s->uxo[t] + s->nu[t] * s->nx[t];
+    }
+    const int n = s->n, m = s->m, X = s->xo[T], U = s->uo[N];
     for (int t = 0; t < T; ++t) s->costs.push_back(costs[t]);
     s->constrained = constraints != nullptr;
     if (s->constrained) for (int t = 0; t < T; ++t) s->cons.push_back(constraints[t]);
     if (opts) s->opt = *opts; else orc_default_options(&s->opt);
 
     // src/data/problem.jl:32-43 — everything zero-initialised
-    s->states.assign(T * n, 0.0); s->actions.assign(N * m, 0.0);
-    s->nominal_states.assign(T * n, 0.0); s->nominal_actions.assign(N * m, 0.0);
+    s->states.assign(X, 0.0); s->actions.assign(U, 0.0);
+    s->nominal_states.assign(X, 0.0); s->nominal_actions.assign(U, 0.0);
     s->parameters.assign(T * (s->nw > 0 ? s->nw : 0) + 1, 0.0);
     if (w && s->nw > 0) std::memcpy(s->parameters.data(), w, sizeof(double) * T * s->nw);
-    s->trajectory.assign(T * n + N * m, 0.0);
-    s->fx.assign(N * n * n, 0.0); s->fu.assign(N * n * m, 0.0);
-    s->gx.assign(T * n, 0.0); s->gu.assign(N * m, 0.0);
-    s->gxx.assign(T * n * n, 0.0); s->guu.assign(N * m * m, 0.0); s->gux.assign(N * m * n, 0.0);
+    s->trajectory.assign(X + U, 0.0);                                   // num_trajectory, src/dynamics.jl:52
+    // src/data/model.jl:11-16, src/data/objective.jl:12-19
+    s->fx.assign(s->fxo[N], 0.0); s->fu.assign(s->fuo[N], 0.0);
+    s->gx.assign(X, 0.0); s->gu.assign(U, 0.0);
+    s->gxx.assign(s->xxo[T], 0.0); s->guu.assign(s->uuo[N], 0.0); s->gux.assign(s->uxo[N], 0.0);
     // src/data/policy.jl:44-78
-    s->K.assign(N * m * n, 0.0); s->k.assign(N * m, 0.0);
-    s->P.assign(T * n * n, 0.0); s->p.assign(T * n, 0.0);
-    s->Qx.assign(N * n, 0.0); s->Qu.assign(N * m, 0.0);
-    s->Qxx.assign(N * n * n, 0.0); s->Quu.assign(N * m * m, 0.0); s->Qux.assign(N * m * n, 0.0);
-    s->xx_tmp.assign(n * n, 0.0); s->ux_hat_tmp.assign(m * n, 0.0);
+    s->K.assign(s->uxo[N], 0.0); s->k.assign(U, 0.0);
+    s->P.assign(s->xxo[T], 0.0); s->p.assign(X, 0.0);
+    s->Qx.assign(s->xo[N], 0.0); s->Qu.assign(U, 0.0);
+    s->Qxx.assign(s->xxo[N], 0.0); s->Quu.assign(s->uuo[N], 0.0); s->Qux.assign(s->uxo[N], 0.0);
+    s->xx_tmp.assign(n * n, 0.0); s->ux_hat_tmp.assign(m * n, 0.0);    // (one buffer of the largest block each; the reference keeps one per t)
     s->uu_tmp.assign(m * m, 0.0); s->ux_tmp.assign(m * n, 0.0);
     // src/data/solver.jl:37-46
     s->objective = std::numeric_limits<double>::infinity();
     s->max_violation = 0.0; s->step_size = 1.0;
-    s->gradient.assign(T * n + N * m, 0.0);
+    s->gradient.assign(X + U, 0.0);
     s->status = false; s->iterations = 0;
-    // src/augmented_lagrangian.jl:13-37 — ρ=1, λ=0, a=1
+    // src/augmented_lagrangian.jl:13-37 — ρ=1, λ=0, a=1; src/data/constraints.jl:11-17 — cx[t] is nc x nx[t], cu[t] nc x nu[t]
     s->coff.assign(T + 1, 0); s->cxoff.assign(T + 1, 0); s->cuoff.assign(T + 1, 0);
     int maxnc = 0;
     for (int t = 0; t < T; ++t) {
         int nc = nc_at(s, t);
         if (nc > ORC_MAX_NC) { delete s; return nullptr; }
+        if (nc > 0 && (s->cons[t]->num_state != s->nx[t] || (t < N && s->cons[t]->num_action != s->nu[t]))) { delete s; return nullptr; }
         if (nc > maxnc) maxnc = nc;
         s->coff[t + 1] = s->coff[t] + nc;
-        s->cxoff[t + 1] = s->cxoff[t] + nc * n;
-        s->cuoff[t + 1] = s->cuoff[t] + (t < N ? nc * m : 0);
+        s->cxoff[t + 1] = s->cxoff[t] + nc * s->nx[t];
+        s->cuoff[t + 1] = s->cuoff[t] + (t < N ? nc * s->nu[t] : 0);
     }
     int C = s->coff[T];
     s->violations.assign(C + 1, 0.0); s->rho.assign(C + 1, 1.0); s->lambda.assign(C + 1, 0.0);
@@ -150,21 +175,24 @@ extern "C" void orc_solver_destroy(OrcSolver* s) { delete s; }
 
 extern "C" void orc_initialize_controls(OrcSolver* s, const double* u) {
     // src/solver.jl:56-60 — writes the NOMINAL buffer only
-    std::memcpy(s->nominal_actions.data(), u, sizeof(double) * (s->T - 1) * s->m);
+    std::memcpy(s->nominal_actions.data(), u, sizeof(double) * s->uo[s->T - 1]);
 }
 extern "C" void orc_initialize_states(OrcSolver* s, const double* x) {
     // src/solver.jl:62-66
-    std::memcpy(s->nominal_states.data(), x, sizeof(double) * s->T * s->n);
+    std::memcpy(s->nominal_states.data(), x, sizeof(double) * s->xo[s->T]);
 }
 
 extern "C" void orc_rollout(int T, const OrcDynamics* const* dynamics, const double* x1,
                             const double* u, const double* w, double* x_out) {
     // src/rollout.jl:33-42 — open-loop rollout
-    const int n = dynamics[0]->num_state, m = dynamics[0]->num_action, nw = dynamics[0]->num_parameter;
-    std::memcpy(x_out, x1, sizeof(double) * n);
+    // x and u are the ragged concatenations [x_1 | x_2 | ...], [u_1 | u_2 | ...] when the dimensions vary along the horizon
+    const int nw = dynamics[0]->num_parameter;
+    std::memcpy(x_out, x1, sizeof(double) * dynamics[0]->num_state);
+    int xo = 0, uo = 0;
     for (int t = 0; t < T - 1; ++t) {
         const OrcDynamics* d = dynamics[t];
-        d->evaluate(x_out + (t + 1) * n, x_out + t * n, u + t * m, w ? w + t * nw : nullptr, d->ctx);
+        d->evaluate(x_out + xo + d->num_state, x_out + xo, u + uo, w ? w + t * nw : nullptr, d->ctx);
+        xo += d->num_state; uo += d->num_action;
     }
 }
 
@@ -172,11 +200,11 @@ extern "C" void orc_rollout(int T, const OrcDynamics* const* dynamics, const dou
 // src/costs.jl:48-55
 static double cost_objective(OrcSolver* s, const double* x, const double* u) {
     double J = 0.0;
-    const int n = s->n, m = s->m, nw = s->nw, T = s->T;
+    const int nw = s->nw, T = s->T;
     for (int t = 0; t < T; ++t) {
         double out = 0.0;
         const OrcCost* c = s->costs[t];
-        c->evaluate(&out, x + t * n, t < T - 1 ? u + t * m : nullptr, s->parameters.data() + t * nw, c->ctx);
+        c->evaluate(&out, x + s->xo[t], t < T - 1 ? u + s->uo[t] : nullptr, s->parameters.data() + t * nw, c->ctx);
         J += out;
     }
     return J;
@@ -184,13 +212,13 @@ static double cost_objective(OrcSolver* s, const double* x, const double* u) {
 
 // src/constraints.jl:66-73
 static void constraint_bang(OrcSolver* s, const double* x, const double* u) {
-    const int n = s->n, m = s->m, nw = s->nw, T = s->T;
+    const int nw = s->nw, T = s->T;
     for (int t = 0; t < T; ++t) {
         const OrcConstraint* con = s->cons[t];
         if (con->num_constraint == 0) continue;
         double* cache = s->cache.data();
         for (int i = 0; i < con->num_constraint; ++i) cache[i] = 0.0;
-        con->evaluate(cache, x + t * n, t < T - 1 ? u + t * m : nullptr, s->parameters.data() + t * nw, con->ctx);
+        con->evaluate(cache, x + s->xo[t], t < T - 1 ? u + s->uo[t] : nullptr, s->parameters.data() + t * nw, con->ctx);
         for (int i = 0; i < con->num_constraint; ++i) s->violations[s->coff[t] + i] = cache[i];
     }
 }
@@ -259,50 +287,53 @@ extern "C" double orc_cost_bang(OrcSolver* s, int mode_current) {
 
 // ------------------------------------------------------------- gradients.jl
 extern "C" void orc_gradients(OrcSolver* s) {
-    const int n = s->n, m = s->m, nw = s->nw, T = s->T, N = T - 1;
+    const int nw = s->nw, T = s->T, N = T - 1;
     const double* x = s->nominal_states.data();
     const double* u = s->nominal_actions.data();
     double* cache = s->cache.data();
-    // gradients!(dynamics) — src/gradients.jl:1-8 → src/dynamics.jl:41-50 (`.=`)
+    // gradients!(dynamics) — src/gradients.jl:1-8 → src/dynamics.jl:41-50 (`.=`); jacobian_state[t] is num_next_state x num_state
     for (int t = 0; t < N; ++t) {
         const OrcDynamics* d = s->dynamics[t];
+        const int n0 = s->nx[t], m0 = s->nu[t], n1 = s->nx[t + 1];
         const double* w = s->parameters.data() + t * nw;
-        for (int i = 0; i < n * n; ++i) cache[i] = 0.0;
-        d->jacobian_state(cache, x + t * n, u + t * m, w, d->ctx);
-        std::memcpy(&s->fx[t * n * n], cache, sizeof(double) * n * n);
-        for (int i = 0; i < n * m; ++i) cache[i] = 0.0;
-        d->jacobian_action(cache, x + t * n, u + t * m, w, d->ctx);
-        std::memcpy(&s->fu[t * n * m], cache, sizeof(double) * n * m);
+        for (int i = 0; i < n1 * n0; ++i) cache[i] = 0.0;
+        d->jacobian_state(cache, x + s->xo[t], u + s->uo[t], w, d->ctx);
+        std::memcpy(&s->fx[s->fxo[t]], cache, sizeof(double) * n1 * n0);
+        for (int i = 0; i < n1 * m0; ++i) cache[i] = 0.0;
+        d->jacobian_action(cache, x + s->xo[t], u + s->uo[t], w, d->ctx);
+        std::memcpy(&s->fu[s->fuo[t]], cache, sizeof(double) * n1 * m0);
     }
     // gradients!(objective) — src/gradients.jl:10-21
     // cost_gradient! — src/costs.jl:57-68 (`.=`)
     for (int t = 0; t < T; ++t) {
         const OrcCost* c = s->costs[t];
+        const int n0 = s->nx[t], m0 = t < N ? s->nu[t] : 0;
         const double* w = s->parameters.data() + t * nw;
-        const double* ut = t < N ? u + t * m : nullptr;
-        for (int i = 0; i < n; ++i) cache[i] = 0.0;
-        c->gradient_state(cache, x + t * n, ut, w, c->ctx);
-        for (int i = 0; i < n; ++i) s->gx[t * n + i] = cache[i];
+        const double* ut = t < N ? u + s->uo[t] : nullptr;
+        for (int i = 0; i < n0; ++i) cache[i] = 0.0;
+        c->gradient_state(cache, x + s->xo[t], ut, w, c->ctx);
+        for (int i = 0; i < n0; ++i) s->gx[s->xo[t] + i] = cache[i];
         if (t == N) continue;
-        for (int i = 0; i < m; ++i) cache[i] = 0.0;
-        c->gradient_action(cache, x + t * n, ut, w, c->ctx);
-        for (int i = 0; i < m; ++i) s->gu[t * m + i] = cache[i];
+        for (int i = 0; i < m0; ++i) cache[i] = 0.0;
+        c->gradient_action(cache, x + s->xo[t], ut, w, c->ctx);
+        for (int i = 0; i < m0; ++i) s->gu[s->uo[t] + i] = cache[i];
     }
     // cost_hessian! — src/costs.jl:70-84 (`.+=` : ACCUMULATES, Appendix A Q1)
     for (int t = 0; t < T; ++t) {
         const OrcCost* c = s->costs[t];
+        const int n0 = s->nx[t], m0 = t < N ? s->nu[t] : 0;
         const double* w = s->parameters.data() + t * nw;
-        const double* ut = t < N ? u + t * m : nullptr;
-        for (int i = 0; i < n * n; ++i) cache[i] = 0.0;
-        c->hessian_state_state(cache, x + t * n, ut, w, c->ctx);
-        for (int i = 0; i < n * n; ++i) s->gxx[t * n * n + i] += cache[i];
+        const double* ut = t < N ? u + s->uo[t] : nullptr;
+        for (int i = 0; i < n0 * n0; ++i) cache[i] = 0.0;
+        c->hessian_state_state(cache, x + s->xo[t], ut, w, c->ctx);
+        for (int i = 0; i < n0 * n0; ++i) s->gxx[s->xxo[t] + i] += cache[i];
         if (t == N) continue;
-        for (int i = 0; i < m * m; ++i) cache[i] = 0.0;
-        c->hessian_action_action(cache, x + t * n, ut, w, c->ctx);
-        for (int i = 0; i < m * m; ++i) s->guu[t * m * m + i] += cache[i];
-        for (int i = 0; i < m * n; ++i) cache[i] = 0.0;
-        c->hessian_action_state(cache, x + t * n, ut, w, c->ctx);
-        for (int i = 0; i < m * n; ++i) s->gux[t * m * n + i] += cache[i];
+        for (int i = 0; i < m0 * m0; ++i) cache[i] = 0.0;
+        c->hessian_action_action(cache, x + s->xo[t], ut, w, c->ctx);
+        for (int i = 0; i < m0 * m0; ++i) s->guu[s->uuo[t] + i] += cache[i];
+        for (int i = 0; i < m0 * n0; ++i) cache[i] = 0.0;
+        c->hessian_action_state(cache, x + s->xo[t], ut, w, c->ctx);
+        for (int i = 0; i < m0 * n0; ++i) s->gux[s->uxo[t] + i] += cache[i];
     }
     if (!s->constrained) return;
 
@@ -311,24 +342,27 @@ extern "C" void orc_gradients(OrcSolver* s) {
         const OrcConstraint* con = s->cons[t];
         int nc = con->num_constraint;
         if (nc == 0) continue;
+        const int n0 = s->nx[t], m0 = t < N ? s->nu[t] : 0;
         const double* w = s->parameters.data() + t * nw;
-        const double* ut = t < N ? u + t * m : nullptr;
-        for (int i = 0; i < nc * n; ++i) cache[i] = 0.0;
-        con->jacobian_state(cache, x + t * n, ut, w, con->ctx);
-        std::memcpy(&s->cx[s->cxoff[t]], cache, sizeof(double) * nc * n);
+        const double* ut = t < N ? u + s->uo[t] : nullptr;
+        for (int i = 0; i < nc * n0; ++i) cache[i] = 0.0;
+        con->jacobian_state(cache, x + s->xo[t], ut, w, con->ctx);
+        std::memcpy(&s->cx[s->cxoff[t]], cache, sizeof(double) * nc * n0);
         if (t == N) continue;
-        for (int i = 0; i < nc * m; ++i) cache[i] = 0.0;
-        con->jacobian_action(cache, x + t * n, ut, w, con->ctx);
-        std::memcpy(&s->cu[s->cuoff[t]], cache, sizeof(double) * nc * m);
+        for (int i = 0; i < nc * m0; ++i) cache[i] = 0.0;
+        con->jacobian_action(cache, x + s->xo[t], ut, w, con->ctx);
+        std::memcpy(&s->cu[s->cuoff[t]], cache, sizeof(double) * nc * m0);
     }
     // AL Gauss-Newton terms — src/gradients.jl:54-80
     for (int t = 0; t < T; ++t) {
         int nc = nc_at(s, t), off = s->coff[t];
         if (nc == 0) continue;
+        const int n = s->nx[t], m = t < N ? s->nu[t] : 0;
         const double* c = &s->violations[off];      // the violations BUFFER (Q2)
         const double* cxt = &s->cx[s->cxoff[t]];    // nc×n column-major
         double* ctmp = &s->c_tmp[off];
         double* cxtmp = s->cx_tmp.data();
+        double* gx = &s->gx[s->xo[t]]; double* gxx = &s->gxx[s->xxo[t]];
         // Iρ = diag(ρ∘a); c_tmp = λ + Iρ c     (:56-62)
         for (int i = 0; i < nc; ++i) {
             double irho = s->rho[off + i] * (double)s->active[off + i];
@@ -338,7 +372,7 @@ extern "C" void orc_gradients(OrcSolver* s) {
         for (int j = 0; j < n; ++j) {
             double acc = 0.0;
             for (int i = 0; i < nc; ++i) acc += cxt[j * nc + i] * ctmp[i];
-            s->gx[t * n + j] += acc;
+            gx[j] += acc;
         }
         // cx_tmp = Iρ cx ; gxx += cxᵀ cx_tmp   (:66-67)
         for (int j = 0; j < n; ++j)
@@ -348,16 +382,17 @@ extern "C" void orc_gradients(OrcSolver* s) {
             for (int i2 = 0; i2 < n; ++i2) {
                 double acc = 0.0;
                 for (int i = 0; i < nc; ++i) acc += cxt[i2 * nc + i] * cxtmp[j * nc + i];
-                s->gxx[t * n * n + j * n + i2] += acc;
+                gxx[j * n + i2] += acc;
             }
         if (t == N) continue;                        // (:69)
         const double* cut = &s->cu[s->cuoff[t]];    // nc×m
         double* cutmp = s->cu_tmp.data();
+        double* gu = &s->gu[s->uo[t]]; double* guu = &s->guu[s->uuo[t]]; double* gux = &s->gux[s->uxo[t]];
         // gu += cuᵀ c_tmp   (:72)
         for (int j = 0; j < m; ++j) {
             double acc = 0.0;
             for (int i = 0; i < nc; ++i) acc += cut[j * nc + i] * ctmp[i];
-            s->gu[t * m + j] += acc;
+            gu[j] += acc;
         }
         // cu_tmp = Iρ cu ; guu += cuᵀ cu_tmp  (:75-76)
         for (int j = 0; j < m; ++j)
@@ -367,14 +402,14 @@ extern "C" void orc_gradients(OrcSolver* s) {
             for (int i2 = 0; i2 < m; ++i2) {
                 double acc = 0.0;
                 for (int i = 0; i < nc; ++i) acc += cut[i2 * nc + i] * cutmp[j * nc + i];
-                s->guu[t * m * m + j * m + i2] += acc;
+                guu[j * m + i2] += acc;
             }
         // gux += cuᵀ cx_tmp   (:79)   gux is m×n
         for (int j = 0; j < n; ++j)
             for (int i2 = 0; i2 < m; ++i2) {
                 double acc = 0.0;
                 for (int i = 0; i < nc; ++i) acc += cut[i2 * nc + i] * cxtmp[j * nc + i];
-                s->gux[t * m * n + j * m + i2] += acc;
+                gux[j * m + i2] += acc;
             }
     }
 }
@@ -450,37 +485,42 @@ extern "C" void orc_potrs_U(const double* U, int m, double* B, int nrhs) { potrs
 
 // --------------------------------------------------------- backward_pass.jl
 extern "C" void orc_backward_pass(OrcSolver* s) {
-    const int n = s->n, m = s->m, T = s->T, N = T - 1;
+    const int T = s->T, N = T - 1;
     // P[H] .= gxx[H]; p[H] .= gx[H]     (:39-40)
-    std::memcpy(&s->P[N * n * n], &s->gxx[N * n * n], sizeof(double) * n * n);
-    std::memcpy(&s->p[N * n], &s->gx[N * n], sizeof(double) * n);
+    std::memcpy(&s->P[s->xxo[N]], &s->gxx[s->xxo[N]], sizeof(double) * s->nx[N] * s->nx[N]);
+    std::memcpy(&s->p[s->xo[N]], &s->gx[s->xo[N]], sizeof(double) * s->nx[N]);
     for (int t = N - 1; t >= 0; --t) {        // (:42)
-        const double* fx = &s->fx[t * n * n];  // n×n
-        const double* fu = &s->fu[t * n * m];  // n×m
-        const double* Pn = &s->P[(t + 1) * n * n];
-        const double* pn = &s->p[(t + 1) * n];
-        double* Qx = &s->Qx[t * n]; double* Qu = &s->Qu[t * m];
-        double* Qxx = &s->Qxx[t * n * n]; double* Quu = &s->Quu[t * m * m]; double* Qux = &s->Qux[t * m * n];
-        double* K = &s->K[t * m * n]; double* k = &s->k[t * m];
-        double* P = &s->P[t * n * n]; double* p = &s->p[t * n];
+        // n = num_state, m = num_action, n1 = num_next_state of step t (src/data/policy.jl:44-72: K[t] is m x n, P[t] n x n,
+        // xx̂_tmp[t] n x n1, ux̂_tmp[t] m x n1)
+        const int n = s->nx[t], m = s->nu[t], n1 = s->nx[t + 1];
+        const double* fx = &s->fx[s->fxo[t]];  // n1×n
+        const double* fu = &s->fu[s->fuo[t]];  // n1×m
+        const double* Pn = &s->P[s->xxo[t + 1]];
+        const double* pn = &s->p[s->xo[t + 1]];
+        const double* gx = &s->gx[s->xo[t]]; const double* gu = &s->gu[s->uo[t]];
+        const double* gxx = &s->gxx[s->xxo[t]]; const double* guu = &s->guu[s->uuo[t]]; const double* gux = &s->gux[s->uxo[t]];
+        double* Qx = &s->Qx[s->xo[t]]; double* Qu = &s->Qu[s->uo[t]];
+        double* Qxx = &s->Qxx[s->xxo[t]]; double* Quu = &s->Quu[s->uuo[t]]; double* Qux = &s->Qux[s->uxo[t]];
+        double* K = &s->K[s->uxo[t]]; double* k = &s->k[s->uo[t]];
+        double* P = &s->P[s->xxo[t]]; double* p = &s->p[s->xo[t]];
         // Qx = fxᵀp' + gx   (:44-45)
-        gemm(Qx, n, 1, fx, n, true, pn, n, n, false);
-        for (int i = 0; i < n; ++i) Qx[i] += s->gx[t * n + i];
+        gemm(Qx, n, 1, fx, n1, true, pn, n1, n1, false);
+        for (int i = 0; i < n; ++i) Qx[i] += gx[i];
         // Qu = fuᵀp' + gu   (:48-49)
-        gemm(Qu, m, 1, fu, n, true, pn, n, n, false);
-        for (int i = 0; i < m; ++i) Qu[i] += s->gu[t * m + i];
+        gemm(Qu, m, 1, fu, n1, true, pn, n1, n1, false);
+        for (int i = 0; i < m; ++i) Qu[i] += gu[i];
         // Qxx = (fxᵀP')fx + gxx   (:52-54)
-        gemm(s->xx_tmp.data(), n, n, fx, n, true, Pn, n, n, false);
-        gemm(Qxx, n, n, s->xx_tmp.data(), n, false, fx, n, n, false);
-        for (int i = 0; i < n * n; ++i) Qxx[i] += s->gxx[t * n * n + i];
+        gemm(s->xx_tmp.data(), n, n1, fx, n1, true, Pn, n1, n1, false);
+        gemm(Qxx, n, n, s->xx_tmp.data(), n, false, fx, n1, n1, false);
+        for (int i = 0; i < n * n; ++i) Qxx[i] += gxx[i];
         // Quu = (fuᵀP')fu + guu   (:57-59)
-        gemm(s->ux_hat_tmp.data(), m, n, fu, n, true, Pn, n, n, false);
-        gemm(Quu, m, m, s->ux_hat_tmp.data(), m, false, fu, n, n, false);
-        for (int i = 0; i < m * m; ++i) Quu[i] += s->guu[t * m * m + i];
+        gemm(s->ux_hat_tmp.data(), m, n1, fu, n1, true, Pn, n1, n1, false);
+        gemm(Quu, m, m, s->ux_hat_tmp.data(), m, false, fu, n1, n1, false);
+        for (int i = 0; i < m * m; ++i) Quu[i] += guu[i];
         // Qux = (fuᵀP')fx + gux   (:62-64)
-        gemm(s->ux_hat_tmp.data(), m, n, fu, n, true, Pn, n, n, false);
-        gemm(Qux, m, n, s->ux_hat_tmp.data(), m, false, fx, n, n, false);
-        for (int i = 0; i < m * n; ++i) Qux[i] += s->gux[t * m * n + i];
+        gemm(s->ux_hat_tmp.data(), m, n1, fu, n1, true, Pn, n1, n1, false);
+        gemm(Qux, m, n, s->ux_hat_tmp.data(), m, false, fx, n1, n1, false);
+        for (int i = 0; i < m * n; ++i) Qux[i] += gux[i];
         // potrf/potrs   (:68-75)
         std::memcpy(s->uu_tmp.data(), Quu, sizeof(double) * m * m);
         int info = potrf_U(s->uu_tmp.data(), m);
@@ -509,53 +549,56 @@ extern "C" void orc_backward_pass(OrcSolver* s) {
 
 // src/solve.jl:67-83
 extern "C" void orc_lagrangian_gradient(OrcSolver* s) {
-    const int n = s->n, m = s->m, T = s->T, N = T - 1;
+    const int T = s->T, N = T - 1, X = s->xo[T];       // data.indices_state / indices_action, src/data/solver.jl:23-35
     for (int t = 0; t < N; ++t) {
-        for (int i = 0; i < n; ++i) s->gradient[t * n + i] = s->Qx[t * n + i] - s->p[t * n + i];
-        for (int i = 0; i < m; ++i) s->gradient[T * n + t * m + i] = s->Qu[t * m + i];
+        for (int i = 0; i < s->nx[t]; ++i) s->gradient[s->xo[t] + i] = s->Qx[s->xo[t] + i] - s->p[s->xo[t] + i];
+        for (int i = 0; i < s->nu[t]; ++i) s->gradient[X + s->uo[t] + i] = s->Qu[s->uo[t] + i];
     }
     // gradient wrt x_T is left untouched
 }
 
 // src/data/methods.jl:42-54
 static void trajectory_sensitivities(OrcSolver* s) {
-    const int n = s->n, m = s->m, T = s->T, N = T - 1;
+    const int T = s->T, N = T - 1, X = s->xo[T];
     std::fill(s->trajectory.begin(), s->trajectory.end(), 0.0);
     for (int t = 0; t < N; ++t) {
-        double* zx = &s->trajectory[t * n];
-        double* zu = &s->trajectory[T * n + t * m];
-        double* zy = &s->trajectory[(t + 1) * n];
-        for (int i = 0; i < m; ++i) zu[i] = s->k[t * m + i];
-        gemm(zu, m, 1, &s->K[t * m * n], m, false, zx, n, n, true);
-        gemm(zy, n, 1, &s->fu[t * n * m], n, false, zu, m, m, false);
-        gemm(zy, n, 1, &s->fx[t * n * n], n, false, zx, n, n, true);
+        const int n = s->nx[t], m = s->nu[t], n1 = s->nx[t + 1];
+        double* zx = &s->trajectory[s->xo[t]];
+        double* zu = &s->trajectory[X + s->uo[t]];
+        double* zy = &s->trajectory[s->xo[t + 1]];
+        for (int i = 0; i < m; ++i) zu[i] = s->k[s->uo[t] + i];
+        gemm(zu, m, 1, &s->K[s->uxo[t]], m, false, zx, n, n, true);
+        gemm(zy, n1, 1, &s->fu[s->fuo[t]], n1, false, zu, m, m, false);
+        gemm(zy, n1, 1, &s->fx[s->fxo[t]], n1, false, zx, n, n, true);
     }
 }
 
 // src/rollout.jl:1-31
 extern "C" void orc_rollout_bang(OrcSolver* s, double step_size) {
-    const int n = s->n, m = s->m, nw = s->nw, T = s->T, N = T - 1;
+    const int nw = s->nw, T = s->T, N = T - 1;
     double* x = s->states.data(); double* u = s->actions.data();
     const double* xb = s->nominal_states.data(); const double* ub = s->nominal_actions.data();
-    for (int i = 0; i < n; ++i) x[i] = xb[i];            // (:19)
+    for (int i = 0; i < s->nx[0]; ++i) x[i] = xb[i];     // (:19)
     for (int t = 0; t < N; ++t) {
-        const double* K = &s->K[t * m * n];
-        double* ut = u + t * m;
-        for (int i = 0; i < m; ++i) ut[i] = s->k[t * m + i];           // (:24)
+        const int n = s->nx[t], m = s->nu[t];
+        const double* K = &s->K[s->uxo[t]];
+        const double* xt = x + s->xo[t]; const double* xbt = xb + s->xo[t];
+        double* ut = u + s->uo[t];
+        for (int i = 0; i < m; ++i) ut[i] = s->k[s->uo[t] + i];        // (:24)
         for (int i = 0; i < m; ++i) ut[i] *= step_size;                // (:25)
-        for (int i = 0; i < m; ++i) ut[i] += ub[t * m + i];            // (:26)
+        for (int i = 0; i < m; ++i) ut[i] += ub[s->uo[t] + i];         // (:26)
         for (int i = 0; i < m; ++i) {                                  // (:27) u += K x
             double acc = 0.0;
-            for (int j = 0; j < n; ++j) acc += K[j * m + i] * x[t * n + j];
+            for (int j = 0; j < n; ++j) acc += K[j * m + i] * xt[j];
             ut[i] += acc;
         }
         for (int i = 0; i < m; ++i) {                                  // (:28) u -= K x̄
             double acc = 0.0;
-            for (int j = 0; j < n; ++j) acc += K[j * m + i] * xb[t * n + j];
+            for (int j = 0; j < n; ++j) acc += K[j * m + i] * xbt[j];
             ut[i] += -1.0 * acc;
         }
         const OrcDynamics* d = s->dynamics[t];
-        d->evaluate(x + (t + 1) * n, x + t * n, ut, s->parameters.data() + t * nw, d->ctx);   // (:29)
+        d->evaluate(x + s->xo[t + 1], xt, ut, s->parameters.data() + t * nw, d->ctx);   // (:29)
     }
     s->rollouts++;
 }
@@ -734,6 +777,13 @@ extern "C" double* orc_buffer(OrcSolver* s, const char* name, int* len) {
     return nullptr;
 }
 
+// per-timestep dimensions of a problem: nx_t[T] (num_state of every step, num_next_state of the last), nu_t[T-1]
+extern "C" void orc_problem_dims(const OrcProblem* p, int* nx_t, int* nu_t) {
+    const int N = p->T - 1;
+    for (int t = 0; t < N; ++t) { nx_t[t] = p->dynamics[t]->num_state; nu_t[t] = p->dynamics[t]->num_action; }
+    nx_t[N] = p->dynamics[N - 1]->num_next_state;
+}
+
 // ------------------------------------------------------------- batch driver
 extern "C" int orc_solve_batch_w(const char* model, int T, int B, const double* x1,
                                  const double* ubar, const double* w, const OrcOptions* opts, int nthreads,
@@ -754,7 +804,16 @@ extern "C" int orc_solve_batch_w(const char* model, int T, int B, const double* 
                                  OrcStats* stats_out) {
     OrcProblem prob;
     if (orc_problem_builtin(model, T, &prob) != 0) return -1;
+    // Host arrays are PADDED to the largest dimensions of the horizon (n = prob.nx, m = prob.nu: what the device path's
+    // zero-padded template uses): x[b][t][n], u[b][t][m], K[b][t][n][m] column-major m x n — for a problem with uniform
+    // dimensions that is the plain layout. The solver itself works on the ragged per-timestep blocks.
     const int n = prob.nx, m = prob.nu, N = T - 1;
+    std::vector<int> nxt(T), nut(N);
+    for (int t = 0; t < N; ++t) { nxt[t] = prob.dynamics[t]->num_state; nut[t] = prob.dynamics[t]->num_action; }
+    nxt[N] = prob.dynamics[N - 1]->num_next_state;
+    int X = 0, U = 0;
+    for (int t = 0; t < T; ++t) X += nxt[t];
+    for (int t = 0; t < N; ++t) U += nut[t];
     int fail = 0;
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
@@ -766,15 +825,34 @@ extern "C" int orc_solve_batch_w(const char* model, int T, int B, const double* 
             fail = 1;
             continue;
         }
-        std::vector<double> xbar(T * n);
-        orc_rollout(T, prob.dynamics, x1 + (size_t)b * n, ubar + (size_t)b * N * m, wb, xbar.data());
-        orc_initialize_controls(s, ubar + (size_t)b * N * m);
+        std::vector<double> xbar(X), ur(U + 1);
+        for (int t = 0; t < N; ++t)
+            for (int i = 0; i < nut[t]; ++i) ur[s->uo[t] + i] = ubar[((size_t)b * N + t) * m + i];
+        orc_rollout(T, prob.dynamics, x1 + (size_t)b * n, ur.data(), wb, xbar.data());
+        orc_initialize_controls(s, ur.data());
         orc_initialize_states(s, xbar.data());
         orc_solve(s);
-        if (x_out) std::memcpy(x_out + (size_t)b * T * n, s->nominal_states.data(), sizeof(double) * T * n);
-        if (u_out) std::memcpy(u_out + (size_t)b * N * m, s->nominal_actions.data(), sizeof(double) * N * m);
-        if (K_out) std::memcpy(K_out + (size_t)b * N * m * n, s->K.data(), sizeof(double) * N * m * n);
-        if (k_out) std::memcpy(k_out + (size_t)b * N * m, s->k.data(), sizeof(double) * N * m);
+        for (int t = 0; t < T; ++t) {
+            if (x_out) {
+                double* o = x_out + ((size_t)b * T + t) * n;
+                for (int i = 0; i < n; ++i) o[i] = i < nxt[t] ? s->nominal_states[s->xo[t] + i] : 0.0;
+            }
+            if (t == N) continue;
+            if (u_out) {
+                double* o = u_out + ((size_t)b * N + t) * m;
+                for (int i = 0; i < m; ++i) o[i] = i < nut[t] ? s->nominal_actions[s->uo[t] + i] : 0.0;
+            }
+            if (k_out) {
+                double* o = k_out + ((size_t)b * N + t) * m;
+                for (int i = 0; i < m; ++i) o[i] = i < nut[t] ? s->k[s->uo[t] + i] : 0.0;
+            }
+            if (K_out) {
+                double* o = K_out + ((size_t)b * N + t) * m * n;
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < m; ++i)
+                        o[j * m + i] = (i < nut[t] && j < nxt[t]) ? s->K[s->uxo[t] + j * nut[t] + i] : 0.0;
+            }
+        }
         if (stats_out) orc_get_stats(s, &stats_out[b]);
         orc_solver_destroy(s);
     }

@@ -17,9 +17,11 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this library.
  *
- * Restrictions vs the reference (documented in DESIGN.md): state/action
- * dimensions are uniform over the horizon (num_next_state == num_state);
- * per-timestep Cost/Constraint objects may differ.
+ * As in the reference, every timestep has its own Dynamics / Cost / Constraint
+ * object and its own dimensions (num_next_state may differ from num_state,
+ * src/dynamics.jl:5-7): all buffers are ragged concatenations of per-timestep
+ * blocks sized as src/data/{model,objective,policy,problem}.jl size them. For
+ * uniform dimensions that is the plain [t][...] layout.
  */
 #ifndef ILQR_ORACLE_H
 #define ILQR_ORACLE_H
@@ -156,15 +158,20 @@ typedef struct {
     void* owner;                             /* internal */
 } OrcProblem;
 
-/* name: "particle","acrobot","car","car_goal","car_obs"(nw=2),"synth32","pendulum_euler",
- * "kat_objective","kat_constraints","acrobot_unconstrained".
+/* name: "particle","acrobot","car","car_goal","car_obs"(nw=2),"car_tv" (distinct per-step objects),
+ * "ragged" (per-step DIMENSIONS: nx = 3,3,4,4,2,2,3,3 | ..., nu = 2,1,2,1,1,2,2,1 | ...; OrcProblem.nx / .nu are the largest),
+ * "synth32","synth12","pendulum_euler","pendulum_pole","kat_objective","kat_constraints","acrobot_unconstrained".
  * Returns 0 on success. The arrays live until orc_problem_free. */
 int orc_problem_builtin(const char* name, int T, OrcProblem* out);
 void orc_problem_free(OrcProblem* p);
+/* per-timestep dimensions: nx_t[T] (num_state of step t; num_next_state of the last dynamics for t = T-1), nu_t[T-1] */
+void orc_problem_dims(const OrcProblem* p, int* nx_t, int* nu_t);
 
 /* batch driver = CPU baseline: one fresh Solver per instance, instances
  * spread over `nthreads` OpenMP threads. x1: B*n, ubar: B*(T-1)*m (states by
- * open-loop rollout). Outputs may be NULL. Returns 0 on success. */
+ * open-loop rollout). Outputs may be NULL. Returns 0 on success.
+ * Problems whose dimensions vary along the horizon: the host arrays are padded to
+ * n = OrcProblem.nx, m = OrcProblem.nu (the largest), padding read as / written with zeros. */
 int orc_solve_batch(const char* model, int T, int B, const double* x1,
                     const double* ubar, const OrcOptions* opts, int nthreads,
                     double* x_out, double* u_out, double* K_out, double* k_out,

@@ -232,6 +232,44 @@ void synth12_term_jx(double* out, const double*, const double*, const double*, c
     for (int i = 0; i < 3; ++i) out[i * 3 + i] = 1.0;
 }
 
+// ------------------------------------------------------------------ ragged
+// Time-varying DIMENSIONS (src/dynamics.jl:5-7: num_next_state != num_state; README.md:26 of the reference): a chain of
+// small maps (n0, m0) -> n1, y_i = sum_j A_ij x_j + sum_j B_ij u_j + [i == 0] 0.1 sin(x_0),
+// A_ij = 0.9 [i == j] + 0.1 cos(1 + i + 2j + n0), B_ij = 0.3 sin(2 + 3i + j + m0) (0-based) — the twin of
+// tests/test_codegen.py::_ragged_problem. Dimensions are run-time here (ctx), at most 4 states / 4 actions.
+struct RaggedCtx { int n0, m0, n1; };
+template <class S> void ragged_f(const RaggedCtx* c, const S* x, const S* u, S* y) {
+    for (int i = 0; i < c->n1; ++i) {
+        S acc = S(0.0);
+        for (int j = 0; j < c->n0; ++j) acc = acc + ((i == j ? 0.9 : 0.0) + 0.1 * std::cos(1.0 + i + 2 * j + c->n0)) * x[j];
+        for (int j = 0; j < c->m0; ++j) acc = acc + (0.3 * std::sin(2.0 + 3 * i + j + c->m0)) * u[j];
+        if (i == 0) acc = acc + 0.1 * sin(x[0]);
+        y[i] = acc;
+    }
+}
+void ragged_eval(double* out, const double* x, const double* u, const double*, const void* ctx) {
+    ragged_f((const RaggedCtx*)ctx, x, u, out);
+}
+void ragged_jx(double* out, const double* x, const double* u, const double*, const void* ctx) {
+    const RaggedCtx* c = (const RaggedCtx*)ctx;
+    typedef Dual<4> S;
+    S xs[4], us[4], ys[4];
+    for (int i = 0; i < c->n0; ++i) { xs[i] = S(x[i]); xs[i].d[i] = 1.0; }
+    for (int i = 0; i < c->m0; ++i) us[i] = S(u[i]);
+    ragged_f(c, xs, us, ys);
+    for (int j = 0; j < c->n0; ++j) for (int i = 0; i < c->n1; ++i) out[j * c->n1 + i] = ys[i].d[j];     // n1 x n0, column-major
+}
+void ragged_ju(double* out, const double* x, const double* u, const double*, const void* ctx) {
+    const RaggedCtx* c = (const RaggedCtx*)ctx;
+    typedef Dual<4> S;
+    S xs[4], us[4], ys[4];
+    for (int i = 0; i < c->n0; ++i) xs[i] = S(x[i]);
+    for (int i = 0; i < c->m0; ++i) { us[i] = S(u[i]); us[i].d[i] = 1.0; }
+    ragged_f(c, xs, us, ys);
+    for (int j = 0; j < c->m0; ++j) for (int i = 0; i < c->n1; ++i) out[j * c->n1 + i] = ys[i].d[j];     // n1 x m0
+}
+const int RAGGED_N[8] = {3, 3, 4, 4, 2, 2, 3, 3}, RAGGED_M[8] = {2, 1, 2, 1, 1, 2, 2, 1};
+
 // generic wrappers: orc_fn adaptors for a dynamics functor
 template <int NX, int NU, class F> void dyn_eval(double* out, const double* x, const double* u, const double*, const void*) {
     F f; f(x, u, out);
@@ -398,6 +436,7 @@ struct Zoo {
     GoalCtx goal; BoxCtx box;
     OrcConstraint ks, kt;
     OrcDynamics dyn2; QuadCtx qs2; OrcCost cs2; OrcConstraint ks2, ks3;   // car_tv: further stage kinds
+    std::vector<OrcDynamics> rdyn; std::vector<RaggedCtx> rctx; std::vector<QuadCtx> rq; std::vector<OrcCost> rcost;   // ragged: one object per step
     std::vector<const OrcDynamics*> dptr;
     std::vector<const OrcCost*> cptr;
     std::vector<const OrcConstraint*> kptr;
@@ -488,6 +527,28 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
         z->kt.evaluate = car_term_eval; z->kt.jacobian_state = car_term_jx;
         z->kt.num_constraint = 4; z->kt.num_state = 3;
         z->kt.num_inequality = 1; z->kt.indices_inequality[0] = 3;
+    } else if (!std::strcmp(name, "ragged")) {
+        // dimensions n_t = 3,3,4,4,2,2,3,3 | 3,..., m_t = 2,1,2,1,1,2,2,1 | 2,... (period 8); stage cost
+        // 0.5 sum (1 + 0.1 i) x_i^2 + 0.05 sum (1 + j) u_j^2, terminal cost 5 |x|^2, terminal equality [x_0 - 0.2, x_1 + 0.1]
+        const int N = T - 1;
+        z->rdyn.resize(N); z->rctx.resize(N); z->rq.resize(N); z->rcost.resize(N);
+        for (int t = 0; t < N; ++t) {
+            RaggedCtx& c = z->rctx[t];
+            c.n0 = RAGGED_N[t % 8]; c.m0 = RAGGED_M[t % 8]; c.n1 = RAGGED_N[(t + 1) % 8];
+            OrcDynamics& d = z->rdyn[t];
+            d.evaluate = ragged_eval; d.jacobian_state = ragged_jx; d.jacobian_action = ragged_ju;
+            d.num_state = c.n0; d.num_action = c.m0; d.num_next_state = c.n1; d.num_parameter = 0; d.ctx = &c;
+            quad_init(&z->rq[t], c.n0, c.m0);
+            for (int i = 0; i < c.n0; ++i) z->rq[t].q[i] = 0.5 * (1.0 + 0.1 * i);
+            for (int j = 0; j < c.m0; ++j) z->rq[t].r[j] = 0.05 * (1.0 + j);
+        }
+        const int nT = RAGGED_N[N % 8];
+        quad_init(&z->qs, 1, 1);            // unused (placeholder for the shared tail below)
+        quad_init(&z->qt, nT, 0);
+        for (int i = 0; i < nT; ++i) z->qt.q[i] = 5.0;
+        z->goal.n = 2; z->goal.xT[0] = 0.2; z->goal.xT[1] = -0.1;
+        z->kt.evaluate = goal_eval; z->kt.jacobian_state = goal_jx; z->kt.num_constraint = 2;
+        z->kt.num_state = nT; z->kt.ctx = &z->goal;
     } else if (!std::strcmp(name, "synth32")) {
         z->dyn = make_dynamics<32, 8, Synth32F>();
         quad_init(&z->qs, 32, 8); quad_init(&z->qt, 32, 0);
@@ -538,6 +599,12 @@ extern "C" int orc_problem_builtin(const char* name, int T, OrcProblem* out) {
             z->cptr.push_back(2 * t >= T - 1 ? &z->cs2 : &z->cs);
             z->kptr.push_back(t % 4 == 0 ? &z->ks : (t % 4 == 2 ? &z->ks3 : &z->ks2));
         }
+    } else if (!std::strcmp(name, "ragged")) {
+        for (int t = 0; t < T - 1; ++t) {
+            z->rcost[t] = make_quad_cost(&z->rq[t]);
+            z->dptr.push_back(&z->rdyn[t]); z->cptr.push_back(&z->rcost[t]); z->kptr.push_back(&z->ks);
+        }
+        z->dyn = z->rdyn[0]; z->dyn.num_state = 4; z->dyn.num_action = 2;     // (out->nx, out->nu below: the LARGEST dimensions)
     } else
     for (int t = 0; t < T - 1; ++t) { z->dptr.push_back(&z->dyn); z->cptr.push_back(&z->cs); z->kptr.push_back(&z->ks); }
     z->cptr.push_back(&z->ct); z->kptr.push_back(&z->kt);

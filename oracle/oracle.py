@@ -67,6 +67,8 @@ def lib():
         L.orc_problem_builtin.argtypes = [C.c_char_p, C.c_int, C.POINTER(OrcProblem)]
         L.orc_problem_builtin.restype = C.c_int
         L.orc_problem_free.argtypes = [C.POINTER(OrcProblem)]
+        L.orc_problem_dims.argtypes = [C.POINTER(OrcProblem), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_problem_dims.restype = None
         L.orc_solver_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p, C.POINTER(OrcOptions)]
         L.orc_solver_create.restype = C.c_void_p
         L.orc_solver_destroy.argtypes = [C.c_void_p]
@@ -127,16 +129,58 @@ class Problem:
         self.c = OrcProblem()
         if lib().orc_problem_builtin(name.encode(), T, C.byref(self.c)) != 0:
             raise ValueError("unknown oracle model %r" % name)
-        self.nx, self.nu = self.c.nx, self.c.nu
+        self.nx, self.nu = self.c.nx, self.c.nu          # the LARGEST dimensions of the horizon
+        nxt = (C.c_int * T)(); nut = (C.c_int * max(T - 1, 1))()
+        lib().orc_problem_dims(C.byref(self.c), nxt, nut)
+        self.state_dims, self.action_dims = list(nxt), list(nut)[:T - 1]
+        self.uniform = set(self.state_dims) == {self.nx} and set(self.action_dims) == {self.nu}
+
+    # Problems whose dimensions vary along the horizon: the solver's buffers are ragged concatenations of per-timestep blocks
+    # (as the reference's Vectors of Vectors are); the helpers below convert to and from arrays padded to (nx, nu).
+    def pack_states(self, x):
+        x = np.asarray(x, dtype=np.float64).reshape(self.T, self.nx)
+        return np.ascontiguousarray(np.concatenate([x[t, :n] for t, n in enumerate(self.state_dims)]))
+
+    def pack_actions(self, u):
+        u = np.asarray(u, dtype=np.float64).reshape(self.T - 1, self.nu)
+        return np.ascontiguousarray(np.concatenate([u[t, :m] for t, m in enumerate(self.action_dims)]))
+
+    def unpack(self, flat, rows, cols=None):
+        """Ragged per-timestep blocks -> zero-padded array. rows / cols: "x" | "u" | "x+" (next state) | None, column-major blocks;
+        result [t][col][row] padded (what the device's getters return), or [t][row] for vectors."""
+        flat = np.asarray(flat)
+        dim = {"x": (self.state_dims, self.nx), "u": (self.action_dims, self.nu), "x+": (self.state_dims[1:], self.nx)}
+        rd, rmax = dim[rows]
+        steps, o = 0, 0          # as many leading timesteps as the buffer holds (Qx, Qxx stop one short of gx, gxx)
+        while steps < len(rd) and (cols is None or steps < len(dim[cols][0])):
+            o += rd[steps] * (1 if cols is None else dim[cols][0][steps])
+            if o > flat.size:
+                break
+            steps += 1
+        if cols is None:
+            out = np.zeros((steps, rmax)); o = 0
+            for t in range(steps):
+                out[t, :rd[t]] = flat[o:o + rd[t]]; o += rd[t]
+            return out
+        cd, cmax = dim[cols]
+        out = np.zeros((steps, cmax, rmax)); o = 0
+        for t in range(steps):
+            out[t, :cd[t], :rd[t]] = flat[o:o + rd[t] * cd[t]].reshape(cd[t], rd[t]); o += rd[t] * cd[t]
+        return out
 
     def rollout(self, x1, u, w=None):
-        """rollout(dynamics, x1, ū[, parameters]) — src/rollout.jl:33-42."""
+        """rollout(dynamics, x1, ū[, parameters]) — src/rollout.jl:33-42. Padded arrays in and out."""
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
         u = np.ascontiguousarray(u, dtype=np.float64)
         w = np.ascontiguousarray(w, dtype=np.float64) if w is not None else None
-        x = np.zeros((self.T, self.nx))
-        lib().orc_rollout(self.T, self.c.dynamics, _p(x1), _p(u), _p(w), _p(x))
-        return x
+        if self.uniform:
+            x = np.zeros((self.T, self.nx))
+            lib().orc_rollout(self.T, self.c.dynamics, _p(x1), _p(u), _p(w), _p(x))
+            return x
+        ur = self.pack_actions(u)
+        x = np.zeros(sum(self.state_dims))
+        lib().orc_rollout(self.T, self.c.dynamics, _p(x1), _p(ur), _p(w), _p(x))
+        return self.unpack(x, "x")
 
     def __del__(self):
         try:
@@ -159,11 +203,11 @@ class Solver:
         self._trace = None
 
     def initialize_controls(self, u):
-        u = np.ascontiguousarray(u, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64) if self.problem.uniform else self.problem.pack_actions(u)
         lib().orc_initialize_controls(self.h, _p(u))
 
     def initialize_states(self, x):
-        x = np.ascontiguousarray(x, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64) if self.problem.uniform else self.problem.pack_states(x)
         lib().orc_initialize_states(self.h, _p(x))
 
     def enable_trace(self, capacity=4096):
@@ -205,7 +249,21 @@ class Solver:
 
     def get_trajectory(self):
         T, n, m = self.problem.T, self.problem.nx, self.problem.nu
+        if not self.problem.uniform:
+            return (self.problem.unpack(self.buffer("nominal_states"), "x"), self.problem.unpack(self.buffer("nominal_actions"), "u"))
         return (self.buffer("nominal_states").reshape(T, n), self.buffer("nominal_actions").reshape(T - 1, m))
+
+    # reference field name -> (rows, cols) of its per-timestep blocks, for Problem.unpack
+    BLOCKS = {"nominal_states": ("x", None), "states": ("x", None), "nominal_actions": ("u", None), "actions": ("u", None),
+              "jacobian_state": ("x+", "x"), "jacobian_action": ("x+", "u"), "gradient_state": ("x", None),
+              "gradient_action": ("u", None), "hessian_state_state": ("x", "x"), "hessian_action_action": ("u", "u"),
+              "hessian_action_state": ("u", "x"), "K": ("u", "x"), "k": ("u", None), "P": ("x", "x"), "p": ("x", None),
+              "Qx": ("x", None), "Qu": ("u", None), "Qxx": ("x", "x"), "Quu": ("u", "u"), "Qux": ("u", "x")}
+
+    def padded(self, name):
+        """A workspace buffer as the zero-padded array the device path keeps: [t][col][row] (or [t][row])."""
+        rows, cols = self.BLOCKS[name]
+        return self.problem.unpack(self.buffer(name), rows, cols)
 
     def __del__(self):
         try:

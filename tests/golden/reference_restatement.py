@@ -708,7 +708,43 @@ def synth_box_problem(T, n, m, xmax=1.2):
     return dyn, costs, [box] * (T - 1) + [Constraint()]
 
 
+RAGGED_N, RAGGED_M = [3, 3, 4, 4, 2, 2, 3, 3], [2, 1, 2, 1, 1, 2, 2, 1]
+
+
+def ragged_problem(T=9):
+    """Time-varying DIMENSIONS (src/dynamics.jl:5-7, README.md:26): num_state = 3,3,4,4,2,2,3,3 | ..., num_action = 2,1,2,1,1,2,2,1 | ...
+    (period 8), a linear-plus-sine map per step, quadratic costs, a terminal equality on the first two states. Same definition as
+    tests/test_codegen.py::_ragged_problem (product) and oracle/models.cpp "ragged" (oracle)."""
+    n_t = [RAGGED_N[t % 8] for t in range(T)]
+    m_t = [RAGGED_M[t % 8] for t in range(T - 1)]
+
+    def dyn(n0, m0, n1):
+        A = [[(0.9 if i == j else 0.0) + 0.1 * math.cos(1.0 + i + 2 * j + n0) for j in range(n0)] for i in range(n1)]
+        Bm = [[0.3 * math.sin(2.0 + 3 * i + j + m0) for j in range(m0)] for i in range(n1)]
+        return Dynamics(lambda x, u: [sum(A[i][j] * x[j] for j in range(n0)) + sum(Bm[i][j] * u[j] for j in range(m0))
+                                      + (0.1 * sp.sin(x[0]) if i == 0 else 0.0) for i in range(n1)], n0, m0)
+
+    def cost(n0, m0):
+        return Cost(lambda x, u: 0.5 * sum((1.0 + 0.1 * i) * x[i] * x[i] for i in range(n0))
+                    + 0.05 * sum((1.0 + j) * u[j] * u[j] for j in range(m0)), n0, m0)
+
+    dcache, ccache = {}, {}
+    dynamics, costs = [], []
+    for t in range(T - 1):
+        kd, kc = (n_t[t], m_t[t], n_t[t + 1]), (n_t[t], m_t[t])
+        if kd not in dcache:
+            dcache[kd] = dyn(*kd)
+        if kc not in ccache:
+            ccache[kc] = cost(*kc)
+        dynamics.append(dcache[kd]); costs.append(ccache[kc])
+    nT = n_t[-1]
+    costs.append(Cost(lambda x, u: 5.0 * sum(x[i] * x[i] for i in range(nT)), nT, 0))
+    constraints = [Constraint() for _ in range(T - 1)] + [Constraint(lambda x, u: [x[0] - 0.2, x[1] + 0.1], nT, 0)]
+    return dynamics, costs, constraints
+
+
 PROBLEMS = {
+    "ragged": ragged_problem,
     "particle": particle_problem,
     "acrobot": acrobot_problem,
     "car": car_problem,
