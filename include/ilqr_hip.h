@@ -266,17 +266,26 @@ int ilqr_timing_get(ilqr_handle* h, double* solve_kernel_ms_avg, int32_t* launch
  * nx <= 64, nu <= 16, at most 64 constraint rows per stage here (ilqr_compile_model_rows: 256). Models with nx > 4 or nu > 4 run on the large path, which streams only the state-dependent Jacobian
  * entries and the structurally non-zero Hessian entries per timestep: for opaque callables these are found by PROBING — the
  * source is compiled a second time with the host C++ compiler (ILQR_HOSTCXX, else g++ / c++ / clang++) and the Jacobian,
- * Hessian and constraint-Jacobian callables are evaluated at three points; an entry bitwise equal at all of them is a constant
- * (the role Symbolics' sparse expressions play in the reference, src/dynamics.jl:16-34). Source that does not compile for the
- * host, or ILQR_NO_STRUCTURE_PROBE in the environment, leaves every entry state-dependent / non-zero (correct at every size,
- * but slow: all nx (nx + nu) Jacobian entries are evaluated, stored and patched per timestep).
+ * Hessian and constraint-Jacobian callables are evaluated at 48 points spread over magnitudes 1e-3 ... 1e3 and both signs
+ * (x, u and w alike; selector parameters of a lowered model cycle through every kind); an entry bitwise equal and finite at
+ * all of them is a constant (the role Symbolics' sparse expressions play in the reference, src/dynamics.jl:16-34); an entry
+ * that is NaN / Inf anywhere counts as state-dependent / non-zero.
+ * ASSUMPTION, and its limit: a derivative entry that is constant on every probed point is taken to be constant EVERYWHERE.
+ * That holds for smooth expressions; a PIECEWISE callable — a clamp or saturation (derivative 1 inside a box, 0 outside), fabs,
+ * max(0, .) penalties, contact switches, terms active only in a region — can look constant on all 48 points and is then baked
+ * in wrongly for instances that leave the probed regime. Models with such callables must set flags = ILQR_MODEL_DENSE_TABLES
+ * (per model; ILQR_NO_STRUCTURE_PROBE in the environment does the same for the whole process). Source that does not compile
+ * for the host also gets the dense tables (correct at every size, but slow: all nx (nx + nu) Jacobian entries are evaluated,
+ * stored and patched per timestep). ilqr_model_compact_sizes reports what a module was built with.
  * The dynamics callable itself stays opaque: every lane of the rollout evaluates the whole vector function. */
+#define ILQR_MODEL_DENSE_TABLES 1   /* flags: no structure probe for THIS model (every Jacobian entry state-dependent, every Hessian entry non-zero) */
 typedef struct {
     const char* name;        /* C identifier */
     int32_t nx, nu, nw;      /* num_state, num_action, num_parameter */
     int32_t nc_stage, nc_term;
     uint64_t ineq_stage, ineq_term;
     const char* source;
+    int32_t flags;           /* 0 or ILQR_MODEL_DENSE_TABLES */
 } ilqr_model_source;
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len);
 /* The same for constraints with more than 64 rows per stage (the reference has no limit: Constraint(f, fx, fu, nc, ...;
@@ -287,6 +296,87 @@ int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size
 #define ILQR_MAX_CONSTRAINT_ROWS 256
 int ilqr_compile_model_rows(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
                             char* registered_name, size_t name_len, char* library_path, size_t path_len);
+
+/* ---- Vectors of DISTINCT per-step objects and time-varying DIMENSIONS — README.md:26 of the reference ("costs, constraints and
+ * dynamics can differ at every timestep"): Solver(dynamics::Vector{Dynamics}, costs::Vector{Cost}, constraints) keeps one object
+ * per timestep (src/solver.jl:28-46) and sizes every buffer per timestep (num_next_state may differ from num_state,
+ * src/dynamics.jl:5-7, src/data/model.jl:11-16, src/data/policy.jl:44-78). The device kernels are compiled for ONE stage template
+ * (one Dynamics / stage Cost / stage Constraint of fixed dimensions, one terminal Cost / Constraint), so the host side LOWERS the
+ * per-step objects onto it, exactly:
+ *   - the distinct objects of a category ("kinds", in order of first appearance) become one combined callable that takes one
+ *     extra per-timestep parameter per kind, a one-hot SELECTOR s_k(t) in {0, 1} riding in theta_t behind the user's own
+ *     parameters; the combined callable runs the kind whose selector is set (a branch, not a product: a kind that is switched
+ *     off may be outside its domain at that step); a category with a single kind gets no selectors;
+ *   - constraint kinds are stacked: kind k owns rows [constraint_row0[k], + nc_k) of the combined stage constraint, the rows of
+ *     the kinds that are off read c = 0 with zero Jacobian — their multipliers stay 0 and they add nothing to the AL cost, its
+ *     gradient, the Gauss-Newton Hessian or max_violation (src/augmented_lagrangian.jl:39-110, src/gradients.jl:23-81,
+ *     src/data/constraints.jl:23-46);
+ *   - dimensions are zero-padded to the largest num_state / num_action of the horizon: padded next-state rows are 0, padded
+ *     actions get the stage cost u^2 / 2 (Quu stays positive definite and block-diagonal with the real block, so its Cholesky
+ *     and solves leave the real block untouched and return K = 0, k = 0 for the padding), padded states enter no function.
+ *     Host arrays (x1, u, trajectories, gains) are the padded ones; state_dims[t] / action_dims[t] entries of step t are real.
+ * ilqr_plan_stages computes the plan from the kinds alone (no device, no compiler): template dimensions, selector columns, the
+ * selector table, row offsets and inequality masks. ilqr_compile_model_stages composes the combined callables from C source
+ * of the kinds' callables and compiles them like ilqr_compile_model. ilqr_set_stage_selectors hands the table to a handle.
+ * (The Python host traces symbolic objects: its lowering.py asks ilqr_plan_stages for the plan and gates the expressions
+ * accordingly; a Julia or C host goes through ilqr_compile_model_stages.) */
+#define ILQR_MAX_STAGE_KINDS 16
+typedef struct {
+    int32_t horizon;                    /* T: T-1 dynamics, T costs, T constraints (src/data/problem.jl:28-30) */
+    int32_t num_parameter;              /* the user's parameters per timestep (largest num_parameter of all objects) */
+    /* Dynamics kinds — src/dynamics.jl:1-12: kind k maps (dynamics_nx[k], dynamics_nu[k]) -> dynamics_nx_next[k] */
+    int32_t n_dynamics;
+    const int32_t* dynamics_nx; const int32_t* dynamics_nu; const int32_t* dynamics_nx_next;
+    const int32_t* dynamics_of_step;    /* [T-1]: kind acting at step t */
+    /* stage Cost kinds — src/costs.jl:1-15 */
+    int32_t n_costs;
+    const int32_t* cost_nx; const int32_t* cost_nu;
+    const int32_t* cost_of_step;        /* [T-1] */
+    /* stage Constraint kinds — src/constraints.jl:1-13; a step without rows names a kind with constraint_nc = 0
+     * (Constraint(), src/constraints.jl:45-52). n_constraints = 0: no stage constraints at all (constraint_of_step unused). */
+    int32_t n_constraints;
+    const int32_t* constraint_nc; const int32_t* constraint_nx; const int32_t* constraint_nu;
+    const uint64_t* constraint_ineq;    /* [n_constraints][4]: four 64-bit words per kind, row i of the kind an inequality = bit i % 64 of its word i / 64 */
+    const int32_t* constraint_of_step;  /* [T-1] */
+    /* terminal Cost / Constraint: num_state = nx_term (must be the last dynamics' num_next_state) */
+    int32_t nx_term, nc_term;
+    uint64_t ineq_term[4];              /* inequality rows of the terminal constraint, as words */
+} ilqr_stage_kinds;
+typedef struct {
+    int32_t nx, nu;                     /* template dimensions: largest num_state / num_action of the horizon */
+    int32_t nw;                         /* template parameters per timestep = num_parameter + n_selectors */
+    int32_t nc_stage, nc_term;          /* rows of the combined stage constraint (all kinds stacked), terminal rows */
+    int32_t n_selectors;
+    int32_t sel_dynamics, sel_cost, sel_constraint;   /* first parameter column of the category's one-hot block; -1: one kind, no selectors */
+    int32_t constraint_row0[ILQR_MAX_STAGE_KINDS];    /* first row of kind k in the combined stage constraint */
+    uint64_t ineq_stage_words[4];       /* inequality rows of the combined stage constraint (row i = bit i % 64 of word i / 64) */
+} ilqr_stage_plan;
+/* selectors: [T][plan->n_selectors] written densely (row T-1, the terminal step, is all zero); selectors_len = doubles available
+ * (T * (n_dynamics + n_costs + n_constraints) always suffices). state_dims: [T], action_dims: [T-1]. Any output pointer but
+ * `plan` may be NULL. Fails with ILQR_ERR_INVALID when the chain of dimensions is inconsistent (dynamics[t].num_next_state !=
+ * dynamics[t+1].num_state, a cost or constraint whose dimensions are not its step's), as the reference would throw at
+ * x[t+1] .= dynamics!(...) (src/rollout.jl:29). */
+int ilqr_plan_stages(const ilqr_stage_kinds* kinds, ilqr_stage_plan* plan, double* selectors, size_t selectors_len,
+                     int32_t* state_dims, int32_t* action_dims);
+/* `source`: C code defining, with the contract of ilqr_compile_model (ILQR_MODEL_FN void NAME(double* out, const double* x,
+ * const double* u, const double* w), out column-major IN THE KIND'S OWN DIMENSIONS and pre-zeroed; w = the user's parameters),
+ *     for every Dynamics kind k:    dynamics_<k>, dynamics_<k>_jacobian_state, dynamics_<k>_jacobian_action
+ *     for every stage Cost kind k:  cost_stage_<k>, cost_stage_<k>_gradient_state, cost_stage_<k>_gradient_action,
+ *                                   cost_stage_<k>_hessian_state_state, cost_stage_<k>_hessian_action_action, cost_stage_<k>_hessian_action_state
+ *     for every Constraint kind k with rows: constraint_stage_<k>, constraint_stage_<k>_jacobian_state, constraint_stage_<k>_jacobian_action
+ *     cost_terminal, cost_terminal_gradient_state, cost_terminal_hessian_state_state,
+ *     constraint_terminal, constraint_terminal_jacobian_state                                         (only if nc_term > 0)
+ * The library writes the combined, padded callables of the template around them (selector branches, re-striding of the
+ * matrices into the template's leading dimensions, u^2 / 2 on padded actions) and compiles the result as ilqr_compile_model
+ * does. Outputs as ilqr_plan_stages plus the registered name and module path for ilqr_problem_desc. After ilqr_create:
+ * ilqr_set_stage_selectors(h, selectors, plan.n_selectors). */
+int ilqr_compile_model_stages(const char* name, const ilqr_stage_kinds* kinds, const char* source, ilqr_stage_plan* plan,
+                              double* selectors, size_t selectors_len, int32_t* state_dims, int32_t* action_dims,
+                              char* registered_name, size_t name_len, char* library_path, size_t path_len);
+/* The selector table of a lowered problem, [T][n_selectors] (n_selectors <= num_parameter of the model): the handle keeps it and
+ * writes it into the last n_selectors parameter columns of every instance, now and on every ilqr_set_parameters — which from
+ * here on takes the USER's parameters only, w: [B][T][nw - n_selectors], as ilqr_get_dims reports them. n_selectors = 0 detaches. */
+int ilqr_set_stage_selectors(ilqr_handle* h, const double* selectors, int32_t n_selectors);
 
 /* Test hook: evaluates one of the device-side scalar routines of csrc/ilqr_math.hpp on cuda device 0 — "recip_fast",
  * "rsqrt_fast", "sqrt_fast" (the d of sqrt_rsqrt_fast), "sin_fast", "cos_fast" — elementwise, y[i] = f(x[i]). These replace

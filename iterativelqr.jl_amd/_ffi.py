@@ -36,6 +36,71 @@ class Stats(C.Structure):
                 ("status", C.c_int32), ("potrf_info", C.c_int32), ("rollouts", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ModelSource(C.Structure):
+    """ilqr_model_source: the reference's user-supplied callables as C source (ilqr_compile_model). flags: 0 or MODEL_DENSE_TABLES."""
+    _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
+                ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p),
+                ("flags", C.c_int32)]
+
+
+MODEL_DENSE_TABLES = 1
+MAX_STAGE_KINDS = 16
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class StageKinds(C.Structure):
+    """ilqr_stage_kinds: the distinct per-step objects of a problem and which one acts at every step."""
+    _fields_ = [("horizon", C.c_int32), ("num_parameter", C.c_int32),
+                ("n_dynamics", C.c_int32), ("dynamics_nx", c_int32_p), ("dynamics_nu", c_int32_p), ("dynamics_nx_next", c_int32_p),
+                ("dynamics_of_step", c_int32_p),
+                ("n_costs", C.c_int32), ("cost_nx", c_int32_p), ("cost_nu", c_int32_p), ("cost_of_step", c_int32_p),
+                ("n_constraints", C.c_int32), ("constraint_nc", c_int32_p), ("constraint_nx", c_int32_p), ("constraint_nu", c_int32_p),
+                ("constraint_ineq", C.POINTER(C.c_uint64)), ("constraint_of_step", c_int32_p),
+                ("nx_term", C.c_int32), ("nc_term", C.c_int32), ("ineq_term", C.c_uint64 * 4)]
+
+
+class StagePlan(C.Structure):
+    """ilqr_stage_plan: the one-stage template the kinds are lowered onto."""
+    _fields_ = [("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32), ("nc_term", C.c_int32),
+                ("n_selectors", C.c_int32), ("sel_dynamics", C.c_int32), ("sel_cost", C.c_int32), ("sel_constraint", C.c_int32),
+                ("constraint_row0", C.c_int32 * MAX_STAGE_KINDS), ("ineq_stage_words", C.c_uint64 * 4)]
+
+
+def stage_kinds(T, num_parameter, dynamics, dynamics_of_step, costs, cost_of_step, constraints, constraint_of_step,
+                nx_term, nc_term, ineq_term):
+    """StageKinds from plain lists: dynamics = [(nx, nu, nx_next)], costs = [(nx, nu)], constraints = [(nc, nx, nu, ineq_mask as a Python int of up to 256 bits)]
+    (empty = no stage constraints). The returned struct keeps its arrays alive."""
+    def arr(vals, typ=C.c_int32):
+        return (typ * max(len(vals), 1))(*vals)
+    k = StageKinds()
+    keep = dict(dnx=arr([d[0] for d in dynamics]), dnu=arr([d[1] for d in dynamics]), dnn=arr([d[2] for d in dynamics]),
+                dof=arr(dynamics_of_step), cnx=arr([c[0] for c in costs]), cnu=arr([c[1] for c in costs]), cof=arr(cost_of_step),
+                knc=arr([q[0] for q in constraints]), knx=arr([q[1] for q in constraints]), knu=arr([q[2] for q in constraints]),
+                kin=arr([(q[3] >> (64 * j)) & (2 ** 64 - 1) for q in constraints for j in range(4)], C.c_uint64),
+                kof=arr(constraint_of_step if constraints else []))
+    k.horizon, k.num_parameter = T, num_parameter
+    k.n_dynamics, k.dynamics_nx, k.dynamics_nu, k.dynamics_nx_next, k.dynamics_of_step = len(dynamics), keep["dnx"], keep["dnu"], keep["dnn"], keep["dof"]
+    k.n_costs, k.cost_nx, k.cost_nu, k.cost_of_step = len(costs), keep["cnx"], keep["cnu"], keep["cof"]
+    k.n_constraints, k.constraint_nc, k.constraint_nx, k.constraint_nu = len(constraints), keep["knc"], keep["knx"], keep["knu"]
+    k.constraint_ineq, k.constraint_of_step = keep["kin"], keep["kof"]
+    k.nx_term, k.nc_term = nx_term, nc_term
+    for j in range(4):
+        k.ineq_term[j] = (ineq_term >> (64 * j)) & (2 ** 64 - 1)
+    k._keep = keep
+    return k
+
+
+def plan_stages(kinds):
+    """ilqr_plan_stages -> (StagePlan, selectors[T][S] as nested lists, state_dims, action_dims). Needs no device."""
+    T = kinds.horizon
+    cap = T * (kinds.n_dynamics + kinds.n_costs + kinds.n_constraints)
+    plan, sel = StagePlan(), (C.c_double * max(cap, 1))()
+    sd, ad = (C.c_int32 * T)(), (C.c_int32 * max(T - 1, 1))()
+    check(lib().ilqr_plan_stages(C.byref(kinds), C.byref(plan), sel, cap, sd, ad))
+    S = plan.n_selectors
+    return plan, [[sel[t * S + j] for j in range(S)] for t in range(T)], list(sd), list(ad)[:T - 1]
+
+
 # every symbol include/ilqr_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ilqr_last_error": (C.c_char_p, []),
@@ -75,6 +140,10 @@ SYMBOLS = {
     "ilqr_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "ilqr_compile_model": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "ilqr_compile_model_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "ilqr_plan_stages": (C.c_int, [C.POINTER(StageKinds), C.POINTER(StagePlan), c_double_p, C.c_size_t, c_int32_p, c_int32_p]),
+    "ilqr_compile_model_stages": (C.c_int, [C.c_char_p, C.POINTER(StageKinds), C.c_char_p, C.POINTER(StagePlan), c_double_p, C.c_size_t,
+                                            c_int32_p, c_int32_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "ilqr_set_stage_selectors": (C.c_int, [C.c_void_p, c_double_p, C.c_int32]),
     "ilqr_device_math": (C.c_int, [C.c_char_p, c_double_p, c_double_p, C.c_int32]),
     "ilqr_register_model": (C.c_int, [C.c_void_p]),
     "ilqr_model_count": (C.c_int, []),

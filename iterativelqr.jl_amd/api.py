@@ -85,13 +85,35 @@ class Solver:
     """
 
     def __init__(self, dynamics=None, costs=None, constraints=None, *, model=None, horizon=None, batch=1,
-                 options=None, device=0, devices=None, name="user"):
+                 options=None, device=0, devices=None, name="user", stage_sources=None):
         """devices: list of HIP ordinals — the batch is split into contiguous ranges over them (ilqr_create_sharded: one handle,
-        every GPU of the node); device: a single ordinal (ilqr_create)."""
+        every GPU of the node); device: a single ordinal (ilqr_create).
+        stage_sources = (StageKinds, C source): distinct per-step objects given as C callables per kind — the route of a host
+        without the symbolic generator (ilqr_compile_model_stages; the Julia wrapper's Solver(dynamics, costs, constraints) with
+        differing objects); dynamics / costs / constraints stay None."""
         L = _ffi.lib()
         model_library = None
         self._selectors = None
-        if model is None:
+        if stage_sources is not None:
+            kinds, source = stage_sources
+            T = kinds.horizon
+            cap = T * (kinds.n_dynamics + kinds.n_costs + kinds.n_constraints)
+            plan, sel = _ffi.StagePlan(), (C.c_double * max(cap, 1))()
+            sd, ad = (C.c_int32 * T)(), (C.c_int32 * max(T - 1, 1))()
+            reg, path = C.create_string_buffer(160), C.create_string_buffer(1024)
+            _ffi.check(L.ilqr_compile_model_stages(name.encode(), C.byref(kinds), source if isinstance(source, bytes) else source.encode(),
+                                                   C.byref(plan), sel, cap, sd, ad, reg, 160, path, 1024))
+            S = plan.n_selectors
+            self._selectors = np.array([sel[i] for i in range(T * S)], dtype=np.float64).reshape(T, S)
+            self.num_user_parameter = kinds.num_parameter
+            self.state_dims, self.action_dims = list(sd), list(ad)[:T - 1]
+            self.constraint_rows = [[plan.constraint_row0[kinds.constraint_of_step[t]] + i
+                                     for i in range(kinds.constraint_nc[kinds.constraint_of_step[t]])] if kinds.n_constraints else []
+                                    for t in range(T - 1)]
+            model, model_library = reg.value.decode(), path.value.decode()
+            horizon = T
+            constrained = True if constraints is None else bool(constraints)
+        elif model is None:
             T = len(costs)
             low = lowering.lower(dynamics, costs, constraints)       # distinct per-step objects -> one stage template
             self._selectors = low["selectors"]
@@ -122,8 +144,9 @@ class Solver:
         _ffi.check(L.ilqr_set_options(self._h, C.byref(self.options)))
         if self._selectors is None or self._selectors.shape[1] == 0:
             self._selectors, self.num_user_parameter = None, self.nw
-        else:                                   # time-varying stage objects: the selectors are part of θ_t
-            self.set_parameters_(np.zeros((self.B, self.T, self.num_user_parameter)))
+        else:      # time-varying stage objects: the handle keeps the selector table and writes it behind the user's parameters in θ_t
+            sel = np.ascontiguousarray(self._selectors, dtype=np.float64)
+            _ffi.check(L.ilqr_set_stage_selectors(self._h, _p(sel), sel.shape[1]))
 
     # -- src/solver.jl:56-66
     def initialize_controls_(self, u):
@@ -151,10 +174,7 @@ class Solver:
     def set_parameters_(self, w):
         """Solver(...; parameters=θ): w[b, t] is the parameter vector of timestep t of instance b."""
         w = np.ascontiguousarray(w, dtype=np.float64).reshape(self.B, self.T, self.num_user_parameter)
-        if self._selectors is not None:
-            w = np.concatenate([w, np.broadcast_to(self._selectors, (self.B,) + self._selectors.shape)], axis=2)
-            w = np.ascontiguousarray(w)
-        _ffi.check(_ffi.lib().ilqr_set_parameters(self._h, _p(w)))
+        _ffi.check(_ffi.lib().ilqr_set_parameters(self._h, _p(w)))      # (selector columns of a lowered problem are the library's)
 
     def reset_(self):
         _ffi.check(_ffi.lib().ilqr_reset(self._h))

@@ -7,6 +7,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -124,6 +125,10 @@ struct ilqr_handle {
     // its own contiguous range of instances [lo[i], lo[i] + shards[i]->B), workspace and stream on its device
     std::vector<ilqr_handle*> shards;
     std::vector<int> lo;
+    // ilqr_set_stage_selectors: the one-hot selector table [T][n_sel] of a lowered problem (distinct per-step objects); it occupies
+    // the LAST n_sel parameter columns of every instance, the caller's ilqr_set_parameters fills the first nw - n_sel
+    std::vector<double> sel;
+    int n_sel = 0;
 };
 
 namespace {
@@ -289,6 +294,9 @@ int ilqr_device_math(const char* fn, const double* x, double* y, int32_t n) {
     double *dx = nullptr, *dy = nullptr;
     hipError_t e;
     auto bail = [&](hipError_t err, const char* what) { if (dx) (void)hipFree(dx); if (dy) (void)hipFree(dy); return fail(ILQR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);                       // the caller's current device is put back below
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev_dev};
     if ((e = hipSetDevice(0)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipMalloc(&dx, (size_t)n * 8)) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMalloc(&dy, (size_t)n * 8)) != hipSuccess) return bail(e, "hipMalloc");
@@ -366,16 +374,21 @@ static int run_child(const std::vector<std::string>& args, const std::string& lo
     return WEXITSTATUS(status);
 }
 
-static ModelStructure probe_model_structure(const ilqr_model_source* src, const std::string& dir, const std::string& tag) {
+// selector columns of a lowered model (ilqr_compile_model_stages): the probe must visit every kind of every category
+struct ProbeHints { int sel[3] = {-1, -1, -1}; int kinds[3] = {0, 0, 0}; };
+
+static ModelStructure probe_model_structure(const ilqr_model_source* src, const std::string& dir, const std::string& tag, const ProbeHints& hints) {
     ModelStructure ms;
     const int n = src->nx, m = src->nu, nw = src->nw, ncs = src->nc_stage, nct = src->nc_term;
+    if (src->flags & ILQR_MODEL_DENSE_TABLES) { ms.note = "disabled for this model (ILQR_MODEL_DENSE_TABLES)"; return ms; }
     if (std::getenv("ILQR_NO_STRUCTURE_PROBE")) { ms.note = "disabled by ILQR_NO_STRUCTURE_PROBE"; return ms; }
     std::string cxx;
     const char* cand[] = {std::getenv("ILQR_HOSTCXX"), "/usr/bin/g++", "/usr/bin/c++", "/usr/bin/clang++", "/opt/rocm/lib/llvm/bin/clang++"};
     for (const char* c : cand)
         if (c && access(c, X_OK) == 0) { cxx = c; break; }
     if (cxx.empty()) { ms.note = "no host C++ compiler (set ILQR_HOSTCXX)"; return ms; }
-    const std::string pid = std::to_string((long)getpid());
+    static std::atomic<unsigned> probe_seq{0};          // two threads of one process compiling the same model must not share temp files
+    const std::string pid = std::to_string((long)getpid()) + "_" + std::to_string(probe_seq.fetch_add(1));
     const std::string cpp = dir + "/probe_" + tag + "." + pid + ".cpp", so = dir + "/probe_" + tag + "." + pid + ".so", log = dir + "/probe_" + tag + "." + pid + ".log";
     FILE* f = std::fopen(cpp.c_str(), "w");
     if (!f) { ms.note = "cannot write " + cpp; return ms; }
@@ -397,16 +410,23 @@ static ModelStructure probe_model_structure(const ilqr_model_source* src, const 
     typedef void (*probe_fn)(int, double*, const double*, const double*, const double*);
     probe_fn pf = hl ? (probe_fn)dlsym(hl, "ilqr_probe") : nullptr;
     if (!pf) { ms.note = "cannot load the host build of the callables"; if (hl) dlclose(hl); cleanup(); return ms; }
-    const int P = 3;
+    // 48 points: magnitudes 1e-3, 0.03, 1, 30, 1e3 per point (every argument of a point at the same scale, so that small and large
+    // regimes are each seen whole) and mixed scales per component on the rest, both signs; x, u and w alike. What this cannot
+    // see is a piecewise callable whose pieces have the same derivative on all of them: see ilqr_hip.h (ILQR_MODEL_DENSE_TABLES).
+    const int P = 48;
     const int sizes[9] = {n * n, n * m, n * n, m * m, m * n, n * n, ncs * n, ncs * m, nct * n};
     std::vector<std::vector<double>> val[9];
     unsigned long long seed = 0x9E3779B97F4A7C15ull;
-    auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return -1.3 + 3.0 * (double)(seed >> 11) / 9007199254740992.0; };
+    auto uni = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (double)(seed >> 11) / 9007199254740992.0; };
+    const double scales[5] = {1.0e-3, 3.0e-2, 1.0, 30.0, 1.0e3};
     for (int p = 0; p < P; ++p) {
         std::vector<double> x(n), u(m), w(nw > 0 ? nw : 1);
-        for (auto& v : x) v = rnd();
-        for (auto& v : u) v = rnd();
-        for (auto& v : w) v = rnd();
+        auto draw = [&]() { const double sc = p < 30 ? scales[p % 5] : scales[(int)(uni() * 5.0) % 5]; return (uni() < 0.5 ? -1.0 : 1.0) * sc * (0.35 + 1.3 * uni()); };
+        for (auto& v : x) v = draw();
+        for (auto& v : u) v = draw();
+        for (auto& v : w) v = draw();
+        for (int c = 0; c < 3; ++c)                                  // one-hot selectors: every kind of every category in turn
+            for (int k = 0; k < hints.kinds[c]; ++k) w[hints.sel[c] + k] = (k == (p / (c == 0 ? 1 : (c == 1 ? 2 : 3))) % hints.kinds[c]) ? 1.0 : 0.0;
         for (int k = 0; k < 9; ++k) {
             std::vector<double> o((size_t)(sizes[k] > 0 ? sizes[k] : 1), 0.0);
             const bool have = k < 6 || (k < 8 ? ncs > 0 : nct > 0);
@@ -416,7 +436,8 @@ static ModelStructure probe_model_structure(const ilqr_model_source* src, const 
     }
     dlclose(hl);
     cleanup();
-    auto same = [&](int k, int e) { for (int p = 1; p < P; ++p) if (std::memcmp(&val[k][p][e], &val[k][0][e], 8) != 0) return false; return true; };
+    // a NaN / Inf compares bitwise equal to itself: such an entry is never a constant
+    auto same = [&](int k, int e) { for (int p = 0; p < P; ++p) if (!std::isfinite(val[k][p][e]) || std::memcmp(&val[k][p][e], &val[k][0][e], 8) != 0) return false; return true; };
     auto nonzero = [&](int k, int e) { for (int p = 0; p < P; ++p) if (val[k][p][e] != 0.0 || val[k][p][e] != val[k][p][e]) return true; return false; };
     ms.fxc.assign(n * n, 0.0); ms.fuc.assign(n * m, 0.0);
     for (int e = 0; e < n * n; ++e) { if (same(0, e)) ms.fxc[e] = val[0][0][e]; else ms.jac_var.push_back(e); }
@@ -456,7 +477,7 @@ static ModelStructure probe_model_structure(const ilqr_model_source* src, const 
 
 // Dynamics / Cost / Constraint constructors for hosts without Python: C source of the reference's callables -> model module.
 static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
-                              char* registered_name, size_t name_len, char* library_path, size_t path_len);
+                              char* registered_name, size_t name_len, char* library_path, size_t path_len, const ProbeHints& hints = ProbeHints());
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len) {
     if (src && (src->nc_stage > 64 || src->nc_term > 64))
         return fail(ILQR_ERR_INVALID, "ilqr_compile_model: at most 64 constraint rows per stage fit the 64-bit inequality masks — "
@@ -470,7 +491,7 @@ int ilqr_compile_model_rows(const ilqr_model_source* src, const uint64_t* ineq_s
     return compile_model_impl(src, ineq_stage_words, ineq_term_words, registered_name, name_len, library_path, path_len);
 }
 static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
-                              char* registered_name, size_t name_len, char* library_path, size_t path_len) {
+                              char* registered_name, size_t name_len, char* library_path, size_t path_len, const ProbeHints& hints) {
     if (!src || !src->name || !src->source || !registered_name || !library_path)
         return fail(ILQR_ERR_INVALID, "null argument");
     if (src->nx < 1 || src->nx > 64 || src->nu < 1 || src->nu > 16 || src->nw < 0 || src->nc_stage < 0 || src->nc_stage > ILQR_MAX_CONSTRAINT_ROWS ||
@@ -508,13 +529,27 @@ static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq
 #ifdef ILQR_BUILD_HASH
     mix(ILQR_BUILD_HASH, std::strlen(ILQR_BUILD_HASH));
 #endif
-    const char* probe_off = std::getenv("ILQR_NO_STRUCTURE_PROBE");
-    mix(probe_off ? "dense" : "probed", 6);
+    // The tables a large model is built with are part of its identity: the probe runs BEFORE the name is formed and what it
+    // found (or that it found nothing: no host compiler, source that is not host C++, probe switched off) goes into the hash —
+    // a module cached on a box where probing was impossible is not served where it works, and the reverse.
+    const std::string dir = libdir + "/models";
+    mkdir(dir.c_str(), 0755);
+    const bool large = src->nx > 4 || src->nu > 4;
+    ModelStructure ms;
+    if (large) {
+        char ptag[32];
+        std::snprintf(ptag, sizeof(ptag), "%016llx", hsh);
+        ms = probe_model_structure(src, dir, ptag, hints);
+        mix(ms.found ? "probed" : "dense", 6);
+        if (ms.found) {
+            mix(ms.fxc.data(), ms.fxc.size() * 8); mix(ms.fuc.data(), ms.fuc.size() * 8);
+            if (!ms.jac_var.empty()) mix(ms.jac_var.data(), ms.jac_var.size() * sizeof(int));
+            if (!ms.hess_idx.empty()) mix(ms.hess_idx.data(), ms.hess_idx.size() * sizeof(int));
+        }
+    }
     char tag[32];
     std::snprintf(tag, sizeof(tag), "%016llx", hsh);
     const std::string uname = std::string(src->name) + "_c" + tag;
-    const std::string dir = libdir + "/models";
-    mkdir(dir.c_str(), 0755);
     // source and log are written under process-unique names: ranks compiling the same model at the same time must not truncate
     // each other's input under a running hipcc (the module itself is moved into place atomically)
     const std::string pid = std::to_string((long)getpid());
@@ -545,10 +580,8 @@ static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq
         std::fprintf(f, "};\n");
         // nx > 4 or nu > 4: the compact forms of the large path — with the constant / zero entries found by probing the callables
         // on the host (probe_model_structure), dense when that is not possible
-        const bool large = src->nx > 4 || src->nu > 4;
         std::string tables;
         if (large) {
-            const ModelStructure ms = probe_model_structure(src, dir, tag);
             if (ms.found) {
                 const int nn = src->nx, mm = src->nu, TNt = (nn + 15) / 16;
                 auto ilist = [](const std::vector<int>& v, size_t lo, size_t hi) { std::string o; for (size_t i = lo; i < hi; ++i) o += std::to_string(v[i]) + ","; if (hi == lo) o = "0"; return o; };
@@ -626,6 +659,196 @@ int ilqr_model_compact_sizes(const char* model, int32_t* jac_nvar, int32_t* hess
     if (jac_nvar) *jac_nvar = vt->jac_nvar;
     if (hess_nnz) *hess_nnz = vt->hess_nnz;
     return ILQR_OK;
+}
+
+// ---- Vectors of distinct per-step objects / time-varying dimensions, lowered onto the one-stage template (ilqr_hip.h).
+// What the reference does by indexing a Vector of objects with t (src/solver.jl:28-46, src/gradients.jl:1-21, src/rollout.jl:22-30)
+// becomes: one combined callable per category that branches on one-hot selector parameters, constraint kinds stacked row-wise,
+// every kind zero-padded to the largest dimensions of the horizon.
+int ilqr_plan_stages(const ilqr_stage_kinds* k, ilqr_stage_plan* plan, double* selectors, size_t selectors_len,
+                     int32_t* state_dims, int32_t* action_dims) {
+    if (!k || !plan) return fail(ILQR_ERR_INVALID, "null argument");
+    const int T = k->horizon, N = T - 1;
+    if (T < 2) return fail(ILQR_ERR_INVALID, "horizon must be >= 2");
+    if (k->n_dynamics < 1 || k->n_dynamics > ILQR_MAX_STAGE_KINDS || k->n_costs < 1 || k->n_costs > ILQR_MAX_STAGE_KINDS ||
+        k->n_constraints < 0 || k->n_constraints > ILQR_MAX_STAGE_KINDS)
+        return fail(ILQR_ERR_INVALID, "1 .. 16 dynamics kinds, 1 .. 16 stage-cost kinds, 0 .. 16 stage-constraint kinds");
+    if (!k->dynamics_nx || !k->dynamics_nu || !k->dynamics_nx_next || !k->dynamics_of_step || !k->cost_nx || !k->cost_nu || !k->cost_of_step ||
+        (k->n_constraints > 0 && (!k->constraint_nc || !k->constraint_nx || !k->constraint_nu || !k->constraint_ineq || !k->constraint_of_step)))
+        return fail(ILQR_ERR_INVALID, "null kind table");
+    if (k->num_parameter < 0 || k->nc_term < 0 || k->nc_term > ILQR_MAX_CONSTRAINT_ROWS) return fail(ILQR_ERR_INVALID, "num_parameter >= 0, 0 <= nc_term <= 256");
+    std::memset(plan, 0, sizeof(*plan));
+    // dimensions along the horizon (src/data/problem.jl:32-38) and the consistency the reference's broadcasts would enforce
+    std::vector<int> nt(T), mt(N);
+    for (int t = 0; t < N; ++t) {
+        const int d = k->dynamics_of_step[t], c = k->cost_of_step[t];
+        if (d < 0 || d >= k->n_dynamics || c < 0 || c >= k->n_costs) return fail(ILQR_ERR_INVALID, "kind index out of range at step " + std::to_string(t));
+        nt[t] = k->dynamics_nx[d]; mt[t] = k->dynamics_nu[d];
+        if (nt[t] < 1 || mt[t] < 1 || k->dynamics_nx_next[d] < 1) return fail(ILQR_ERR_INVALID, "dimensions must be >= 1");
+        if (t > 0 && k->dynamics_nx_next[k->dynamics_of_step[t - 1]] != nt[t])
+            return fail(ILQR_ERR_INVALID, "dynamics[" + std::to_string(t - 1) + "] does not produce the state of step " + std::to_string(t));
+        if (k->cost_nx[c] != nt[t] || k->cost_nu[c] != mt[t]) return fail(ILQR_ERR_INVALID, "cost[" + std::to_string(t) + "] dimensions are not its step's");
+        if (k->n_constraints > 0) {
+            const int q = k->constraint_of_step[t];
+            if (q < 0 || q >= k->n_constraints) return fail(ILQR_ERR_INVALID, "constraint kind index out of range at step " + std::to_string(t));
+            if (k->constraint_nc[q] < 0 || k->constraint_nc[q] > ILQR_MAX_CONSTRAINT_ROWS) return fail(ILQR_ERR_INVALID, "at most 256 rows per constraint kind");
+            if (k->constraint_nc[q] > 0 && (k->constraint_nx[q] != nt[t] || k->constraint_nu[q] != mt[t]))
+                return fail(ILQR_ERR_INVALID, "constraint[" + std::to_string(t) + "] dimensions are not its step's");
+        }
+    }
+    nt[N] = k->dynamics_nx_next[k->dynamics_of_step[N - 1]];
+    if (k->nx_term != nt[N]) return fail(ILQR_ERR_INVALID, "the terminal objects' num_state is not the last dynamics' num_next_state");
+    int n = 0, m = 0;
+    for (int t = 0; t < T; ++t) n = std::max(n, nt[t]);
+    for (int t = 0; t < N; ++t) m = std::max(m, mt[t]);
+    plan->nx = n; plan->nu = m; plan->nc_term = k->nc_term;
+    // stacked stage constraint: kind q owns rows [row0[q], row0[q] + nc_q)
+    int rows = 0;
+    for (int q = 0; q < k->n_constraints; ++q) {
+        plan->constraint_row0[q] = rows;
+        for (int i = 0; i < k->constraint_nc[q] && i < ILQR_MAX_CONSTRAINT_ROWS; ++i)
+            if ((k->constraint_ineq[4 * q + i / 64] >> (i % 64)) & 1ull) {
+                const int r = rows + i;
+                if (r < ILQR_MAX_CONSTRAINT_ROWS) plan->ineq_stage_words[r / 64] |= 1ull << (r % 64);
+            }
+        rows += k->constraint_nc[q];
+    }
+    if (rows > ILQR_MAX_CONSTRAINT_ROWS) return fail(ILQR_ERR_INVALID, "at most 256 stage constraint rows over all kinds");
+    plan->nc_stage = rows;
+    // selector blocks: one per category that really varies, in the order dynamics, cost, constraint, behind the user's parameters
+    int off = k->num_parameter;
+    plan->sel_dynamics = plan->sel_cost = plan->sel_constraint = -1;
+    const bool uniform = k->n_dynamics == 1 && k->n_costs == 1 && k->n_constraints <= 1;
+    if (!uniform) {
+        if (k->n_dynamics > 1) { plan->sel_dynamics = off; off += k->n_dynamics; }
+        if (k->n_costs > 1) { plan->sel_cost = off; off += k->n_costs; }
+        if (k->n_constraints > 1) { plan->sel_constraint = off; off += k->n_constraints; }
+    }
+    plan->nw = off; plan->n_selectors = off - k->num_parameter;
+    const int S = plan->n_selectors;
+    if (selectors) {
+        if (selectors_len < (size_t)T * (size_t)S) return fail(ILQR_ERR_INVALID, "selector buffer too small");
+        std::fill(selectors, selectors + (size_t)T * S, 0.0);
+        for (int t = 0; t < N; ++t) {
+            double* row = selectors + (size_t)t * S - k->num_parameter;          // indexed by parameter column
+            if (plan->sel_dynamics >= 0) row[plan->sel_dynamics + k->dynamics_of_step[t]] = 1.0;
+            if (plan->sel_cost >= 0) row[plan->sel_cost + k->cost_of_step[t]] = 1.0;
+            if (plan->sel_constraint >= 0) row[plan->sel_constraint + k->constraint_of_step[t]] = 1.0;
+        }
+    }
+    if (state_dims) for (int t = 0; t < T; ++t) state_dims[t] = nt[t];
+    if (action_dims) for (int t = 0; t < N; ++t) action_dims[t] = mt[t];
+    return ILQR_OK;
+}
+
+// The combined callables of the template, as C source around the kinds' own callables (which live in namespace kinds).
+static std::string compose_stage_source(const ilqr_stage_kinds* k, const ilqr_stage_plan& pl, const char* user_source) {
+    const int n = pl.nx, m = pl.nu;
+    std::string o = "namespace kinds {\n" + std::string(user_source) + "\n}\n";
+    const std::string sig = "(double* o, const double* x, const double* u, const double* w)";
+    auto S = [](int v) { return std::to_string(v); };
+    // `if (w[sel + k] > 0.5)` chain of a category; a category with one kind calls it unconditionally
+    auto branch = [&](int sel, int kinds, int kk) {
+        if (sel < 0 || kinds <= 1) return std::string("    {\n");
+        return std::string(kk == 0 ? "    if" : "    else if") + " (w[" + S(sel + kk) + "] > 0.5) {\n";
+    };
+    // call NAME into a (rows x cols, leading dimension ld_k) scratch and copy into o with leading dimension ld at row offset r0;
+    // direct when the layouts coincide
+    auto mat = [&](const std::string& name, int rows_k, int cols_k, int ld, int r0) {
+        if (rows_k == ld && r0 == 0) return "        kinds::" + name + "(o, x, u, w);\n";
+        if (rows_k * cols_k == 0) return std::string();
+        std::string c = "        double t[" + S(rows_k * cols_k) + "];\n        for (int i = 0; i < " + S(rows_k * cols_k) + "; ++i) t[i] = 0.0;\n";
+        c += "        kinds::" + name + "(t, x, u, w);\n";
+        c += "        for (int c = 0; c < " + S(cols_k) + "; ++c) for (int r = 0; r < " + S(rows_k) + "; ++r) o[c * " + S(ld) + " + " + S(r0) + " + r] = t[c * " + S(rows_k) + " + r];\n";
+        return c;
+    };
+    // ---- Dynamics (src/dynamics.jl:36-50): jacobian_state is num_next_state x num_state, jacobian_action num_next_state x num_action
+    const char* dsuf[3] = {"", "_jacobian_state", "_jacobian_action"};
+    for (int f = 0; f < 3; ++f) {
+        o += "ILQR_MODEL_FN void dynamics" + std::string(dsuf[f]) + sig + " {\n";
+        for (int q = 0; q < k->n_dynamics; ++q) {
+            const std::string nm = "dynamics_" + S(q) + dsuf[f];
+            o += branch(pl.sel_dynamics, k->n_dynamics, q);
+            if (f == 0) o += "        kinds::" + nm + "(o, x, u, w);\n";
+            else o += mat(nm, k->dynamics_nx_next[q], f == 1 ? k->dynamics_nx[q] : k->dynamics_nu[q], n, 0);
+            o += "    }\n";
+        }
+        o += "}\n";
+    }
+    // ---- stage Cost (src/costs.jl:48-84); padded actions cost u^2 / 2
+    const char* csuf[6] = {"", "_gradient_state", "_gradient_action", "_hessian_state_state", "_hessian_action_action", "_hessian_action_state"};
+    for (int f = 0; f < 6; ++f) {
+        o += "ILQR_MODEL_FN void cost_stage" + std::string(csuf[f]) + sig + " {\n";
+        for (int q = 0; q < k->n_costs; ++q) {
+            const std::string nm = "cost_stage_" + S(q) + csuf[f];
+            const int n0 = k->cost_nx[q], m0 = k->cost_nu[q];
+            o += branch(pl.sel_cost, k->n_costs, q);
+            if (f == 0) {
+                o += "        kinds::" + nm + "(o, x, u, w);\n";
+                if (m0 < m) {
+                    std::string sum;
+                    for (int j = m0; j < m; ++j) sum += (j > m0 ? " + " : "") + ("u[" + S(j) + "] * u[" + S(j) + "]");
+                    o += "        o[0] = o[0] + (" + sum + ") / 2.0;\n";
+                }
+            } else if (f == 1) o += "        kinds::" + nm + "(o, x, u, w);\n";
+            else if (f == 2) {
+                o += "        kinds::" + nm + "(o, x, u, w);\n";
+                for (int j = m0; j < m; ++j) o += "        o[" + S(j) + "] = u[" + S(j) + "];\n";
+            } else if (f == 3) o += mat(nm, n0, n0, n, 0);
+            else if (f == 4) {
+                o += mat(nm, m0, m0, m, 0);
+                for (int j = m0; j < m; ++j) o += "        o[" + S(j * m + j) + "] = 1.0;\n";
+            } else o += mat(nm, m0, n0, m, 0);
+            o += "    }\n";
+        }
+        o += "}\n";
+    }
+    // ---- terminal Cost: num_state = nx_term
+    o += "ILQR_MODEL_FN void cost_terminal" + sig + " { kinds::cost_terminal(o, x, u, w); }\n";
+    o += "ILQR_MODEL_FN void cost_terminal_gradient_state" + sig + " { kinds::cost_terminal_gradient_state(o, x, u, w); }\n";
+    o += "ILQR_MODEL_FN void cost_terminal_hessian_state_state" + sig + " {\n    {\n" + mat("cost_terminal_hessian_state_state", k->nx_term, k->nx_term, n, 0) + "    }\n}\n";
+    // ---- stage Constraint (src/constraints.jl:66-87): kinds stacked, kind q at rows row0[q] ..
+    if (pl.nc_stage > 0) {
+        const char* ksuf[3] = {"", "_jacobian_state", "_jacobian_action"};
+        for (int f = 0; f < 3; ++f) {
+            o += "ILQR_MODEL_FN void constraint_stage" + std::string(ksuf[f]) + sig + " {\n";
+            bool first = true;
+            for (int q = 0; q < k->n_constraints; ++q) {
+                if (k->constraint_nc[q] == 0) continue;
+                const std::string nm = "constraint_stage_" + S(q) + ksuf[f];
+                if (pl.sel_constraint < 0) o += "    {\n";
+                else o += std::string(first ? "    if" : "    else if") + " (w[" + S(pl.sel_constraint + q) + "] > 0.5) {\n";
+                first = false;
+                if (f == 0) o += "        kinds::" + nm + "(o + " + S(pl.constraint_row0[q]) + ", x, u, w);\n";
+                else o += mat(nm, k->constraint_nc[q], f == 1 ? k->constraint_nx[q] : k->constraint_nu[q], pl.nc_stage, pl.constraint_row0[q]);
+                o += "    }\n";
+            }
+            o += "}\n";
+        }
+    }
+    // ---- terminal Constraint: nc_term x nx_term, column-major with leading dimension nc_term — the template's nc_term x nx has the same
+    if (k->nc_term > 0) {
+        o += "ILQR_MODEL_FN void constraint_terminal" + sig + " { kinds::constraint_terminal(o, x, u, w); }\n";
+        o += "ILQR_MODEL_FN void constraint_terminal_jacobian_state" + sig + " { kinds::constraint_terminal_jacobian_state(o, x, u, w); }\n";
+    }
+    return o;
+}
+
+int ilqr_compile_model_stages(const char* name, const ilqr_stage_kinds* kinds, const char* source, ilqr_stage_plan* plan,
+                              double* selectors, size_t selectors_len, int32_t* state_dims, int32_t* action_dims,
+                              char* registered_name, size_t name_len, char* library_path, size_t path_len) {
+    if (!name || !kinds || !source || !plan) return fail(ILQR_ERR_INVALID, "null argument");
+    const int rc = ilqr_plan_stages(kinds, plan, selectors, selectors_len, state_dims, action_dims);
+    if (rc != ILQR_OK) return rc;
+    const std::string combined = compose_stage_source(kinds, *plan, source);
+    ilqr_model_source ms;
+    ms.name = name; ms.nx = plan->nx; ms.nu = plan->nu; ms.nw = plan->nw; ms.nc_stage = plan->nc_stage; ms.nc_term = plan->nc_term;
+    ms.ineq_stage = plan->ineq_stage_words[0]; ms.ineq_term = kinds->ineq_term[0]; ms.source = combined.c_str(); ms.flags = 0;
+    ProbeHints hints;
+    hints.sel[0] = plan->sel_dynamics; hints.kinds[0] = plan->sel_dynamics >= 0 ? kinds->n_dynamics : 0;
+    hints.sel[1] = plan->sel_cost; hints.kinds[1] = plan->sel_cost >= 0 ? kinds->n_costs : 0;
+    hints.sel[2] = plan->sel_constraint; hints.kinds[2] = plan->sel_constraint >= 0 ? kinds->n_constraints : 0;
+    return compile_model_impl(&ms, plan->ineq_stage_words, kinds->ineq_term, registered_name, name_len, library_path, path_len, hints);
 }
 
 int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
@@ -744,7 +967,7 @@ int ilqr_get_dims(const ilqr_handle* h, int32_t* nx, int32_t* nu, int32_t* nw, i
     if (!h) return fail(ILQR_ERR_INVALID, "null handle");
     if (nx) *nx = h->vt->nx;
     if (nu) *nu = h->vt->nu;
-    if (nw) *nw = h->vt->nw;
+    if (nw) *nw = h->vt->nw - h->n_sel;          // the USER's parameters per timestep (selector columns are the library's)
     if (ncs) *ncs = h->vt->ncs;
     if (nct) *nct = h->vt->nct;
     if (horizon) *horizon = h->L.T;
@@ -791,10 +1014,39 @@ int ilqr_initialize_states(ilqr_handle* h, const double* x) {
     return copy_in(h, find_buffer(h, "nominal_states"), x);
 }
 
+// the full parameter block [B][T][nw] of a handle with selectors: the user's columns (NULL = zeros) followed by the table
+static int write_parameters_with_selectors(ilqr_handle* h, const double* w_user) {
+    const int T = h->L.T, nw = h->vt->nw, S = h->n_sel, nwu = nw - S;
+    std::vector<double> full((size_t)h->B * T * nw, 0.0);
+    for (int b = 0; b < h->B; ++b)
+        for (int t = 0; t < T; ++t) {
+            double* row = &full[((size_t)b * T + t) * nw];
+            if (w_user) for (int j = 0; j < nwu; ++j) row[j] = w_user[((size_t)b * T + t) * nwu + j];
+            for (int j = 0; j < S; ++j) row[nwu + j] = h->sel[(size_t)t * S + j];
+        }
+    return copy_in(h, find_buffer(h, "parameters"), full.data());
+}
+
+int ilqr_set_stage_selectors(ilqr_handle* h, const double* selectors, int32_t n_selectors) {
+    if (!h || n_selectors < 0 || (n_selectors > 0 && !selectors)) return fail(ILQR_ERR_INVALID, "null argument");
+    if (n_selectors > h->vt->nw) return fail(ILQR_ERR_INVALID, "more selector columns than the model has parameters");
+    if (SHARDED(h)) {
+        const int rc = each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_stage_selectors(s, selectors, n_selectors); }, true);
+        if (rc == ILQR_OK) { h->n_sel = n_selectors; h->sel.assign(selectors, selectors + (size_t)h->L.T * n_selectors); }
+        return rc;
+    }
+    h->n_sel = n_selectors;
+    h->sel.assign(selectors, selectors + (size_t)h->L.T * n_selectors);
+    if (n_selectors == 0) return ILQR_OK;
+    return write_parameters_with_selectors(h, nullptr);
+}
+
 int ilqr_set_parameters(ilqr_handle* h, const double* w) {
     if (!h || !w) return fail(ILQR_ERR_INVALID, "null argument");
-    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_set_parameters(s, w + lo * (size_t)h->L.T * h->L.nw); }, true);
-    if (h->vt->nw == 0) return fail(ILQR_ERR_INVALID, "this model has no parameters (num_parameter == 0)");
+    const size_t nwu = (size_t)(h->L.nw - h->n_sel);
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t lo) { return ilqr_set_parameters(s, w + lo * (size_t)h->L.T * nwu); }, true);
+    if (nwu == 0) return fail(ILQR_ERR_INVALID, "this model has no parameters (num_parameter == 0)");
+    if (h->n_sel > 0) return write_parameters_with_selectors(h, w);
     return copy_in(h, find_buffer(h, "parameters"), w);
 }
 

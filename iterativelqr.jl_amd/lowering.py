@@ -57,9 +57,9 @@ def _kinds(objs):
     return kinds, index
 
 
-def lower(dynamics, costs, constraints=None):
-    """-> dict(dynamics, cost_stage, cost_term, con_stage, con_term, num_user_parameter, selectors[T, S],
-    constraint_rows[t] = device rows of the stage constraint that belong to step t)."""
+def stage_kinds(dynamics, costs, constraints=None):
+    """The problem's objects as ilqr_stage_kinds (include/ilqr_hip.h): distinct kinds per category and the kind of every step."""
+    from . import _ffi
     T = len(costs)
     assert len(dynamics) == T - 1, "need T-1 dynamics and T costs"                    # src/data/problem.jl:30
     assert constraints is None or len(constraints) == T
@@ -68,36 +68,38 @@ def lower(dynamics, costs, constraints=None):
     kk, ki = _kinds(constraints[:-1]) if constraints is not None else ([], [])
     cost_term = costs[-1]
     con_term = constraints[-1] if constraints is not None else None
-    # dimensions along the horizon (src/dynamics.jl:5-7: num_next_state may differ from num_state)
-    n_t = [d.num_state for d in dynamics] + [dynamics[-1].num_next_state]
-    m_t = [d.num_action for d in dynamics]
-    for t in range(T - 1):
-        assert dynamics[t].num_next_state == n_t[t + 1], "dynamics[%d] does not produce the state of step %d" % (t, t + 1)
-        assert (costs[t].num_state, costs[t].num_action) == (n_t[t], m_t[t]), "cost[%d] dimensions" % t
-        if constraints is not None and constraints[t].num_constraint:
-            assert (constraints[t].num_state, constraints[t].num_action) == (n_t[t], m_t[t]), "constraint[%d] dimensions" % t
-    assert cost_term.num_state == n_t[-1]
-    assert con_term is None or con_term.num_constraint == 0 or con_term.num_state == n_t[-1]
-    n, m = max(n_t), max(m_t)
     everything = dk + ck + kk + [cost_term] + ([con_term] if con_term is not None else [])
     nwu = max(o.num_parameter for o in everything)
-    if len(dk) == 1 and len(ck) == 1 and len(kk) <= 1:
+    mask = lambda c: sum(1 << (i - 1) for i in c.indices_inequality)          # indices_inequality is 1-based like the reference
+    nct = con_term.num_constraint if con_term is not None else 0
+    k = _ffi.stage_kinds(T, nwu, [(d.num_state, d.num_action, d.num_next_state) for d in dk], di,
+                         [(c.num_state, c.num_action) for c in ck], ci,
+                         [(c.num_constraint, c.num_state, c.num_action, mask(c)) for c in kk], ki,
+                         cost_term.num_state, nct, mask(con_term) if nct else 0)
+    return k, (dk, ck, kk, ki, cost_term, con_term, nwu)
+
+
+def lower(dynamics, costs, constraints=None):
+    """-> dict(dynamics, cost_stage, cost_term, con_stage, con_term, num_user_parameter, selectors[T, S],
+    constraint_rows[t] = device rows of the stage constraint that belong to step t).
+
+    The PLAN — template dimensions, selector columns and table, row offsets of the stacked constraint kinds, consistency of the
+    chain of dimensions — comes from the library (ilqr_plan_stages, the same code a Julia or C host reaches through
+    ilqr_compile_model_stages); what is done here is only what needs the symbolic objects: finding the distinct kinds and
+    gating their expressions by the plan's selector columns."""
+    from . import _ffi
+    T = len(costs)
+    kinds, (dk, ck, kk, ki, cost_term, con_term, nwu) = stage_kinds(dynamics, costs, constraints)
+    plan, sel_rows, n_t, m_t = _ffi.plan_stages(kinds)         # raises IlqrError on an inconsistent chain of dimensions
+    n, m, nw = plan.nx, plan.nu, plan.nw
+    if plan.n_selectors == 0 and len(dk) == 1 and len(ck) == 1 and len(kk) <= 1:
         return dict(dynamics=dk[0], cost_stage=ck[0], cost_term=cost_term, con_stage=kk[0] if kk else None,
                     con_term=con_term, num_user_parameter=nwu, selectors=np.zeros((T, 0)),
                     constraint_rows=[list(range(kk[0].num_constraint if kk else 0))] * (T - 1),
                     state_dims=n_t, action_dims=m_t)
-    # selector columns: one block per category that really varies
-    off, blocks = nwu, {}
-    for name, kinds in (("dynamics", dk), ("cost", ck), ("constraint", kk)):
-        if len(kinds) > 1:
-            blocks[name] = off
-            off += len(kinds)
-    nw = off
-    sel = np.zeros((T, nw - nwu))
-    for t in range(T - 1):
-        for name, idx in (("dynamics", di), ("cost", ci), ("constraint", ki)):
-            if name in blocks:
-                sel[t, blocks[name] - nwu + idx[t]] = 1.0
+    blocks = {name: col for name, col in (("dynamics", plan.sel_dynamics), ("cost", plan.sel_cost), ("constraint", plan.sel_constraint))
+              if col >= 0}
+    sel = np.array(sel_rows, dtype=np.float64).reshape(T, plan.n_selectors)
 
     def gate(name, k, w, expr):
         """expr where kind k of the category is selected at this step, 0 elsewhere — a real SELECT (ternary in the generated
@@ -121,11 +123,9 @@ def lower(dynamics, costs, constraints=None):
     con_stage = con_term_l = None
     rows = [[] for _ in range(T - 1)]
     if constraints is not None:
-        row0, ineq = [], []
-        for k, c in enumerate(kk):
-            row0.append(sum(q.num_constraint for q in kk[:k]))
-            ineq += [row0[k] + i for i in c.indices_inequality]
-        total = sum(q.num_constraint for q in kk)
+        row0 = [plan.constraint_row0[k] for k in range(len(kk))]
+        total = plan.nc_stage
+        ineq = [i + 1 for i in range(total) if (plan.ineq_stage_words[i // 64] >> (i % 64)) & 1]
         assert total <= MAX_CONSTRAINT_ROWS, "at most %d stage constraint rows over all kinds" % MAX_CONSTRAINT_ROWS
         if total:
             con_stage = Constraint(lambda x, u, w: [gate("constraint", k, w, e) for k, c in enumerate(kk) for e in c.evaluate],

@@ -180,6 +180,93 @@ def car_tv(T):
     return dynamics, costs, constraints
 
 
+# ---------------------------------------------------------------- ragged: time-varying DIMENSIONS (src/dynamics.jl:5-7, README.md:26)
+RAGGED_N, RAGGED_M = [3, 3, 4, 4, 2, 2, 3, 3], [2, 1, 2, 1, 1, 2, 2, 1]
+
+
+def _ragged_tables(n0, m0, n1):
+    A = [[(0.9 if i == j else 0.0) + 0.1 * math.cos(1.0 + i + 2 * j + n0) for j in range(n0)] for i in range(n1)]
+    Bm = [[0.3 * math.sin(2.0 + 3 * i + j + m0) for j in range(m0)] for i in range(n1)]
+    return A, Bm
+
+
+def ragged(T):
+    """num_state = 3,3,4,4,2,2,3,3 | ..., num_action = 2,1,2,1,1,2,2,1 | ... (period 8): y_i = sum_j A_ij x_j + sum_j B_ij u_j +
+    [i == 0] 0.1 sin x_0 per step, quadratic costs, a terminal equality on the first two states. Twins: oracle/models.cpp "ragged",
+    tests/golden/reference_restatement.py:ragged_problem. Returns (dynamics[T-1], costs[T], constraints[T], state_dims, action_dims)."""
+    n_t = [RAGGED_N[t % 8] for t in range(T)]
+    m_t = [RAGGED_M[t % 8] for t in range(T - 1)]
+    dyn_cache, cost_cache = {}, {}
+
+    def dyn(n0, m0, n1):
+        if (n0, m0, n1) not in dyn_cache:
+            A, Bm = _ragged_tables(n0, m0, n1)
+            dyn_cache[(n0, m0, n1)] = Dynamics(
+                lambda x, u: [sum(A[i][j] * x[j] for j in range(n0)) + sum(Bm[i][j] * u[j] for j in range(m0))
+                              + (0.1 * sp.sin(x[0]) if i == 0 else 0.0) for i in range(n1)], n0, m0)
+        return dyn_cache[(n0, m0, n1)]
+
+    def cost(n0, m0):
+        if (n0, m0) not in cost_cache:
+            cost_cache[(n0, m0)] = Cost(lambda x, u: 0.5 * sum((1.0 + 0.1 * i) * x[i] * x[i] for i in range(n0))
+                                        + 0.05 * sum((1.0 + j) * u[j] * u[j] for j in range(m0)), n0, m0)
+        return cost_cache[(n0, m0)]
+
+    dynamics = [dyn(n_t[t], m_t[t], n_t[t + 1]) for t in range(T - 1)]
+    costs = [cost(n_t[t], m_t[t]) for t in range(T - 1)] + [Cost(lambda x, u: 5.0 * sum(x[i] * x[i] for i in range(n_t[-1])), n_t[-1], 0)]
+    none = Constraint()
+    goal = Constraint(lambda x, u: [x[0] - 0.2, x[1] + 0.1], n_t[-1], 0)
+    return dynamics, costs, [none] * (T - 1) + [goal], n_t, m_t
+
+
+def ragged_c_stages(T):
+    """The same problem as C source of the reference's callables PER KIND, for ilqr_compile_model_stages — what a Julia or C host
+    hands over when the objects of a Solver differ along the horizon. Returns (StageKinds, source)."""
+    from . import _ffi
+    n_t = [RAGGED_N[t % 8] for t in range(T)]
+    m_t = [RAGGED_M[t % 8] for t in range(T - 1)]
+    dk, ck, di, ci = [], [], [], []
+    for t in range(T - 1):
+        kd, kc = (n_t[t], m_t[t], n_t[t + 1]), (n_t[t], m_t[t])
+        if kd not in dk:
+            dk.append(kd)
+        if kc not in ck:
+            ck.append(kc)
+        di.append(dk.index(kd)); ci.append(ck.index(kc))
+    src = ["/* GENERATED by iterativelqr.jl_amd/models.py:ragged_c_stages(%d): per-kind callables, each in its own dimensions, `out` column-major and zeroed */" % T]
+    g = lambda v: "%.17g" % v
+    for q, (n0, m0, n1) in enumerate(dk):
+        A, Bm = _ragged_tables(n0, m0, n1)
+        body = []
+        for i in range(n1):
+            terms = ["%s * x[%d]" % (g(A[i][j]), j) for j in range(n0)] + ["%s * u[%d]" % (g(Bm[i][j]), j) for j in range(m0)]
+            body.append("    y[%d] = %s%s;" % (i, " + ".join(terms), " + 0.1 * sin(x[0])" if i == 0 else ""))
+        src.append("ILQR_MODEL_FN void dynamics_%d(double* y, const double* x, const double* u, const double* w) {\n%s\n}" % (q, "\n".join(body)))
+        jx = ["    fx[%d] = %s%s;" % (j * n1 + i, g(A[i][j]), " + 0.1 * cos(x[0])" if (i == 0 and j == 0) else "") for j in range(n0) for i in range(n1)]
+        src.append("ILQR_MODEL_FN void dynamics_%d_jacobian_state(double* fx, const double* x, const double* u, const double* w) {\n%s\n}" % (q, "\n".join(jx)))
+        ju = ["    fu[%d] = %s;" % (j * n1 + i, g(Bm[i][j])) for j in range(m0) for i in range(n1)]
+        src.append("ILQR_MODEL_FN void dynamics_%d_jacobian_action(double* fu, const double* x, const double* u, const double* w) {\n%s\n}" % (q, "\n".join(ju)))
+    sig = "(double* o, const double* x, const double* u, const double* w)"
+    for q, (n0, m0) in enumerate(ck):
+        qx = [0.5 * (1.0 + 0.1 * i) for i in range(n0)]
+        ru = [0.05 * (1.0 + j) for j in range(m0)]
+        ell = " + ".join(["%s * x[%d] * x[%d]" % (g(qx[i]), i, i) for i in range(n0)] + ["%s * u[%d] * u[%d]" % (g(ru[j]), j, j) for j in range(m0)])
+        src.append("ILQR_MODEL_FN void cost_stage_%d%s { o[0] = %s; }" % (q, sig, ell))
+        src.append("ILQR_MODEL_FN void cost_stage_%d_gradient_state%s { %s }" % (q, sig, " ".join("o[%d] = %s * x[%d];" % (i, g(2.0 * qx[i]), i) for i in range(n0))))
+        src.append("ILQR_MODEL_FN void cost_stage_%d_gradient_action%s { %s }" % (q, sig, " ".join("o[%d] = %s * u[%d];" % (j, g(2.0 * ru[j]), j) for j in range(m0))))
+        src.append("ILQR_MODEL_FN void cost_stage_%d_hessian_state_state%s { %s }" % (q, sig, " ".join("o[%d] = %s;" % (i * n0 + i, g(2.0 * qx[i])) for i in range(n0))))
+        src.append("ILQR_MODEL_FN void cost_stage_%d_hessian_action_action%s { %s }" % (q, sig, " ".join("o[%d] = %s;" % (j * m0 + j, g(2.0 * ru[j])) for j in range(m0))))
+        src.append("ILQR_MODEL_FN void cost_stage_%d_hessian_action_state%s { }" % (q, sig))
+    nT = n_t[-1]
+    src.append("ILQR_MODEL_FN void cost_terminal%s { o[0] = %s; }" % (sig, " + ".join("5.0 * x[%d] * x[%d]" % (i, i) for i in range(nT))))
+    src.append("ILQR_MODEL_FN void cost_terminal_gradient_state%s { %s }" % (sig, " ".join("o[%d] = 10.0 * x[%d];" % (i, i) for i in range(nT))))
+    src.append("ILQR_MODEL_FN void cost_terminal_hessian_state_state%s { %s }" % (sig, " ".join("o[%d] = 10.0;" % (i * nT + i) for i in range(nT))))
+    src.append("ILQR_MODEL_FN void constraint_terminal%s { o[0] = x[0] - 0.2; o[1] = x[1] + 0.1; }" % sig)
+    src.append("ILQR_MODEL_FN void constraint_terminal_jacobian_state%s { o[0] = 1.0; o[3] = 1.0; }" % sig)     # 2 x nT column-major: (0,0), (1,1)
+    kinds = _ffi.stage_kinds(T, 0, dk, di, ck, ci, [], [], nT, 2, 0)
+    return kinds, "\n".join(src) + "\n"
+
+
 # ---------------------------------------------------------------- synth32 (SURVEY.md §8(d) C5)
 def synth32():
     """x⁺ = x + h(Ax + Bu + 0.1 sin x), nx = 32, nu = 8, action box as 16 stage inequalities."""

@@ -201,33 +201,9 @@ def test_time_varying_objects_lowering():
 
 
 def _ragged_problem(pkg, T=9):
-    """Dimensions change along the horizon: n_t = 3,3,4,4,2,2,3,3,3 and m_t = 2,1,2,1,1,2,2,1."""
-    import math
-    n_t = [3, 3, 4, 4, 2, 2, 3, 3, 3][:T]
-    m_t = [2, 1, 2, 1, 1, 2, 2, 1][:T - 1]
-    dyn_cache, cost_cache = {}, {}
-
-    def dyn(n0, m0, n1):
-        if (n0, m0, n1) not in dyn_cache:
-            A = [[(0.9 if i == j else 0.0) + 0.1 * math.cos(1.0 + i + 2 * j + n0) for j in range(n0)] for i in range(n1)]
-            Bm = [[0.3 * math.sin(2.0 + 3 * i + j + m0) for j in range(m0)] for i in range(n1)]
-            dyn_cache[(n0, m0, n1)] = pkg.Dynamics(
-                lambda x, u: [sum(A[i][j] * x[j] for j in range(n0)) + sum(Bm[i][j] * u[j] for j in range(m0))
-                              + (0.1 * pkg.codegen.sp.sin(x[0]) if i == 0 else 0.0) for i in range(n1)], n0, m0)
-        return dyn_cache[(n0, m0, n1)]
-
-    def cost(n0, m0):
-        if (n0, m0) not in cost_cache:
-            cost_cache[(n0, m0)] = pkg.Cost(lambda x, u: 0.5 * sum((1.0 + 0.1 * i) * x[i] * x[i] for i in range(n0))
-                                            + 0.05 * sum((1.0 + j) * u[j] * u[j] for j in range(m0)), n0, m0)
-        return cost_cache[(n0, m0)]
-
-    dynamics = [dyn(n_t[t], m_t[t], n_t[t + 1]) for t in range(T - 1)]
-    costs = [cost(n_t[t], m_t[t]) for t in range(T - 1)] + [pkg.Cost(lambda x, u: 5.0 * sum(x[i] * x[i] for i in range(n_t[-1])), n_t[-1], 0)]
-    none = pkg.Constraint()
-    goal = pkg.Constraint(lambda x, u: [x[0] - 0.2, x[1] + 0.1], n_t[-1], 0)
-    constraints = [none] * (T - 1) + [goal]
-    return dynamics, costs, constraints, n_t, m_t
+    """Dimensions change along the horizon: n_t = 3,3,4,4,2,2,3,3 | 3.. and m_t = 2,1,2,1,1,2,2,1 | 2.. (models.ragged; the oracle's
+    "ragged" problem and the independent restatement's ragged_problem are the same definition)."""
+    return pkg.models.ragged(T)
 
 
 def test_time_varying_dimensions_lowering():
@@ -247,6 +223,64 @@ def test_time_varying_dimensions_lowering():
         ell = pkg.codegen.sp.sympify(Cs.evaluate).subs(sub)
         pad = sum(Cs.u[j] ** 2 for j in range(m_t[t], 2)) / 2
         assert pkg.codegen.sp.simplify(ell - costs[t].evaluate - pad) == 0          # u²/2 on padded actions only
+
+
+def test_lowering_plan_comes_from_the_library_and_refuses_an_inconsistent_chain():
+    """lowering.lower asks ilqr_plan_stages (the C-ABI entry a Julia / C host uses through ilqr_compile_model_stages) for template
+    dimensions, selector columns, row offsets and inequality masks; a chain of dimensions the reference would throw on
+    (x[t+1] .= dynamics!(...), src/rollout.jl:29) is refused there."""
+    import pytest
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
+    T = 13
+    dynamics, costs, constraints = pkg.models.car_tv(T)
+    kinds, _ = pkg.lowering.stage_kinds(dynamics, costs, constraints)
+    plan, sel, n_t, m_t = pkg._ffi.plan_stages(kinds)
+    assert (plan.nx, plan.nu, plan.nw, plan.nc_stage, plan.nc_term, plan.n_selectors) == (3, 2, 7, 6, 4, 7)
+    assert (plan.sel_dynamics, plan.sel_cost, plan.sel_constraint) == (0, 2, 4) and list(plan.constraint_row0)[:3] == [0, 5, 5]
+    assert plan.ineq_stage_words[0] == 0b011111 and n_t == [3] * T and m_t == [2] * (T - 1)
+    low = pkg.lowering.lower(dynamics, costs, constraints)
+    assert (low["selectors"] == np.array(sel)).all() and low["constraint_rows"][2] == [5] and low["constraint_rows"][1] == []
+    d2 = pkg.Dynamics(lambda x, u: [x[0] + u[0], x[1]], 3, 2)              # 3 states in, 2 out
+    with pytest.raises(pkg._ffi.IlqrError, match="does not produce the state"):
+        pkg.lowering.lower([dynamics[0], d2] + dynamics[2:], costs, constraints)
+
+
+def test_compile_model_stages_composes_the_template_from_c_sources_per_kind(tmp_path):
+    """ilqr_compile_model_stages: per-kind C callables in their own dimensions -> combined, padded template callables (selector
+    branches, re-strided matrices, u^2 / 2 on padded actions) -> hipcc. Compiles without a GPU; the GPU test solves with it."""
+    import ctypes as C
+    import os
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
+    F, L = pkg._ffi, pkg._ffi.lib()
+    T = 17
+    kinds, src = pkg.models.ragged_c_stages(T)
+    cap = T * (kinds.n_dynamics + kinds.n_costs + kinds.n_constraints)
+    plan, sel = F.StagePlan(), (C.c_double * cap)()
+    sd, ad = (C.c_int32 * T)(), (C.c_int32 * (T - 1))()
+    reg, path = C.create_string_buffer(160), C.create_string_buffer(1024)
+    os.environ["ILQR_KEEP_MODEL_SOURCE"] = "1"
+    try:
+        rc = L.ilqr_compile_model_stages(b"ragged_c", C.byref(kinds), src.encode(), C.byref(plan), sel, cap, sd, ad, reg, 160, path, 1024)
+    finally:
+        del os.environ["ILQR_KEEP_MODEL_SOURCE"]
+    assert rc == 0, L.ilqr_last_error().decode()
+    _, _, _, n_t, m_t = pkg.models.ragged(T)
+    assert (plan.nx, plan.nu, plan.nc_stage, plan.nc_term) == (4, 2, 0, 2) and list(sd) == n_t and list(ad) == m_t
+    assert plan.n_selectors == kinds.n_dynamics + kinds.n_costs and plan.nw == plan.n_selectors
+    S = plan.n_selectors
+    rows = np.array([sel[i] for i in range(T * S)]).reshape(T, S)
+    assert (rows[:-1].sum(axis=1) == 2).all() and (rows[-1] == 0).all()
+    assert os.path.exists(path.value.decode()) and L.ilqr_model_name(L.ilqr_model_count() - 1) == reg.value
+    # the same objects through the symbolic lowering give the same plan
+    dynamics, costs, constraints, _, _ = pkg.models.ragged(T)
+    low = pkg.lowering.lower(dynamics, costs, constraints)
+    assert (low["selectors"] == rows).all() and low["state_dims"] == n_t
+    # inconsistent kinds are refused before anything is compiled
+    bad = F.stage_kinds(3, 0, [(2, 1, 3), (2, 1, 2)], [0, 1], [(2, 1)], [0, 0], [], [], 2, 0, 0)
+    assert L.ilqr_compile_model_stages(b"bad", C.byref(bad), b"", C.byref(plan), None, 0, None, None, reg, 160, path, 1024) < 0
+    assert b"does not produce the state" in L.ilqr_last_error()
 
 
 def test_lowering_selects_instead_of_multiplying_and_dedupes_kinds():

@@ -681,65 +681,99 @@ def test_synth12_workload_builtin_equals_plugin_and_oracle(pkg, oracle):
     assert np.abs(res["mid"]["x"] - ref["x"])[same].max() < 1e-7 and np.abs(res["mid"]["u"] - ref["u"])[same].max() < 1e-7
 
 
-def test_time_varying_dimensions(pkg):
-    """num_next_state != num_state along the horizon (src/dynamics.jl:5-7), lowered by zero padding (lowering.py).
-    The oracle keeps uniform dimensions, so the check is direct: the Riccati recursion of src/backward_pass.jl:42-90
-    evaluated with numpy on the RAGGED blocks of the device's own linearisation must reproduce the device's gains and
-    value function, and everything in the padding must be exactly zero."""
-    from test_codegen import _ragged_problem
-    T, B = 9, 8
-    dynamics, costs, constraints, n_t, m_t = _ragged_problem(pkg, T)
-    sol = pkg.Solver(dynamics, costs, constraints, batch=B, options=pkg.Options(verbose=0), name="ragged")
-    n, m = sol.nx, sol.nu
-    assert (n, m, sol.state_dims, sol.action_dims) == (4, 2, n_t, m_t)
-    rng = np.random.default_rng(5)
-    x1 = np.zeros((B, n)); x1[:, :n_t[0]] = 0.5 * rng.standard_normal((B, n_t[0]))
-    ub = np.zeros((B, T - 1, m))
+def _ragged_inputs(pr, B, seed=5):
+    rng = np.random.default_rng(seed)
+    T = pr.T
+    x1 = np.zeros((B, pr.nx)); x1[:, :pr.state_dims[0]] = 0.5 * rng.standard_normal((B, pr.state_dims[0]))
+    ub = np.zeros((B, T - 1, pr.nu))
     for t in range(T - 1):
-        ub[:, t, :m_t[t]] = 0.2 * rng.standard_normal((B, m_t[t]))
+        ub[:, t, :pr.action_dims[t]] = 0.2 * rng.standard_normal((B, pr.action_dims[t]))
+    return x1, ub
+
+
+def _check_ragged_against_the_oracle(pkg, oracle, sol, T, B):
+    """Stage buffers of one linearisation + Riccati pass and the whole solve of the zero-padded template against the ORACLE's
+    genuinely ragged problem (per-timestep blocks sized as src/data/{model,objective,policy}.jl size them)."""
+    pr = oracle.Problem("ragged", T)
+    n, m = sol.nx, sol.nu
+    assert (n, m, sol.state_dims, sol.action_dims) == (4, 2, pr.state_dims, pr.action_dims)
+    x1, ub = _ragged_inputs(pr, B)
     sol.initialize_rollout_(x1, ub)
     xb = sol.buffer("nominal_states").reshape(B, T, n)
-    for t in range(T):
-        assert (xb[:, t, n_t[t]:] == 0).all()
-    sol.run_stage_("cost_nominal"); sol.run_stage_("gradients"); sol.run_stage_("backward_pass")
-    g = {k: sol.buffer(k) for k in ("jacobian_state", "jacobian_action", "gradient_state", "gradient_action",
-                                    "hessian_state_state", "hessian_action_action", "hessian_action_state", "K", "k", "P", "p")}
-    fx = g["jacobian_state"].reshape(B, T - 1, n, n).transpose(0, 1, 3, 2)          # [b][t][row][col]
-    fu = g["jacobian_action"].reshape(B, T - 1, m, n).transpose(0, 1, 3, 2)
-    gxx = g["hessian_state_state"].reshape(B, T, n, n).transpose(0, 1, 3, 2)
-    guu = g["hessian_action_action"].reshape(B, T - 1, m, m).transpose(0, 1, 3, 2)
-    gux = g["hessian_action_state"].reshape(B, T - 1, n, m).transpose(0, 1, 3, 2)   # [b][t][m][n]
-    gx = g["gradient_state"].reshape(B, T, n); gu = g["gradient_action"].reshape(B, T - 1, m)
-    K = g["K"].reshape(B, T - 1, n, m).transpose(0, 1, 3, 2); k = g["k"].reshape(B, T - 1, m)
-    P = g["P"].reshape(B, T, n, n).transpose(0, 1, 3, 2); p = g["p"].reshape(B, T, n)
-    for b in range(B):
-        nT = n_t[-1]
-        Pn, pn = gxx[b, T - 1, :nT, :nT], gx[b, T - 1, :nT]
-        for t in range(T - 2, -1, -1):
-            n0, m0, n1 = n_t[t], m_t[t], n_t[t + 1]
-            A, Bm = fx[b, t, :n1, :n0], fu[b, t, :n1, :m0]
-            Qx = A.T @ pn + gx[b, t, :n0]; Qu = Bm.T @ pn + gu[b, t, :m0]
-            Qxx = A.T @ Pn @ A + gxx[b, t, :n0, :n0]
-            Quu = Bm.T @ Pn @ Bm + guu[b, t, :m0, :m0]
-            Qux = Bm.T @ Pn @ A + gux[b, t, :m0, :n0]
-            Kt = -np.linalg.solve(Quu, Qux); kt = -np.linalg.solve(Quu, Qu)
-            assert np.allclose(K[b, t, :m0, :n0], Kt, rtol=1e-9, atol=1e-11), (b, t)
-            assert np.allclose(k[b, t, :m0], kt, rtol=1e-9, atol=1e-11)
-            assert (K[b, t, m0:, :] == 0).all() and (K[b, t, :, n0:] == 0).all() and (k[b, t, m0:] == 0).all()
-            Pn = Kt.T @ Quu @ Kt + Kt.T @ Qux + Qux.T @ Kt + Qxx
-            pn = (Quu @ Kt).T @ kt + Kt.T @ Qu + Qux.T @ kt + Qx
-            assert np.allclose(P[b, t, :n0, :n0], Pn, rtol=1e-9, atol=1e-11)
-            assert np.allclose(p[b, t, :n0], pn, rtol=1e-9, atol=1e-11)
-            assert (P[b, t, n0:, :] == 0).all() and (P[b, t, :, n0:] == 0).all() and (p[b, t, n0:] == 0).all()
-    # whole solve: converges on the real problem, the padding stays exactly zero
+    for b in range(3):
+        assert np.abs(xb[b] - pr.rollout(x1[b], ub[b])).max() < 1e-13                # padding included: exactly zero in both
+    # -- stages on identical inputs, twice (the second linearisation adds to the accumulated Hessians, Q1)
+    refs = []
+    for b in range(3):
+        o = oracle.Solver(pr); o.initialize_controls(ub[b]); o.initialize_states(pr.rollout(x1[b], ub[b]))
+        refs.append(o)
+    for rep in range(2):
+        sol.run_stage_("cost_nominal"); sol.run_stage_("gradients"); sol.run_stage_("backward_pass")
+        for o in refs:
+            o.call("cost_bang", 0); o.call("gradients"); o.call("backward_pass")
+        shapes = {"jacobian_state": (T - 1, n, n), "jacobian_action": (T - 1, m, n), "gradient_state": (T, n), "gradient_action": (T - 1, m),
+                  "hessian_state_state": (T, n, n), "hessian_action_action": (T - 1, m, m), "hessian_action_state": (T - 1, n, m),
+                  "K": (T - 1, n, m), "k": (T - 1, m), "P": (T, n, n), "p": (T, n)}
+        for name, shp in shapes.items():
+            got = sol.buffer(name)[:3].reshape((3,) + shp)
+            want = np.stack([o.padded(name) for o in refs])
+            if name == "hessian_action_action":            # the template's padded actions carry u^2 / 2: 1 (x linearisations so far) on their diagonal
+                for t in range(T - 1):
+                    for j in range(pr.action_dims[t], m):
+                        want[:, t, j, j] = rep + 1.0
+            tol = 1e-12 if name.startswith(("jacobian", "gradient", "hessian")) else 1e-9
+            assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (name, rep)
+            if name in ("K", "k", "P", "p", "jacobian_state", "jacobian_action"):
+                assert (got[want == 0] == 0).all(), name                                 # the padding is EXACTLY zero
+        sol.run_stage_("forward_pass")
+        for o in refs:
+            o.call("forward_pass")
+        st = sol.stats()
+        assert [st["step_size"][b] for b in range(3)] == [o.stats().step_size for o in refs]
+    # -- whole solve
     sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()
-    x, u = sol.get_trajectory(); st = sol.stats()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    ref = oracle.solve_batch("ragged", T, x1, ub, nthreads=4)
+    for f in ("iterations", "outer_iterations", "rollouts", "status"):
+        assert (st[f] == ref["stats"][f]).all(), f                                      # control flow exact on every instance
+    assert (st["step_size"] == ref["stats"]["step_size"]).all()
+    assert np.abs(x - ref["x"]).max() <= 1e-7 and np.abs(u - ref["u"]).max() <= 1e-7
+    assert np.abs(K - ref["K"]).max() <= 1e-7 * np.abs(ref["K"]).max() and np.abs(k - ref["k"]).max() <= 1e-7
+    assert np.allclose(st["objective"], ref["stats"]["objective"], rtol=1e-9) and np.allclose(st["max_violation"], ref["stats"]["max_violation"], atol=1e-9)
     for t in range(T):
-        assert (x[:, t, n_t[t]:] == 0).all()
+        assert (x[:, t, pr.state_dims[t]:] == 0).all()                                  # padding exactly zero
     for t in range(T - 1):
-        assert (u[:, t, m_t[t]:] == 0).all()
-    assert np.isfinite(x).all() and (st["max_violation"] <= 5e-3).all(), st["max_violation"]
-    assert np.abs(x[:, -1, 0] - 0.2).max() <= 5e-3 and np.abs(x[:, -1, 1] + 0.1).max() <= 5e-3
+        n0, m0 = pr.state_dims[t], pr.action_dims[t]
+        assert (u[:, t, m0:] == 0).all() and (k[:, t, m0:] == 0).all()
+        assert (K[:, t, :, m0:] == 0).all() and (K[:, t, n0:, :] == 0).all()             # K[b][t] is [nx][nu]
+    assert (st["max_violation"] <= 5e-3).all()
+    return np.abs(x - ref["x"]).max(), np.abs(u - ref["u"]).max()
+
+
+@pytest.mark.parametrize("T", [9, 41])
+def test_time_varying_dimensions(pkg, oracle, T):
+    """num_next_state != num_state along the horizon (src/dynamics.jl:5-7), lowered by zero padding (lowering.py, plan from
+    ilqr_plan_stages) — against the oracle, which holds the genuinely ragged per-timestep buffers of the reference."""
+    from test_codegen import _ragged_problem
+    B = 24
+    dynamics, costs, constraints, n_t, m_t = _ragged_problem(pkg, T)
+    sol = pkg.Solver(dynamics, costs, constraints, batch=B, options=pkg.Options(verbose=0), name="ragged")
+    _check_ragged_against_the_oracle(pkg, oracle, sol, T, B)
+    sol.close()
+
+
+def test_time_varying_dimensions_from_c_sources_per_kind(pkg, oracle):
+    """The same problem the way a Julia or C host hands it over: C callables per kind, each in its own dimensions, lowered by the
+    LIBRARY (ilqr_compile_model_stages + ilqr_set_stage_selectors) — no Python lowering, no symbolic generator."""
+    T, B = 41, 24
+    sol = pkg.Solver(stage_sources=pkg.models.ragged_c_stages(T), batch=B, options=pkg.Options(verbose=0), name="ragged_c")
+    assert sol.num_user_parameter == 0 and sol.nw == 0             # ilqr_get_dims reports the USER's parameters: none
+    with pytest.raises(pkg._ffi.IlqrError, match="no parameters"):
+        sol.set_parameters_(np.zeros((B, T, 0)))
+    _check_ragged_against_the_oracle(pkg, oracle, sol, T, B)
+    # the selector columns are in the device's parameter block, behind nothing (no user parameters)
+    w = sol.buffer("parameters").reshape(B, T, -1)
+    assert w.shape[2] == sol._selectors.shape[1] and (w == sol._selectors[None]).all()
     sol.close()
 
 
@@ -1445,7 +1479,7 @@ def test_c_callables_define_a_large_path_model(pkg, oracle, tmp_path):
 
     class Src(C.Structure):
         _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
-                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p), ("flags", C.c_int32)]
     L = pkg._ffi.lib()
     ms = Src(b"synth12_t", 12, 5, 0, 10, 3, (1 << 10) - 1, 0, text)
     name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
@@ -1650,7 +1684,7 @@ def test_c_callables_synth32_with_probed_structure(pkg, oracle):
 
     class Src(C.Structure):
         _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
-                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p), ("flags", C.c_int32)]
     L = pkg._ffi.lib()
     ms = Src(b"synth32_c", 32, 8, 0, 16, 0, (1 << 16) - 1, 0, text)
     name = C.create_string_buffer(128); path = C.create_string_buffer(1024)
@@ -1688,7 +1722,7 @@ def test_c_callables_synth32_without_the_structure_probe(pkg, oracle, monkeypatc
 
     class Src(C.Structure):
         _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
-                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p), ("flags", C.c_int32)]
     L = pkg._ffi.lib()
     names = {}
     for label in ("dense", "probed"):
@@ -1735,7 +1769,7 @@ def test_c_callables_at_the_size_limits(pkg, probe, monkeypatch):
 
     class Src(C.Structure):
         _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
-                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+                    ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p), ("flags", C.c_int32)]
     if not probe:
         monkeypatch.setenv("ILQR_NO_STRUCTURE_PROBE", "1")
     L = pkg._ffi.lib()

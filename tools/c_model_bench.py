@@ -16,7 +16,7 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "synth32"
 
 class Src(C.Structure):
     _fields_ = [("name", C.c_char_p), ("nx", C.c_int32), ("nu", C.c_int32), ("nw", C.c_int32), ("nc_stage", C.c_int32),
-                ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p)]
+                ("nc_term", C.c_int32), ("ineq_stage", C.c_uint64), ("ineq_term", C.c_uint64), ("source", C.c_char_p), ("flags", C.c_int32)]
 
 
 def compile_c(dense):
