@@ -1,9 +1,12 @@
 # IterativeLQRAMD.jl — Julia host side of the MI355X-native batched iLQR solver.
 #
-# NOT EXECUTED in this repository's CI: the build image has no Julia (SURVEY.md §0).
-# It is the binding a maintainer of IterativeLQR.jl would add: the same exported
-# names (src/IterativeLQR.jl:30-45) over `ccall`s into libilqr_hip.so
-# (include/ilqr_hip.h). The tested twin of this file is iterativelqr.jl_amd/api.py.
+# THIS FILE HAS NEVER RUN. The build image has no Julia (SURVEY.md §0), so nothing below has been parsed, let alone
+# executed: the `ccall` signatures are written against include/ilqr_hip.h by hand, and the Symbolics calls
+# (`build_function(...; target = CTarget(), fname, lhsname, rhsnames)`) from memory of its documentation. Treat it as the
+# sketch of the binding a maintainer of IterativeLQR.jl would add — the same exported names (src/IterativeLQR.jl:30-45) over
+# `ccall`s into libilqr_hip.so — not as a tested component. What IS tested is the C-ABI it binds (tests/test_abi.py, the C
+# programs under examples/) and the Python twin of this file, iterativelqr.jl_amd/api.py, which drives every entry point
+# used here (including ilqr_compile_model_stages / ilqr_set_stage_selectors, through Solver(stage_sources = ...)).
 #
 # One `Solver` here owns a BATCH of B independent problem instances of one model;
 # states are B×T×nx, actions B×(T-1)×nu (row-major on the C side, so Julia arrays
@@ -64,6 +67,7 @@ mutable struct Solver
     handle::Ptr{Cvoid}
     nx::Int; nu::Int; T::Int; B::Int
     options::Options
+    state_dims::Vector{Int}; action_dims::Vector{Int}     # real entries per step (all nx / nu unless the problem's dimensions vary)
 end
 
 """
@@ -95,7 +99,7 @@ function Solver(model::AbstractString; horizon::Integer, batch::Integer, constra
     check(ccall((:ilqr_get_dims, LIB[]), Cint,
                 (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}),
                 h[], d...))
-    s = Solver(h[], d[1][], d[2][], d[6][], d[7][], options)
+    s = Solver(h[], d[1][], d[2][], d[6][], d[7][], options, fill(Int(d[1][]), d[6][]), fill(Int(d[2][]), d[6][] - 1))
     finalizer(x -> ccall((:ilqr_destroy, LIB[]), Cint, (Ptr{Cvoid},), x.handle), s)
     return s
 end
@@ -162,7 +166,10 @@ end
 # (`Symbolics.build_function(expr, x, u, w; target = Symbolics.CTarget())` — from memory of the Symbolics docs; the
 # image has no Julia, so this half has never run) and handed to `ilqr_compile_model`, which wraps them for the kernels
 # (csrc/ilqr_model_adapter.hpp) and compiles them with hipcc. Requires `using Symbolics` in the caller's environment.
-struct Dynamics;  body::String; num_state::Int; num_action::Int; num_parameter::Int; end
+# `body` is C source whose function names start with the placeholder @P@ (e.g. @P@_jacobian_state): Solver(...) gives every
+# distinct object of a problem its own prefix — dynamics_<k>, cost_stage_<k>, constraint_stage_<k>, cost_terminal,
+# constraint_terminal — as ilqr_compile_model_stages expects them (include/ilqr_hip.h).
+struct Dynamics;  body::String; num_next_state::Int; num_state::Int; num_action::Int; num_parameter::Int; end
 struct Cost;      body::String; num_state::Int; num_action::Int; num_parameter::Int; end
 struct Constraint; body::String; num_constraint::Int; num_state::Int; num_action::Int; num_parameter::Int
                    indices_inequality::Vector{Int}; end
@@ -174,22 +181,23 @@ function c_function(Symbolics, name::String, exprs, x, u, w)
                                    lhsname = :out, rhsnames = [:x, :u, :w])
     return string(src, "\nILQR_MODEL_FN void ", name,
                   "(double* out, const double* x, const double* u, const double* w) { ", name, "_raw(out, x, u, w); }\n")
+    # (name carries the @P@ placeholder; it is substituted in the whole body, raw function included, before compilation)
 end
 
 function Dynamics(Symbolics, f::Function, num_state::Int, num_action::Int; num_parameter::Int = 0)
     x = Symbolics.variables(:x, 1:num_state); u = Symbolics.variables(:u, 1:num_action); w = Symbolics.variables(:w, 1:num_parameter)
     y = num_parameter > 0 ? f(x, u, w) : f(x, u)
-    body = c_function(Symbolics, "dynamics", y, x, u, w) *
-           c_function(Symbolics, "dynamics_jacobian_state", vec(Symbolics.jacobian(y, x)), x, u, w) *
-           c_function(Symbolics, "dynamics_jacobian_action", vec(Symbolics.jacobian(y, u)), x, u, w)
-    Dynamics(body, num_state, num_action, num_parameter)
+    body = c_function(Symbolics, "@P@", y, x, u, w) *
+           c_function(Symbolics, "@P@_jacobian_state", vec(Symbolics.jacobian(y, x)), x, u, w) *
+           c_function(Symbolics, "@P@_jacobian_action", vec(Symbolics.jacobian(y, u)), x, u, w)
+    Dynamics(body, length(y), num_state, num_action, num_parameter)      # num_next_state = length(f(x, u)), src/dynamics.jl:22-29
 end
 
 function Cost(Symbolics, f::Function, num_state::Int, num_action::Int; num_parameter::Int = 0, terminal::Bool = num_action == 0)
     x = Symbolics.variables(:x, 1:num_state); u = Symbolics.variables(:u, 1:num_action); w = Symbolics.variables(:w, 1:num_parameter)
     l = num_parameter > 0 ? f(x, u, w) : f(x, u)
     gx = Symbolics.gradient(l, x); gu = Symbolics.gradient(l, u)
-    p = terminal ? "cost_terminal" : "cost_stage"
+    p = "@P@"
     body = c_function(Symbolics, p, [l], x, u, w) * c_function(Symbolics, p * "_gradient_state", gx, x, u, w) *
            c_function(Symbolics, p * "_hessian_state_state", vec(Symbolics.jacobian(gx, x)), x, u, w)
     if !terminal
@@ -204,7 +212,7 @@ function Constraint(Symbolics, f::Function, num_state::Int, num_action::Int; ind
                     num_parameter::Int = 0, terminal::Bool = num_action == 0)
     x = Symbolics.variables(:x, 1:num_state); u = Symbolics.variables(:u, 1:num_action); w = Symbolics.variables(:w, 1:num_parameter)
     c = num_parameter > 0 ? f(x, u, w) : f(x, u)
-    p = terminal ? "constraint_terminal" : "constraint_stage"
+    p = "@P@"
     body = c_function(Symbolics, p, c, x, u, w) * c_function(Symbolics, p * "_jacobian_state", vec(Symbolics.jacobian(c, x)), x, u, w)
     terminal || (body *= c_function(Symbolics, p * "_jacobian_action", vec(Symbolics.jacobian(c, u)), x, u, w))
     Constraint(body, length(c), num_state, num_action, num_parameter, indices_inequality)
@@ -221,54 +229,99 @@ Dynamics(f::Function, num_state::Int, num_action::Int; kwargs...) = Dynamics(sym
 Cost(f::Function, num_state::Int, num_action::Int; kwargs...) = Cost(symbolics_module(), f, num_state, num_action; kwargs...)
 Constraint(f::Function, num_state::Int, num_action::Int; kwargs...) = Constraint(symbolics_module(), f, num_state, num_action; kwargs...)
 
-struct ModelSource
-    name::Cstring; nx::Int32; nu::Int32; nw::Int32; nc_stage::Int32; nc_term::Int32
-    ineq_stage::UInt64; ineq_term::UInt64; source::Cstring
+# ilqr_stage_kinds / ilqr_stage_plan (include/ilqr_hip.h), field for field
+struct StageKinds
+    horizon::Int32; num_parameter::Int32
+    n_dynamics::Int32; dynamics_nx::Ptr{Int32}; dynamics_nu::Ptr{Int32}; dynamics_nx_next::Ptr{Int32}; dynamics_of_step::Ptr{Int32}
+    n_costs::Int32; cost_nx::Ptr{Int32}; cost_nu::Ptr{Int32}; cost_of_step::Ptr{Int32}
+    n_constraints::Int32; constraint_nc::Ptr{Int32}; constraint_nx::Ptr{Int32}; constraint_nu::Ptr{Int32}
+    constraint_ineq::Ptr{UInt64}; constraint_of_step::Ptr{Int32}
+    nx_term::Int32; nc_term::Int32; ineq_term::NTuple{4,UInt64}
 end
-ineq_mask(idx) = reduce(|, (UInt64(1) << (i - 1) for i in idx if i <= 64); init = UInt64(0))
-# rows beyond 64 (ilqr_compile_model_rows): row i = bit (i - 1) % 64 of word (i - 1) ÷ 64, at least one word
-function ineq_words(idx, num_constraint)
-    w = zeros(UInt64, max(1, cld(num_constraint, 64)))
+struct StagePlan
+    nx::Int32; nu::Int32; nw::Int32; nc_stage::Int32; nc_term::Int32; n_selectors::Int32
+    sel_dynamics::Int32; sel_cost::Int32; sel_constraint::Int32
+    constraint_row0::NTuple{16,Int32}; ineq_stage_words::NTuple{4,UInt64}
+end
+# inequality rows as four 64-bit words: row i (1-based, as indices_inequality is) = bit (i - 1) % 64 of word (i - 1) ÷ 64
+function ineq_words(idx)
+    w = zeros(UInt64, 4)
     for i in idx
         w[(i - 1) ÷ 64 + 1] |= UInt64(1) << ((i - 1) % 64)
     end
     return w
 end
 
+# distinct objects of a vector in order of first appearance, and the (0-based) kind of every element
+function kinds_of(objs)
+    kinds = eltype(objs)[]; index = Int32[]
+    for o in objs
+        k = findfirst(q -> q == o, kinds)
+        if k === nothing
+            push!(kinds, o); k = length(kinds)
+        end
+        push!(index, Int32(k - 1))
+    end
+    return kinds, index
+end
+Base.:(==)(a::Dynamics, b::Dynamics) = a.body == b.body && (a.num_next_state, a.num_state, a.num_action) == (b.num_next_state, b.num_state, b.num_action)
+Base.:(==)(a::Cost, b::Cost) = a.body == b.body && (a.num_state, a.num_action) == (b.num_state, b.num_action)
+Base.:(==)(a::Constraint, b::Constraint) = a.body == b.body && a.indices_inequality == b.indices_inequality &&
+                                           (a.num_constraint, a.num_state, a.num_action) == (b.num_constraint, b.num_state, b.num_action)
+
 """
     Solver(dynamics, costs, constraints; batch, options, name)
 
-`Solver(dynamics, costs, constraints)` of the reference (src/solver.jl:28-46) for a batch: `dynamics[1]`, `costs[1]`,
-`constraints[1]` are the stage objects (uniform over the horizon in this wrapper; distinct per-step objects are lowered by
-the Python host, lowering.py), `costs[end]` / `constraints[end]` the terminal ones.
+`Solver(dynamics, costs, constraints)` of the reference (src/solver.jl:28-46) for a batch: T-1 Dynamics, T Costs, T Constraints,
+the last Cost / Constraint being the terminal objects (they are evaluated with `u = zeros(0)`, src/costs.jl:52, src/constraints.jl:69).
+The objects MAY DIFFER from step to step and so may their dimensions (README.md:26, src/dynamics.jl:5-7): the distinct ones are
+handed to the library kind by kind (`ilqr_compile_model_stages`), which lowers them onto its one-stage template — selectors in θ_t,
+stacked constraint rows, zero padding to the largest dimensions — and the handle is given the selector table
+(`ilqr_set_stage_selectors`). Arrays passed to / returned by the solver are the PADDED ones: (solver.nx, T, B) with
+`solver.state_dims[t]` real entries at step t, likewise `solver.action_dims`.
 """
 function Solver(dynamics::Vector{Dynamics}, costs::Vector{Cost}, constraints::Vector{Constraint};
                 batch::Integer, options::Options = Options(), name::AbstractString = "user", device::Integer = 0,
                 devices::AbstractVector{<:Integer} = Int[], constrained::Bool = true)
-    # The device kernels are compiled for ONE stage template. Distinct per-step objects (README.md:26 of the reference) are
-    # lowered onto it by the Python host only (lowering.py); here they are refused instead of silently solving with [1].
-    length(costs) == length(dynamics) + 1 && length(constraints) == length(costs) ||
+    T = length(costs)
+    length(dynamics) == T - 1 && length(constraints) == T ||
         error("Solver: expected T-1 dynamics, T costs and T constraints (src/solver.jl:28-46)")
-    all(x -> x.body == dynamics[1].body, dynamics) ||
-        error("Solver: per-step Dynamics objects differ; this wrapper takes one stage template (use the Python host's lowering)")
-    all(x -> x.body == costs[1].body, costs[1:end-1]) ||
-        error("Solver: per-step stage Cost objects differ; this wrapper takes one stage template (use the Python host's lowering)")
-    all(x -> x.body == constraints[1].body && x.indices_inequality == constraints[1].indices_inequality, constraints[1:end-1]) ||
-        error("Solver: per-step stage Constraint objects differ; this wrapper takes one stage template (use the Python host's lowering)")
-    d, cs, ct = dynamics[1], constraints[1], constraints[end]
-    source = d.body * costs[1].body * costs[end].body * cs.body * ct.body
-    regname = Vector{UInt8}(undef, 128); path = Vector{UInt8}(undef, 1024)
-    GC.@preserve name source begin
-        ms = ModelSource(Base.unsafe_convert(Cstring, name), d.num_state, d.num_action, d.num_parameter,
-                         cs.num_constraint, ct.num_constraint, ineq_mask(cs.indices_inequality), ineq_mask(ct.indices_inequality),
-                         Base.unsafe_convert(Cstring, source))
-        ws, wt = ineq_words(cs.indices_inequality, cs.num_constraint), ineq_words(ct.indices_inequality, ct.num_constraint)
-        check(ccall((:ilqr_compile_model_rows, LIB[]), Cint,
-                    (Ref{ModelSource}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt8}, Csize_t, Ptr{UInt8}, Csize_t),
-                    ms, ws, wt, regname, length(regname), path, length(path)))
+    dk, di = kinds_of(dynamics)
+    ck, ci = kinds_of(costs[1:end-1])
+    kk, ki = kinds_of(constraints[1:end-1])
+    ct, kt = costs[end], constraints[end]
+    nwu = maximum(o.num_parameter for o in vcat(dk, ck, kk, [ct], [kt]))
+    prefix(body, p) = replace(body, "@P@" => p)
+    source = join([prefix(d.body, "dynamics_$(k - 1)") for (k, d) in enumerate(dk)]) *
+             join([prefix(c.body, "cost_stage_$(k - 1)") for (k, c) in enumerate(ck)]) *
+             join([prefix(c.body, "constraint_stage_$(k - 1)") for (k, c) in enumerate(kk) if c.num_constraint > 0]) *
+             prefix(ct.body, "cost_terminal") * (kt.num_constraint > 0 ? prefix(kt.body, "constraint_terminal") : "")
+    i32(v) = Int32.(collect(v))
+    dnx, dnu, dnn = i32(d.num_state for d in dk), i32(d.num_action for d in dk), i32(d.num_next_state for d in dk)
+    cnx, cnu = i32(c.num_state for c in ck), i32(c.num_action for c in ck)
+    knc, knx, knu = i32(c.num_constraint for c in kk), i32(c.num_state for c in kk), i32(c.num_action for c in kk)
+    kin = reduce(vcat, [ineq_words(c.indices_inequality) for c in kk]; init = UInt64[])
+    cap = T * (length(dk) + length(ck) + length(kk))
+    selectors = zeros(Float64, max(cap, 1)); state_dims = zeros(Int32, T); action_dims = zeros(Int32, T - 1)
+    plan = Ref(StagePlan(0, 0, 0, 0, 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 16), ntuple(_ -> UInt64(0), 4)))
+    regname = Vector{UInt8}(undef, 160); path = Vector{UInt8}(undef, 1024)
+    GC.@preserve name source dnx dnu dnn di cnx cnu ci knc knx knu kin ki begin
+        kinds = StageKinds(Int32(T), Int32(nwu),
+                           Int32(length(dk)), pointer(dnx), pointer(dnu), pointer(dnn), pointer(di),
+                           Int32(length(ck)), pointer(cnx), pointer(cnu), pointer(ci),
+                           Int32(length(kk)), pointer(knc), pointer(knx), pointer(knu), pointer(kin), pointer(ki),
+                           Int32(ct.num_state), Int32(kt.num_constraint), Tuple(ineq_words(kt.indices_inequality)))
+        check(ccall((:ilqr_compile_model_stages, LIB[]), Cint,
+                    (Cstring, Ref{StageKinds}, Cstring, Ref{StagePlan}, Ptr{Float64}, Csize_t, Ptr{Int32}, Ptr{Int32},
+                     Ptr{UInt8}, Csize_t, Ptr{UInt8}, Csize_t),
+                    name, kinds, source, plan, selectors, cap, state_dims, action_dims, regname, length(regname), path, length(path)))
     end
-    Solver(unsafe_string(pointer(regname)); horizon = length(costs), batch = batch, constrained = constrained, options = options,
-           device = device, devices = devices, model_library = unsafe_string(pointer(path)))
+    s = Solver(unsafe_string(pointer(regname)); horizon = T, batch = batch, constrained = constrained, options = options,
+               device = device, devices = devices, model_library = unsafe_string(pointer(path)))
+    S = plan[].n_selectors
+    S > 0 && check(ccall((:ilqr_set_stage_selectors, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), s.handle, selectors, S))
+    s.state_dims = Int.(state_dims); s.action_dims = Int.(action_dims)
+    return s
 end
 
 # Solver(dynamics, costs) — src/solver.jl:11-26: no constraints, plain iLQR
