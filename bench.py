@@ -69,8 +69,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure HBM traffic of the solve kernel live")
     ap.add_argument("--distinct-shards", action="store_true",
-                    help="rank r solves instances [r*B, (r+1)*B) of one big synthetic batch instead of the same B instances "
-                         "on every rank (weak scaling then also measures how unlucky the worst shard's slowest instance is)")
+                    help="rank r solves instances [r*B, (r+1)*B) of one big synthetic batch (BASELINE config 4's meaning of sharding; "
+                         "the DEFAULT for --gpus N > 1; at N = 1 the shard is [0, B) either way)")
+    ap.add_argument("--same-instances", action="store_true",
+                    help="every rank solves the SAME B instances [0, B) (fixed per-GPU work: weak scaling is then perfect by construction; "
+                         "reported as secondary.same_instances in the default run)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
@@ -235,11 +238,14 @@ def worker(args, solver_factory=None):
     cdev = "cpu" if cpu_group else dev          # where the collectives' tensors live
 
     B = args.batch
-    # weak scaling with IDENTICAL per-GPU work by default: a step lasts as long as the slowest instance of the batch
-    # (iteration counts are data dependent: 500 for the slowest of these 1024 instances, 381..649 for the slowest of
-    # other shards), so distinct shards would fold that data lottery into the scaling figure
+    # N > 1: rank r solves ITS OWN shard [rB, (r+1)B) of one synthetic batch of N * B instances — the batch split BASELINE.json's
+    # configs[3] describes. A step lasts as long as the slowest instance of a shard (iteration counts are data dependent: 500 for the
+    # slowest of the first 1024 acrobot instances, 381..649 for the slowest of other shards), and that is part of the whole-node
+    # figure. --same-instances puts the same B instances on every rank (fixed per-GPU work; secondary.same_instances by default).
+    distinct = bool(args.distinct_shards) or not bool(getattr(args, "same_instances", False))
+    args.distinct_shards = distinct
     lo, _ = pkg.distributed.shard_range(rank, B)
-    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if args.distinct_shards else 0))
+    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if distinct else 0))
     if sharded:
         # one handle, ndev contiguous ranges of B instances: the same B instances on every device (fixed per-GPU work, like the
         # process-per-GPU default) or ndev * B distinct ones
@@ -336,8 +342,11 @@ def worker(args, solver_factory=None):
             barrier()
             return pkg.distributed.max_over_ranks(mine, dist, cdev)
 
-        if not args.distinct_shards:
-            m2, T2, x1b, ubb = pkg.workloads.make_inputs(args.config, B, offset=lo)
+        if world > 1 or not args.distinct_shards:
+            # the other instance assignment than the timed one: distinct shards when the run was --same-instances, the same [0, B) on
+            # every rank when it was distinct (only differs from the timed run for N > 1)
+            other_lo = lo if not args.distinct_shards else 0
+            m2, T2, x1b, ubb = pkg.workloads.make_inputs(args.config, B, offset=other_lo)
             if stub:
                 d2 = (None, None)
             else:
@@ -349,9 +358,11 @@ def worker(args, solver_factory=None):
                 sol.solve_(sync=False)
             el = timed(step_distinct, [sol])
             itmax = pkg.distributed.gather_over_ranks([float(sol.stats()["iterations"].max())], dist, cdev)
-            secondary["distinct_shards"] = {"value": world * B * k2 / el, "unit": "trajectories/s", "ms_per_step": 1e3 * el / k2, "steps": k2,
-                                            "iterations_max_per_rank": [r[0] for r in itmax],
-                                            "note": "rank r solves instances [r*B, (r+1)*B): the data-dependent iteration counts of the shards enter the figure"}
+            key = "same_instances" if args.distinct_shards else "distinct_shards"
+            secondary[key] = {"value": world * B * k2 / el, "unit": "trajectories/s", "ms_per_step": 1e3 * el / k2, "steps": k2,
+                              "iterations_max_per_rank": [r[0] for r in itmax],
+                              "note": ("every rank solves the same instances [0, B): fixed per-GPU work" if args.distinct_shards else
+                                       "rank r solves instances [r*B, (r+1)*B): the data-dependent iteration counts of the shards enter the figure")}
         if len(sols) == 1 and not stub:
             extra = pkg.Solver(model=model, horizon=T, batch=B, device=gpu,
                                options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
@@ -379,13 +390,16 @@ def worker(args, solver_factory=None):
             worst = int(np.argmax(st_["iterations"]))
             lone = pkg.Solver(model=model, horizon=T, batch=1, device=gpu,
                               options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
-            lone.set_kernel_variant_(args.variant)
+            batch_kernel = sol.resolved_kernel_variant()         # "auto" on a batch of ONE would pick the latency kernel whatever the batch ran on
+            lone.set_kernel_variant_(batch_kernel)
+            lone.set_handover_(0)
             lone_ms = []
             for _ in range(3):
                 lone.reset_(); lone.initialize_rollout_(x1[worst:worst + 1], ub[worst:worst + 1]); lone.timing_reset(); lone.solve_(sync=True)
                 lone_ms.append(lone.timing()[0])
             secondary["slowest_instance_alone"] = {"kernel_ms": min(lone_ms[1:]), "instance": worst, "iterations": int(lone.stats()["iterations"][0]),
                                                    "batch_iterations_max": int(st_["iterations"].max()),
+                                                   "kernel_variant": batch_kernel, "kernel_variant_of_the_batch": batch_kernel,
                                                    "note": "one launch of the same kernel with only the batch's slowest instance on the GPU: "
                                                            "the serial latency no batch size can go below; the step's kernel time minus this is "
                                                            "what sharing the SIMDs with the rest of the batch costs that instance"}
@@ -413,7 +427,8 @@ def worker(args, solver_factory=None):
         "config": {"workload": "%s (nx=%d, nu=%d, T=%d) AL-iLQR solve!, batch=%d per GPU, fp64, faithful reference semantics"
                                % (args.config, sol.nx, sol.nu, T, B),
                    "global_batch": n_gpus * B, "horizon": T,
-                   "parallelism": "batch-shard x%d (no collective), %s" % (n_gpus, "distinct shards" if args.distinct_shards else "same %d instances per GPU" % B),
+                   "parallelism": "batch-shard x%d (no collective), %s" % (n_gpus, "distinct shards: rank r solves instances [r*%d, (r+1)*%d)" % (B, B)
+                                                                           if args.distinct_shards else "same %d instances per GPU" % B),
                    "batches_in_flight": len(sols), "kernel_variant": args.variant,
                    "mode": ("shared_step: one step size per iteration for the global batch, all-reduce(sum) of 3 doubles per trial over %s, "
                             "host-stepped line search — changes the iterates, not comparable with the reference" % (backend or "one rank"))
@@ -547,7 +562,8 @@ def worker(args, solver_factory=None):
             O.solve_batch(model, T, x1[:one], ub[:one], options=oopt, nthreads=1, want_policy=False)
             c_one = time.perf_counter() - c0
             out["cpu_baseline"] = {"value": sample / c1, "unit": "trajectories/s", "cores": threads, "kind": "port",
-                                   "single_thread_value": one / c_one,
+                                   "single_thread_value": one / c_one, "sample_instances": sample, "single_thread_sample_instances": one,
+                                   "wall_s": c1, "single_thread_wall_s": c_one,
                                    "sample": "first %d of the %d instances of this workload, C++ oracle "
                                              "(literal restatement of the Julia reference, which cannot run here), "
                                              "OpenMP over instances, %.1f s wall" % (sample, B, c1)}

@@ -217,6 +217,9 @@ int ilqr_scalar_slot(const char* name);
  * residency (up to 4 packs per CU, i.e. batch <= 16 x CUs); 5 = packed, one wave per pack always; 6 = packed, two waves where they
  * fit (= 3; kept distinct for A/B runs). All run the same arithmetic up to the association of a few sums. */
 int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant);
+/* The kernel ilqr_solve launches for this handle as it stands (never 0): 1 latency / four waves per instance, 2 throughput,
+ * 4 one wave per instance (large models), 5 packed with one wave per pack, 6 packed with two. */
+int ilqr_resolved_kernel_variant(ilqr_handle* h, int32_t* variant);
 /* Straggler hand-over of the packed kernel (no counterpart in the reference, which is one trajectory per Solver): a batched
  * launch lasts as long as its slowest instance, and in the packed kernel a straggler keeps a whole wave at 120-240 us per
  * cycle (one line-search trial per cycle). Instances that leave the packed kernel do so with their state complete in the

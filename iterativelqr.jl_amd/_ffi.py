@@ -131,6 +131,7 @@ SYMBOLS = {
     "ilqr_enable_action_value_buffers": (C.c_int, [C.c_void_p]),
     "ilqr_scalar_slot": (C.c_int, [C.c_char_p]),
     "ilqr_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ilqr_resolved_kernel_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "ilqr_set_handover": (C.c_int, [C.c_void_p, C.c_int32]),
     "ilqr_set_handover_live": (C.c_int, [C.c_void_p, C.c_int32]),
     "ilqr_enable_trace": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -147,6 +147,7 @@ class Solver:
         else:      # time-varying stage objects: the handle keeps the selector table and writes it behind the user's parameters in θ_t
             sel = np.ascontiguousarray(self._selectors, dtype=np.float64)
             _ffi.check(L.ilqr_set_stage_selectors(self._h, _p(sel), sel.shape[1]))
+            self.nw -= sel.shape[1]             # what ilqr_get_dims reports from here on: the user's parameters per timestep
 
     # -- src/solver.jl:56-66
     def initialize_controls_(self, u):
@@ -304,6 +305,12 @@ class Solver:
         """"auto" | "latency" | "throughput" | "packed" | "mid" | "packed1" | "packed2" (see ilqr_set_kernel_variant)."""
         v = {"auto": 0, "latency": 1, "throughput": 2, "packed": 3, "mid": 4, "packed1": 5, "packed2": 6}.get(variant, variant)
         _ffi.check(_ffi.lib().ilqr_set_kernel_variant(self._h, int(v)))
+
+    def resolved_kernel_variant(self):
+        """The kernel solve_ launches for this handle as it stands: "latency" | "throughput" | "mid" | "packed1" | "packed2"."""
+        v = C.c_int32(0)
+        _ffi.check(_ffi.lib().ilqr_resolved_kernel_variant(self._h, C.byref(v)))
+        return {1: "latency", 2: "throughput", 4: "mid", 5: "packed1", 6: "packed2"}[v.value]
 
     def set_handover_(self, outer):
         """Straggler hand-over of the packed kernel (see ilqr_set_handover): -1 auto (by head count), 0 off, k >= 2 = instances entering outer iteration k."""

@@ -1319,6 +1319,22 @@ int ilqr_set_kernel_variant(ilqr_handle* h, int32_t variant) {
     return ILQR_OK;
 }
 
+// what ilqr_solve launches for this handle as it stands (variant, batch, horizon): the auto rules of ilqr_solve, stated once more
+int ilqr_resolved_kernel_variant(ilqr_handle* h, int32_t* variant) {
+    if (!h || !variant) return fail(ILQR_ERR_INVALID, "null argument");
+    if (SHARDED(h)) return ilqr_resolved_kernel_variant(h->shards[0], variant);
+    const bool can_pack = h->vt->launch_solve_packed != nullptr;
+    const bool packed = can_pack && (h->variant == 3 || h->variant == 5 || h->variant == 6 || !h->lds_fits || (h->variant == 0 && h->B > h->num_simds));
+    const bool slim = !packed && h->vt->launch_solve_slim != nullptr && (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
+    if (packed) {
+        const int packs = (h->B + 3) / 4, cus = std::max(1, h->num_simds / 4), per_cu = (packs + cus - 1) / cus;
+        *variant = (h->variant != 5 && per_cu <= 4) ? 6 : 5;
+    } else if (slim) *variant = 2;
+    else if (use_mid(h)) *variant = 4;
+    else *variant = 1;
+    return ILQR_OK;
+}
+
 int ilqr_set_handover(ilqr_handle* h, int32_t outer) {
     if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_handover(s, outer); });
     if (!h || outer < -1 || outer == 1) return fail(ILQR_ERR_INVALID, "hand-over: -1 (auto), 0 (off) or the outer iteration (>= 2) from which stragglers leave the packed kernel");

@@ -46,15 +46,15 @@ class OracleSolver:
                  iterations=self.res["stats"]["iterations"], x1=self.x1, ub=self.ub)
 
 
-def _worker(rank, world, port, dump, q):
+def _worker(rank, world, port, dump, q, extra=()):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       ILQR_TEST_DUMP_DIR=dump)
     import contextlib
     import io
     import bench
-    args = bench.parse_args(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--batch", str(B_PER_RANK), "--config", CONFIG,
-                             "--distinct-shards"])
+    # no flag: for N > 1 distinct shards ARE the default (BASELINE config 4's meaning of sharding)
+    args = bench.parse_args(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--batch", str(B_PER_RANK), "--config", CONFIG] + list(extra))
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.worker(args, solver_factory=OracleSolver)
@@ -93,3 +93,25 @@ def test_world_size_2_worker_solves_its_shard_and_the_union_is_the_whole_batch(t
     assert np.array_equal(np.concatenate([p["x"] for p in parts]), whole["x"])
     assert np.array_equal(np.concatenate([p["u"] for p in parts]), whole["u"])
     assert out["solve_stats"]["iterations_max_per_rank"] == [float(p["iterations"].max()) for p in parts]
+
+
+def test_same_instances_flag_puts_the_first_shard_on_every_rank(tmp_path):
+    """--same-instances: the round-4 default, now opt-in — every rank solves instances [0, B) (fixed per-GPU work)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path), q, ("--same-instances",))) for r in range(WORLD)]
+    for p in procs: p.start()
+    outs = dict(q.get(timeout=300) for _ in range(WORLD))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    out = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][0])
+    assert "same %d instances per GPU" % B_PER_RANK in out["config"]["parallelism"]
+    sys.path.insert(0, ROOT)
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
+    model, T, x1, ub = pkg.workloads.make_inputs(CONFIG, B_PER_RANK)
+    for rk in range(WORLD):
+        part = np.load(tmp_path / ("rank%d.npz" % rk))
+        assert np.array_equal(part["x1"], x1) and np.array_equal(part["ub"], ub)
