@@ -428,8 +428,17 @@ def _unpack(names_dims):
     return lines
 
 
+# Functions whose value enters the OBJECTIVE (cost!, src/data/methods.jl:13-30): compiled without FMA contraction, so that J is the
+# same bits at every site they are inlined into — every kernel family forms the objective in one arithmetic (ilqr_device.hpp:
+# objective_term), and an instance may change kernels in the middle of a solve. (hipcc's default, -ffp-contract=fast, lets the
+# backend choose which product of a sum of products to fuse, and it chose differently in different inlining contexts.)
+NO_CONTRACT = ("cost_s", "cost_t", "con_s", "con_t")
+
+
 def _fn(ret, name, args, body):
     out = ["    __device__ __forceinline__ static %s %s(%s) {" % (ret, name, ", ".join(args))]
+    if name in NO_CONTRACT:
+        out.append("#pragma clang fp contract(off)")
     out += ["        " + l for l in body]
     out.append("    }")
     return out

@@ -233,6 +233,45 @@ template <class M> __device__ void reset_model_objective_large(Inst<M>& I, bool 
 template <class M, bool STORE_VALUE> __device__ void backward_pass_large(Inst<M>& I);
 template <class M> __device__ void rollout_large(Inst<M>& I, double alpha, bool want_delta, double& delta_out);
 
+// ------------------------------------------------------------------ the objective, in ONE arithmetic for every small-model kernel
+// J (src/augmented_lagrangian.jl:39-66, src/costs.jl:48-55) feeds the Armijo test (src/forward_pass.jl:44) and the objective
+// tolerance (src/solve.jl:49) and is reported (solver.data.objective, the trace), and an instance may change kernels in the middle
+// of a solve (straggler hand-over, §3.2 of DESIGN.md): every kernel family therefore forms it in the same order, bit for bit —
+//   v_t  = (l_t + λ_tᵀ c_t) + ½ Σ_{a_i = 1} ρ_i c_i²     one timestep's term (objective_term: explicit fma chains, no contraction;
+//                                                         the generated M::cost_*, M::con_* carry `fp contract(off)` themselves)
+//   A_l  = v_l + v_{l+64} + v_{l+128} + …                 ascending, l = 0 … 63 (what lane l of a 64-lane cost pass sums)
+//   S_j  = (A_j + A_{j+32}) + (A_{j+16} + A_{j+48})       j = 0 … 15 (the first two butterfly steps of wave_sum)
+//   J    = butterfly over the 16 S_j (xor 8, 4, 2, 1: wave_sum's last four steps = the packed kernel's row_sum)
+// The 64-lane kernels get this from wave_sum as it stands; the packed kernel (16 lanes per instance, lane j walking t = j, j + 16,
+// …) keeps the four A of its lane apart (ObjAcc) and combines them at the end.
+template <class M, bool STAGE, int NC>
+__device__ __forceinline__ double objective_term(double l, const double (&cv)[NC], const double* lam, const double* rho, double* act, bool with_al) {
+#pragma clang fp contract(off)
+    if (!with_al) return l;
+    double dot = 0.0, pen = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const double lm = lam[i];
+        const bool ineq = STAGE ? IneqMask<M>::s(i) : IneqMask<M>::t(i);
+        const bool inactive = ineq && cv[i] < 0.0 && lm == 0.0;                 // active_set!, src/augmented_lagrangian.jl:77-82
+        act[i] = inactive ? 0.0 : 1.0;
+        dot = __builtin_fma(lm, cv[i], dot);
+        const double c2 = cv[i] * cv[i], hr = 0.5 * rho[i];
+        if (!inactive) pen = __builtin_fma(hr, c2, pen);
+    }
+    return (l + dot) + pen;
+}
+// the four residue sums A_j, A_{j+16}, A_{j+32}, A_{j+48} of a lane that walks t = j (mod 16): timestep t adds to A[(t >> 4) & 3].
+// Adding +0.0 to the others is exact (a sum that starts at +0.0 never becomes -0.0), so the select is on the addend.
+struct ObjAcc {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    __device__ __forceinline__ void add(int t, double v) {
+        const int q = (t >> 4) & 3;
+        a0 += q == 0 ? v : 0.0; a1 += q == 1 ? v : 0.0; a2 += q == 2 ? v : 0.0; a3 += q == 3 ? v : 0.0;
+    }
+    __device__ __forceinline__ double S() const { return (a0 + a2) + (a1 + a3); }
+};
+
 // ------------------------------------------------------------------ cost!
 // One timestep per lane. upd_J: evaluate J and the active set at (X,U)
 // (src/augmented_lagrangian.jl:39-85); upd_viol: overwrite the violations
@@ -253,26 +292,16 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
             double ut[m];
 #pragma unroll
             for (int i = 0; i < m; ++i) ut[i] = U[t * m + i];
-            if (upd_J) Jp += M::cost_s(xt, ut, w);
+            double l_ = 0.0;
+            if (upd_J) { l_ = M::cost_s(xt, ut, w); ILQR_OPAQUE(l_); }
+            if constexpr (ncs == 0) { if (upd_J) Jp += l_; }
             if constexpr (ncs > 0) {
+                if (!constrained) { if (upd_J) Jp += l_; }
                 if (constrained) {
                     double cv[ncs];
                     M::con_s(xt, ut, w, cv);
                     const int off = t * ncs;
-                    if (upd_J) {
-                        double dot = 0.0, pen = 0.0;
-#pragma unroll
-                        for (int i = 0; i < ncs; ++i) {
-                            const double lam = I.lam[off + i];
-                            const bool ineq = IneqMask<M>::s(i);
-                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
-                            I.act[off + i] = inactive ? 0.0 : 1.0;
-                            dot += lam * cv[i];
-                            if (!inactive) pen += 0.5 * I.rho[off + i] * (cv[i] * cv[i]);
-                        }
-                        Jp += dot;
-                        Jp += pen;
-                    }
+                    if (upd_J) { double v_ = objective_term<M, true, ncs>(l_, cv, I.lam + off, I.rho + off, I.act + off, true); ILQR_OPAQUE(v_); Jp += v_; }
                     if (upd_viol) {
 #pragma unroll
                         for (int i = 0; i < ncs; ++i) {
@@ -284,26 +313,16 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
                 }
             }
         } else {
-            if (upd_J) Jp += M::cost_t(xt, w);
+            double l_ = 0.0;
+            if (upd_J) { l_ = M::cost_t(xt, w); ILQR_OPAQUE(l_); }
+            if constexpr (nct == 0) { if (upd_J) Jp += l_; }
             if constexpr (nct > 0) {
+                if (!constrained) { if (upd_J) Jp += l_; }
                 if (constrained) {
                     double cv[nct];
                     M::con_t(xt, w, cv);
                     const int off = I.N * ncs;
-                    if (upd_J) {
-                        double dot = 0.0, pen = 0.0;
-#pragma unroll
-                        for (int i = 0; i < nct; ++i) {
-                            const double lam = I.lam[off + i];
-                            const bool ineq = IneqMask<M>::t(i);
-                            const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
-                            I.act[off + i] = inactive ? 0.0 : 1.0;
-                            dot += lam * cv[i];
-                            if (!inactive) pen += 0.5 * I.rho[off + i] * (cv[i] * cv[i]);
-                        }
-                        Jp += dot;
-                        Jp += pen;
-                    }
+                    if (upd_J) { double v_ = objective_term<M, false, nct>(l_, cv, I.lam + off, I.rho + off, I.act + off, true); ILQR_OPAQUE(v_); Jp += v_; }
                     if (upd_viol) {
 #pragma unroll
                         for (int i = 0; i < nct; ++i) {

@@ -134,14 +134,14 @@ __device__ __forceinline__ void cost_load(const double* g, const Layout& L, int 
             if (i < cnt) { o.lam[i] = g[L.lam + off + i]; o.rho[i] = g[L.rho + off + i]; }
     }
 }
-// (Inlined into its two callers — cost_pass and the helper wave's cost_follow — hipcc contracts the model's sums of products into
-// FMAs differently: the two forms of the kernel report objectives ONE ULP apart on a few trials. A shared real function makes them
-// bitwise equal — cost_eval alone, operands by reference: +25 % kernel time; a lane's whole walk by value: +1.5 % on the one-wave
-// form and half the two-wave form's gain — and was not kept: the model's cost is opaque to the accumulation and the constraint terms
-// are explicit fma chains, the rest is the compiler's; the two forms are compared bitwise in everything but the reported objective.)
+// (Inlined into its two callers — cost_pass and the helper wave's cost_follow. Round 4: hipcc contracted the model's sums of products
+// into FMAs differently at the two sites and the two forms of the kernel reported objectives one ulp apart on a few trials. Since
+// round 5 the generated M::cost_s / cost_t / con_s / con_t carry `#pragma clang fp contract(off)`, the AL terms are the explicit fma
+// chains of objective_term (ilqr_device.hpp) and the sums follow the canonical order stated there: J is the same bits in every
+// kernel family, wherever an instance changes kernels.)
 template <class M>
 __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const CostIn<M>& cur, int t, bool upd_J, bool upd_viol, bool constrained,
-                                          double& Jp, double& vp) {
+                                          ObjAcc& Jp, double& vp) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     const int N = L.T - 1;
     double* cbuf = g + L.c; double* act = g + L.act;
@@ -151,26 +151,16 @@ __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const Cost
         double ut[m];
 #pragma unroll
         for (int i = 0; i < m; ++i) ut[i] = cur.u[i];
-        if (upd_J) { double l_ = M::cost_s(xt, ut, w); ILQR_OPAQUE(l_); Jp += l_; }
+        double l_ = 0.0;
+        if (upd_J) { l_ = M::cost_s(xt, ut, w); ILQR_OPAQUE(l_); }
+        if constexpr (ncs == 0) { if (upd_J) Jp.add(t, l_); }
         if constexpr (ncs > 0) {
+            if (!constrained) { if (upd_J) Jp.add(t, l_); }
             if (constrained) {
                 double cv[ncs];
                 M::con_s(xt, ut, w, cv);
                 const int off = t * ncs;
-                if (upd_J) {
-                    double dot = 0.0, pen = 0.0;
-#pragma unroll
-                    for (int i = 0; i < ncs; ++i) {
-                        const double lam = cur.lam[i];
-                        const bool ineq = IneqMask<M>::s(i);
-                        const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
-                        act[off + i] = inactive ? 0.0 : 1.0;
-                        dot = fma(lam, cv[i], dot);
-                        if (!inactive) pen = fma(0.5 * cur.rho[i], cv[i] * cv[i], pen);
-                    }
-                    Jp += dot;
-                    Jp += pen;
-                }
+                if (upd_J) { double v_ = objective_term<M, true, ncs>(l_, cv, cur.lam, cur.rho, act + off, true); ILQR_OPAQUE(v_); Jp.add(t, v_); }
                 if (upd_viol) {
 #pragma unroll
                     for (int i = 0; i < ncs; ++i) {
@@ -182,26 +172,16 @@ __device__ __forceinline__ void cost_eval(double* g, const Layout& L, const Cost
             }
         }
     } else {
-        if (upd_J) { double l_ = M::cost_t(xt, w); ILQR_OPAQUE(l_); Jp += l_; }
+        double l_ = 0.0;
+        if (upd_J) { l_ = M::cost_t(xt, w); ILQR_OPAQUE(l_); }
+        if constexpr (nct == 0) { if (upd_J) Jp.add(t, l_); }
         if constexpr (nct > 0) {
+            if (!constrained) { if (upd_J) Jp.add(t, l_); }
             if (constrained) {
                 double cv[nct];
                 M::con_t(xt, w, cv);
                 const int off = N * ncs;
-                if (upd_J) {
-                    double dot = 0.0, pen = 0.0;
-#pragma unroll
-                    for (int i = 0; i < nct; ++i) {
-                        const double lam = cur.lam[i];
-                        const bool ineq = IneqMask<M>::t(i);
-                        const bool inactive = ineq && cv[i] < 0.0 && lam == 0.0;
-                        act[off + i] = inactive ? 0.0 : 1.0;
-                        dot = fma(lam, cv[i], dot);
-                        if (!inactive) pen = fma(0.5 * cur.rho[i], cv[i] * cv[i], pen);
-                    }
-                    Jp += dot;
-                    Jp += pen;
-                }
+                if (upd_J) { double v_ = objective_term<M, false, nct>(l_, cv, cur.lam, cur.rho, act + off, true); ILQR_OPAQUE(v_); Jp.add(t, v_); }
                 if (upd_viol) {
 #pragma unroll
                     for (int i = 0; i < nct; ++i) {
@@ -218,7 +198,8 @@ template <class M>
 __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol, bool constrained, double& J_out, double& viol_out) {
     const Layout& L = I.L;
     const int T = L.T;
-    double Jp = 0.0, vp = 0.0;
+    ObjAcc Jp;
+    double vp = 0.0;
     // A lane walks its timesteps t = j, j + 16, ...; every pass needs x_t, u_t, λ_t, ρ_t from HBM / L2 and nothing hides that
     // round trip at one wave per SIMD (the pass used to cost one round trip per 16 timesteps: 9 of the 80 µs of a car cycle).
     // The operands of the NEXT pass are requested before the current one is evaluated.
@@ -231,7 +212,7 @@ __device__ void cost_pass(PInst<M>& I, int Xo, int Uo, bool upd_J, bool upd_viol
         cost_eval<M>(I.g, L, cur, t, upd_J, upd_viol, constrained, Jp, vp);
         cur = nxt;
     }
-    J_out = row_sum(Jp);
+    J_out = row_sum(Jp.S());
     viol_out = row_max(vp);
     pk_sync<M>(I);
 }
@@ -782,7 +763,8 @@ __device__ void pk_helper(const KArgs& a) {
             // that produces the trajectory — segment k of 15 timesteps once the solver wave has passed its k-th in-loop barrier, the
             // rest and the terminal timestep behind the rollout's closing barrier. Lane j takes the timesteps t with t % 16 == j in
             // ascending order, as cost_pass does: the same per-lane sums, the same reduction.
-            double Jp = 0.0, vp = 0.0;
+            ObjAcc Jp;
+            double vp = 0.0;
             CostIn<M> in;
             const int nseg = pk_rollout_segments(N);
             for (int k = 0; k <= nseg; ++k) {                               // k == nseg: behind the rollout's closing barrier, up to the terminal timestep
@@ -795,7 +777,7 @@ __device__ void pk_helper(const KArgs& a) {
                     }
                 }
             }
-            const double J = row_sum(Jp), v = row_max(vp);
+            const double J = row_sum(Jp.S()), v = row_max(vp);
             if (j == 0) { pk_lds[LD::RES + q] = J; pk_lds[LD::RES + 4 + q] = v; }
             __syncthreads(); ++nb;                                          // answers in place
         }

@@ -146,8 +146,10 @@ def _whole_solve(pkg, oracle, config, B, min_match):
     dx = np.abs(x - ref["x"]).reshape(B, -1).max(1); du = np.abs(u - ref["u"]).reshape(B, -1).max(1)
     Kmax = np.abs(ref["K"]).reshape(B, -1).max(1)
     dK = np.abs(K - ref["K"]).reshape(B, -1).max(1) / np.maximum(Kmax, 1.0)
-    assert dx[same_f].max() <= 1e-7 and du[same_f].max() <= 1e-7, (dx[same_f].max(), du[same_f].max())
-    assert dK[same_f].max() <= 5e-7, dK[same_f].max()
+    # tolerances ~10x what is observed on every BASELINE-size workload (profiles/r04_parity.txt, r05_parity.txt: control flow
+    # identical on 100 % of the instances, max |dx|, |du| 1.6e-9, max |dK| / max |K| 2.2e-8)
+    assert dx[same_f].max() <= 2e-8 and du[same_f].max() <= 2e-8, (dx[same_f].max(), du[same_f].max())
+    assert dK[same_f].max() <= 1e-7, dK[same_f].max()
     assert np.allclose(st["objective"][same_f], rs["objective"][same_f], rtol=1e-8)
     assert np.allclose(st["max_violation"][same_f], rs["max_violation"][same_f], rtol=1e-6, atol=1e-10)
     assert (st["potrf_info"] == rs["potrf_info"])[same].all()
@@ -159,22 +161,22 @@ def _whole_solve(pkg, oracle, config, B, min_match):
 
 
 def test_particle_whole_solve(pkg, oracle):
-    _whole_solve(pkg, oracle, "particle", 64, 0.99)
+    _whole_solve(pkg, oracle, "particle", 64, 0.999)
 
 
 def test_acrobot_whole_solve_t51(pkg, oracle):
-    r = _whole_solve(pkg, oracle, "acrobot51", 64, 0.99)
+    r = _whole_solve(pkg, oracle, "acrobot51", 64, 0.999)
     assert (np.abs(r["x"][:, -1, :] - [np.pi, 0, 0, 0]).max(1) < 5e-3).all()      # test/acrobot.jl:114
 
 
 def test_acrobot_whole_solve_headline(pkg, oracle):
     """BASELINE configs[1]: acrobot T=101, batch=1024."""
-    r = _whole_solve(pkg, oracle, "acrobot", 1024, 0.99)
+    r = _whole_solve(pkg, oracle, "acrobot", 1024, 0.999)
     assert (np.abs(r["x"][:, -1, :] - [np.pi, 0, 0, 0]).max(1) < 5e-3).mean() > 0.99
 
 
 def test_car_whole_solve(pkg, oracle):
-    r = _whole_solve(pkg, oracle, "car", 256, 0.99)
+    r = _whole_solve(pkg, oracle, "car", 256, 0.999)
     x, u = r["x"], r["u"]
     # test/car.jl:74-79 on instance 0 (the reference's deterministic initialisation)
     e = x[0, :-1, :2] - 0.5
@@ -185,7 +187,7 @@ def test_car_whole_solve(pkg, oracle):
 
 
 def test_car_goal_whole_solve(pkg, oracle):
-    _whole_solve(pkg, oracle, "car_goal", 256, 0.99)
+    _whole_solve(pkg, oracle, "car_goal", 256, 0.999)
 
 
 def test_resolve_is_deterministic(pkg):
@@ -482,7 +484,7 @@ def test_long_horizon_above_64k_lds(pkg, oracle):
     x, u = sol.get_trajectory(); st = sol.stats()
     ref = oracle.solve_batch("acrobot", T, x1, ub, options=oracle.default_options(max_dual_updates=2, max_iterations=15), nthreads=6)
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.8
+    assert same.all(), same          # six instances, 300 steps: observed identical control flow on all of them
     assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
     sol.close()
 
@@ -677,8 +679,8 @@ def test_synth12_workload_builtin_equals_plugin_and_oracle(pkg, oracle):
     ref = oracle.solve_batch(model, T, x1, ub, options=oracle.default_options(**kw), nthreads=8)
     st = res["mid"]["st"]
     same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.95, same.mean()
-    assert np.abs(res["mid"]["x"] - ref["x"])[same].max() < 1e-7 and np.abs(res["mid"]["u"] - ref["u"])[same].max() < 1e-7
+    assert same.mean() >= 0.999, same.mean()
+    assert np.abs(res["mid"]["x"] - ref["x"])[same].max() < 2e-8 and np.abs(res["mid"]["u"] - ref["u"])[same].max() < 2e-8
 
 
 def _ragged_inputs(pr, B, seed=5):
@@ -831,26 +833,15 @@ def test_packed_kernel_with_a_linearisation_server_equals_the_one_wave_form(pkg,
         st = sol.stats()
         out[(v, ho)] = dict(x=sol.get_trajectory()[0], u=sol.get_trajectory()[1], K=sol.get_policy()[0], k=sol.get_policy()[1],
                             lam=sol.buffer("constraint_dual"), fx=sol.buffer("jacobian_state"), gxx=sol.buffer("hessian_state_state"),
-                            it=st["iterations"], ro=st["rollouts"], oi=st["outer_iterations"], viol=st["max_violation"], tr=sol.trace())
+                            it=st["iterations"], ro=st["rollouts"], oi=st["outer_iterations"], viol=st["max_violation"], obj=st["objective"],
+                            tr=sol.trace())
         sol.close()
     a = out[("packed1", 0)]
     for key in (("packed2", 0), ("packed2", -1)):
         b = out[key]
         for f in a:
-            if key[1] == -1 and config == "car_obs":
-                # the two-wave latency kernel that finishes handed-over instances is not bitwise the packed kernel on THIS model (a few
-                # instances 5e-14 apart in x, control flow identical; one-wave and two-wave packed forms agree with each other under
-                # hand-over too): compared to rounding here
-                assert np.allclose(a[f], b[f], rtol=1e-9, atol=1e-11, equal_nan=True), (key, f)
-                continue
-            if f == "tr":
-                # the objective REPORTED in a trace row: the helper wave's cost code is the one-wave form's source inlined in another
-                # place, and hipcc contracts the model's sums of products differently there (one ulp on a few trials); an instance that
-                # changed kernels reports the latency kernel's summation order. Everything the solve computes WITH is compared bitwise.
-                cols = [c for c in range(a[f].shape[-1]) if c != 2]
-                assert np.array_equal(a[f][..., cols], b[f][..., cols], equal_nan=True), (key, f)
-                assert np.allclose(a[f][..., 2], b[f][..., 2], rtol=4e-16, atol=0.0, equal_nan=True), (key, f, "objective")
-                continue
+            # every field BITWISE, the objective of every trace row included: all kernel families form J in one arithmetic
+            # (ilqr_device.hpp: objective_term, ObjAcc; the generated cost / constraint functions are compiled without FMA contraction)
             assert np.array_equal(a[f], b[f], equal_nan=True), (key, f)
     ref = oracle.solve_batch(model, T, x1, ub, nthreads=8, w=w)
     same = (a["it"] == ref["stats"]["iterations"]) & (a["ro"] == ref["stats"]["rollouts"])
@@ -1413,8 +1404,8 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
     """ilqr_set_handover_live: once no more than `live` instances of the batch are still running, each survivor leaves the packed
     kernel at the head of its next inner or outer iteration and the latency kernel finishes it in a launch behind it. WHICH
     instances leave, and where, depends on the timing of the run — so nothing may depend on it: counts, trace rows and every
-    array must be those of the packed kernel alone, bitwise (the two kernels do the same arithmetic; only the REPORTED
-    objective of a trace row is summed in another order: one ulp), run after run."""
+    array must be those of the packed kernel alone, bitwise — the reported objective included: the two kernels do the same
+    arithmetic, J in one canonical order (ilqr_device.hpp: objective_term) —, run after run."""
     model, T, x1, ub = pkg.workloads.make_inputs(config, B)
 
     def run(on):
@@ -1430,12 +1421,10 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
     for rep in range(3):
         on = run(True)
         assert (on["resume"] == 0).all()
-        for k in ("iterations", "outer_iterations", "rollouts", "status", "potrf_info"):
-            assert np.array_equal(off["st"][k], on["st"][k]), k
+        for k in ("iterations", "outer_iterations", "rollouts", "status", "potrf_info", "objective", "max_violation", "gradient_norm", "step_size"):
+            assert np.array_equal(off["st"][k], on["st"][k], equal_nan=True), k
         assert np.array_equal(off["tl"], on["tl"])
-        cols = [0, 1, 3, 4, 5, 6, 7]
-        assert np.array_equal(off["tr"][:, :, cols], on["tr"][:, :, cols], equal_nan=True)
-        assert np.allclose(off["tr"][:, :, 2], on["tr"][:, :, 2], rtol=1e-14, atol=0, equal_nan=True)
+        assert np.array_equal(off["tr"], on["tr"], equal_nan=True)            # every column, the objective included (one arithmetic for J in every kernel)
         # delta: the Armijo product of the LAST forward pass — the first one after a hand-over takes the number the packed kernel's
         # backward pass left in the block (S_DELTA_NEXT), not a sum of its own in another order
         for k in ("x", "u", "K", "k", "lam", "fx", "gxx", "delta"):
@@ -1459,10 +1448,9 @@ def test_packed_kernel_extra_trials_for_an_instance_that_keeps_rejecting(pkg):
         s.close()
     a, b = out["packed"], out["latency"]
     assert a["st"]["rollouts"][0] - a["st"]["iterations"][0] >= 500          # the rejecting kind
-    for k in ("iterations", "outer_iterations", "rollouts", "status"):
+    for k in ("iterations", "outer_iterations", "rollouts", "status", "objective"):
         assert np.array_equal(a["st"][k], b["st"][k]), k
-    cols = [0, 1, 3, 4, 5, 6, 7]
-    assert np.array_equal(a["tr"][:, :, cols], b["tr"][:, :, cols], equal_nan=True)
+    assert np.array_equal(a["tr"], b["tr"], equal_nan=True)
     for k in ("x", "u", "K", "lam"):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
 
