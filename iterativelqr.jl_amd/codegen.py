@@ -103,6 +103,43 @@ _INLINE_FP = {0.0, 0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 4.0, -4.0}
 
 
 class _Printer(C99CodePrinter):
+    # Sums of products are emitted as EXPLICIT fma chains, and every generated function is compiled with FMA contraction off
+    # (`#pragma clang fp contract(off)`, _fn below): which product of a sum the backend fuses under hipcc's default
+    # -ffp-contract=fast depends on the code the function is inlined into, so the same model function gave results one ulp apart in
+    # the latency, the packed and the stage kernels (car_obs: trajectories 5e-14 apart after a hand-over). With the fusion written
+    # out, a generated function computes the same bits wherever it is inlined. Order: the terms of a sum in sympy's canonical
+    # order; plain terms are added first, then each product is folded in with one fma (a product of more than two factors keeps
+    # its first factor as the fma's multiplier and forms the rest with plain multiplications).
+    def _print_Add(self, expr):
+        plain, prods = [], []
+        for t in expr.as_ordered_terms():
+            f = [a for a in sp.Mul.make_args(t)]
+            nonnum = [a for a in f if not a.is_Number]
+            if len(f) >= 2 and not (len(f) == 2 and f[0] == -1) and len(nonnum) >= 1 and not (len(nonnum) == 1 and len(f) == 2 and f[0] in (1, -1)):
+                prods.append(f)
+            else:
+                plain.append(t)
+        if not prods:
+            return super()._print_Add(expr)
+        acc = None
+        if plain:
+            acc = super()._print_Add(sp.Add(*plain, evaluate=False)) if len(plain) > 1 else self._print(plain[0])
+            if len(plain) > 1:
+                acc = "(" + acc + ")"
+        for f in prods:
+            a = f[0]
+            rest = sp.Mul(*f[1:], evaluate=False) if len(f) > 2 else f[1]
+            sa = self.parenthesize(a, PRECEDENCE["Mul"])
+            sr = self._print(rest) if len(f) == 2 else "(" + self._print_Mul_plain(f[1:]) + ")"
+            if acc is None:
+                acc = "(%s*%s)" % (sa, self.parenthesize(rest, PRECEDENCE["Mul"]) if len(f) == 2 else sr)
+            else:
+                acc = "fma(%s, %s, %s)" % (sa, sr, acc)
+        return acc
+
+    def _print_Mul_plain(self, factors):
+        return "*".join(self.parenthesize(a, PRECEDENCE["Mul"]) for a in factors)
+
     def _print_Float(self, expr):
         v = float(expr)
         if _CONST_CTX is not None and v not in _INLINE_FP:
@@ -428,17 +465,13 @@ def _unpack(names_dims):
     return lines
 
 
-# Functions whose value enters the OBJECTIVE (cost!, src/data/methods.jl:13-30): compiled without FMA contraction, so that J is the
-# same bits at every site they are inlined into — every kernel family forms the objective in one arithmetic (ilqr_device.hpp:
-# objective_term), and an instance may change kernels in the middle of a solve. (hipcc's default, -ffp-contract=fast, lets the
-# backend choose which product of a sum of products to fuse, and it chose differently in different inlining contexts.)
-NO_CONTRACT = ("cost_s", "cost_t", "con_s", "con_t")
-
-
+# Every generated function is compiled with FMA contraction off and carries its fusions explicitly (_Printer._print_Add): the same
+# bits wherever it is inlined — every kernel family forms the objective in one arithmetic (ilqr_device.hpp: objective_term), and
+# an instance may change kernels in the middle of a solve (hand-over), so the linearisation, the rollout and the cost must not
+# depend on the inlining context either.
 def _fn(ret, name, args, body):
     out = ["    __device__ __forceinline__ static %s %s(%s) {" % (ret, name, ", ".join(args))]
-    if name in NO_CONTRACT:
-        out.append("#pragma clang fp contract(off)")
+    out.append("#pragma clang fp contract(off)")
     out += ["        " + l for l in body]
     out.append("    }")
     return out

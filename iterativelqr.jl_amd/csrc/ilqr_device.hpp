@@ -261,6 +261,12 @@ __device__ __forceinline__ double objective_term(double l, const double (&cv)[NC
     }
     return (l + dot) + pen;
 }
+// Iρ = ρ∘a and c̃ = λ + Iρ c of the Gauss-Newton AL terms (src/gradients.jl:56-62), one row: c̃ as ONE fma in every kernel
+__device__ __forceinline__ void al_multipliers(double rho, double act, double lam, double c, double& ir, double& ct) {
+#pragma clang fp contract(off)
+    ir = rho * act;
+    ct = __builtin_fma(ir, c, lam);
+}
 // the four residue sums A_j, A_{j+16}, A_{j+32}, A_{j+48} of a lane that walks t = j (mod 16): timestep t adds to A[(t >> 4) & 3].
 // Adding +0.0 to the others is exact (a sum that starts at +0.0 never becomes -0.0), so the select is on the addend.
 struct ObjAcc {
@@ -401,116 +407,39 @@ __device__ void gradients_small(Inst<M>& I, bool constrained) {
                 for (int i = 0; i < m; ++i) I.gu[t * m + i] = gu[i];
                 continue;
             }
-            double hxx[n * n], huu[m * m], hux[m * n];
-            M::cost_s_hess(xt, ut, w, hxx, huu, hux);
-            double axx[n * n], auu[m * m], aux[m * n];
-#pragma unroll
-            for (int i = 0; i < n * n; ++i) axx[i] = I.gxx[t * n * n + i] + hxx[i];
-#pragma unroll
-            for (int i = 0; i < m * m; ++i) auu[i] = I.guu[t * m * m + i] + huu[i];
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) aux[i] = I.gux[t * m * n + i] + hux[i];
+            // `.+=` of the cost Hessian (src/costs.jl:74-80), then the Gauss-Newton AL terms (src/gradients.jl:54-80), both straight into
+            // the accumulated arrays through the model's structural accumulators — the SAME two calls, in the same order, as the packed
+            // kernel's linearise_stage: whichever kernel linearises an instance, the accumulated Hessians are the same bits (round 4
+            // formed them here with dense loops over cx, cu in registers: equal algebra, other roundings — car_obs showed it)
+            M::cost_s_hess_acc(xt, ut, w, I.gxx + t * n * n, I.guu + t * m * m, I.gux + t * m * n);
             if constexpr (ncs > 0) {
                 if (constrained) {
-                    double cx[ncs * n], cu[ncs * m], ct[ncs], ir[ncs];
-                    M::con_s_jac(xt, ut, w, cx, cu);
+                    double ct[ncs], ir[ncs];
                     const int off = t * ncs;
 #pragma unroll
-                    for (int i = 0; i < ncs; ++i) {
-                        ir[i] = I.rho[off + i] * I.act[off + i];
-                        ct[i] = I.lam[off + i] + ir[i] * I.c[off + i];
-                    }
-#pragma unroll
-                    for (int j = 0; j < n; ++j) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int i = 0; i < ncs; ++i) acc += cx[j * ncs + i] * ct[i];
-                        gx[j] += acc;
-                    }
-#pragma unroll
-                    for (int j = 0; j < n; ++j)
-#pragma unroll
-                        for (int i2 = 0; i2 < n; ++i2) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int i = 0; i < ncs; ++i) acc += cx[i2 * ncs + i] * (ir[i] * cx[j * ncs + i]);
-                            axx[j * n + i2] += acc;
-                        }
-#pragma unroll
-                    for (int j = 0; j < m; ++j) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int i = 0; i < ncs; ++i) acc += cu[j * ncs + i] * ct[i];
-                        gu[j] += acc;
-                    }
-#pragma unroll
-                    for (int j = 0; j < m; ++j)
-#pragma unroll
-                        for (int i2 = 0; i2 < m; ++i2) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int i = 0; i < ncs; ++i) acc += cu[i2 * ncs + i] * (ir[i] * cu[j * ncs + i]);
-                            auu[j * m + i2] += acc;
-                        }
-#pragma unroll
-                    for (int j = 0; j < n; ++j)
-#pragma unroll
-                        for (int i2 = 0; i2 < m; ++i2) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int i = 0; i < ncs; ++i) acc += cu[i2 * ncs + i] * (ir[i] * cx[j * ncs + i]);
-                            aux[j * m + i2] += acc;
-                        }
+                    for (int i = 0; i < ncs; ++i) al_multipliers(I.rho[off + i], I.act[off + i], I.lam[off + i], I.c[off + i], ir[i], ct[i]);
+                    M::al_s(xt, ut, w, ct, ir, gx, gu, I.gxx + t * n * n, I.guu + t * m * m, I.gux + t * m * n);
                 }
             }
 #pragma unroll
             for (int i = 0; i < n; ++i) I.gx[t * n + i] = gx[i];
 #pragma unroll
             for (int i = 0; i < m; ++i) I.gu[t * m + i] = gu[i];
-#pragma unroll
-            for (int i = 0; i < n * n; ++i) I.gxx[t * n * n + i] = axx[i];
-#pragma unroll
-            for (int i = 0; i < m * m; ++i) I.guu[t * m * m + i] = auu[i];
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) I.gux[t * m * n + i] = aux[i];
         } else {
-            double gx[n], hxx[n * n], axx[n * n];
+            double gx[n];
             M::cost_t_grad(xt, w, gx);
-            M::cost_t_hess(xt, w, hxx);
-#pragma unroll
-            for (int i = 0; i < n * n; ++i) axx[i] = I.gxx[t * n * n + i] + hxx[i];
+            M::cost_t_hess_acc(xt, w, I.gxx + t * n * n);
             if constexpr (nct > 0) {
                 if (constrained) {
-                    double cx[nct * n], ct[nct], ir[nct];
-                    M::con_t_jac(xt, w, cx);
+                    double ct[nct], ir[nct];
                     const int off = I.N * ncs;
 #pragma unroll
-                    for (int i = 0; i < nct; ++i) {
-                        ir[i] = I.rho[off + i] * I.act[off + i];
-                        ct[i] = I.lam[off + i] + ir[i] * I.c[off + i];
-                    }
-#pragma unroll
-                    for (int j = 0; j < n; ++j) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int i = 0; i < nct; ++i) acc += cx[j * nct + i] * ct[i];
-                        gx[j] += acc;
-                    }
-#pragma unroll
-                    for (int j = 0; j < n; ++j)
-#pragma unroll
-                        for (int i2 = 0; i2 < n; ++i2) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int i = 0; i < nct; ++i) acc += cx[i2 * nct + i] * (ir[i] * cx[j * nct + i]);
-                            axx[j * n + i2] += acc;
-                        }
+                    for (int i = 0; i < nct; ++i) al_multipliers(I.rho[off + i], I.act[off + i], I.lam[off + i], I.c[off + i], ir[i], ct[i]);
+                    M::al_t(xt, w, ct, ir, gx, I.gxx + t * n * n);
                 }
             }
 #pragma unroll
             for (int i = 0; i < n; ++i) I.gx[t * n + i] = gx[i];
-#pragma unroll
-            for (int i = 0; i < n * n; ++i) I.gxx[t * n * n + i] = axx[i];
         }
     }
     __syncthreads();
@@ -1816,6 +1745,17 @@ __device__ void reset_model_objective(Inst<M>& I, bool literal = true) {
 }
 
 // augmented_lagrangian_update! — src/augmented_lagrangian.jl:87-110
+// augmented_lagrangian_update! for one constraint row (src/augmented_lagrangian.jl:100-108): λ ← λ + ρ c (one fma: the same bits in
+// every kernel that runs it — left to the compiler, the latency and the packed kernel contracted it differently on car_obs),
+// inequalities clamped at 0 (Julia's max propagates NaN), ρ ← min(scaling ρ, max_penalty) (Julia's min propagates NaN)
+__device__ __forceinline__ void dual_update_row(double& lam, double& rho, double c, bool ineq, const ilqr_options& opt) {
+#pragma clang fp contract(off)
+    double l = __builtin_fma(rho, c, lam);
+    if (ineq) l = nanmax(0.0, l);
+    lam = l;
+    const double r = opt.scaling_penalty * rho;
+    rho = (r < opt.max_penalty || r != r) ? r : opt.max_penalty;
+}
 template <class M>
 __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
     constexpr int ncs = M::NCS, W = waves_of<M>::value;
@@ -1824,11 +1764,9 @@ __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
         bool ineq;
         if (i < ns) ineq = ncs > 0 ? IneqMask<M>::s(i % (ncs > 0 ? ncs : 1)) : false;
         else ineq = IneqMask<M>::t(i - ns);
-        double lam = I.lam[i] + I.rho[i] * I.c[i];
-        if (ineq) lam = nanmax(0.0, lam);
-        I.lam[i] = lam;
-        const double r = opt.scaling_penalty * I.rho[i];
-        I.rho[i] = (r < opt.max_penalty || r != r) ? r : opt.max_penalty;      // Julia's min propagates NaN
+        double lam = I.lam[i], rho = I.rho[i];
+        dual_update_row(lam, rho, I.c[i], ineq, opt);
+        I.lam[i] = lam; I.rho[i] = rho;
     }
     __syncthreads();
 }

@@ -296,10 +296,7 @@ __attribute__((noinline)) __device__ void linearise_stage(LinArgs a) {
             double ct[ncs], ir[ncs];
             const int off = t * ncs;
 #pragma unroll
-            for (int i = 0; i < ncs; ++i) {
-                ir[i] = gr[a.rho + off + i] * gr[a.act + off + i];
-                ct[i] = gr[a.lam + off + i] + ir[i] * gr[a.c + off + i];
-            }
+            for (int i = 0; i < ncs; ++i) al_multipliers(gr[a.rho + off + i], gr[a.act + off + i], gr[a.lam + off + i], gr[a.c + off + i], ir[i], ct[i]);
             M::al_s(xt, ut, w, ct, ir, gx, gu, gxx, guu, gux);
         }
     }
@@ -340,10 +337,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
                 double ct[nct], ir[nct];
                 const int off = N * ncs;
 #pragma unroll
-                for (int i = 0; i < nct; ++i) {
-                    ir[i] = gr[L.rho + off + i] * gr[L.act + off + i];
-                    ct[i] = gr[L.lam + off + i] + ir[i] * gr[L.c + off + i];
-                }
+                for (int i = 0; i < nct; ++i) al_multipliers(gr[L.rho + off + i], gr[L.act + off + i], gr[L.lam + off + i], gr[L.c + off + i], ir[i], ct[i]);
                 M::al_t(xt, w, ct, ir, gx, gxx);
             }
         }
@@ -684,10 +678,7 @@ __attribute__((noinline)) __device__ void materialise_stage(LinArgs a, int fx_of
             double ct[ncs], ir[ncs], dxx[n * n], duu[m * m], dux[m * n];
             const int off = t * ncs;
 #pragma unroll
-            for (int i = 0; i < ncs; ++i) {
-                ir[i] = gr[a.rho + off + i] * gr[a.act + off + i];
-                ct[i] = gr[a.lam + off + i] + ir[i] * gr[a.c + off + i];
-            }
+            for (int i = 0; i < ncs; ++i) al_multipliers(gr[a.rho + off + i], gr[a.act + off + i], gr[a.lam + off + i], gr[a.c + off + i], ir[i], ct[i]);
 #pragma unroll
             for (int i = 0; i < n * n; ++i) dxx[i] = 0.0;
 #pragma unroll
@@ -879,11 +870,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
                         bool ineq;
                         if (i < ns) ineq = ncs > 0 ? IneqMask<M>::s(i % (ncs > 0 ? ncs : 1)) : false;
                         else ineq = IneqMask<M>::t(i - ns);
-                        double lam = g[L.lam + i] + g[L.rho + i] * g[L.c + i];
-                        if (ineq) lam = nanmax(0.0, lam);
-                        g[L.lam + i] = lam;
-                        const double rv = opt.scaling_penalty * g[L.rho + i];
-                        g[L.rho + i] = (rv < opt.max_penalty || rv != rv) ? rv : opt.max_penalty;
+                        double lam = g[L.lam + i], rho = g[L.rho + i];
+                        dual_update_row(lam, rho, g[L.c + i], ineq, opt);
+                        g[L.lam + i] = lam; g[L.rho + i] = rho;
                     }
                 }
                 if (conv || (upd && I.outer >= outer_max)) I.state = ST_DONE;
