@@ -590,6 +590,15 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
 #else
     constexpr bool PAIRED = NWV == 1;                      // one wave: independent tiles of a window share their fragment reads and interleave their MFMAs
 #endif
+    // Three windows per step (RicSchedule<2>, 17 <= nx <= 32 on four waves): window A is merged into window D — every wave forms its
+    // share of the next step's ûx from the P tile it holds in registers (partial sum over the tile's rows of P′) and ADDS it into
+    // the zeroed ûx buffer with ds_add_f64: two contributions per element, a + b = b + a bitwise, so the order the waves arrive in
+    // does not show
+    constexpr bool XA = TN == 2 && NWV == 4;
+    // ... and the step's two matrix-vector products ride in the padding of ûx's tiles: p′ᵀ is row nu of ûx, so row nu of Qux = ûx fx
+    // is (fxᵀp′)ᵀ = Qx - gx and row nu of Quu = ûx fu is (fuᵀp′)ᵀ = Qu - gu (src/backward_pass.jl:44-49 as part of the products of :57-64)
+    constexpr bool VPAD = XA && m < LD::MP;
+    constexpr int VR = m / 4, VK = m % 4;                  // row nu of a tile: register VR of the lanes with lk == VK
     static_assert(n <= 64 && m <= 16, "large path: nx <= 64 (one state component per lane), nu <= 16");
     static_assert(LD::total == large_lds_doubles(n, m, LD::HS), "LDS carve and host-side size disagree");
     static_assert(NWV == LARGE_WAVES || (NWV == 1 && TN == 1), "the Riccati step is scheduled over four waves per instance, or run by one when every matrix is a single tile");
@@ -739,11 +748,57 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     if (STAGE && N > 0) { stage_load(N - 1, rval); stage_store(rval); }
     double gmax = 0.0;
     __syncthreads();
+    int tcur = N - 1;                                                  // the step the loop is at (the tiles' epilogues read its gx, gu without a staging row)
+    auto run_tiles = [&](auto Wc, auto WINc) {                        // window WIN's tasks of wave W, all compile-time
+        constexpr int W = decltype(Wc)::value, WIN = decltype(WINc)::value;
+        static_for<0, RS::MAXL>([&](auto Ic) {
+            constexpr int task = WIN == 0 ? RS::tab.a[W][decltype(Ic)::value] : WIN == 1 ? RS::tab.b[W][decltype(Ic)::value] : RS::tab.ct[W][decltype(Ic)::value];
+            if constexpr (task >= 0) {
+                constexpr int kind = task & 0xe0, idx = task & 0x1f;
+                if constexpr (kind == RIC_UH) {
+                    const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFu, sP + ld * 16 * idx, li, lk);
+                    tile_store<ldm>(sUh, acc, 0, 16 * idx, li, lk);
+                } else if constexpr (kind == RIC_T) {
+                    constexpr int a = idx / TN, c = idx % TN;
+                    const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
+                    tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
+                } else if constexpr (kind == RIC_QUX) {                  // Qux = ûx fx + gux (:63-64)
+                    double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
+                    const int eo = (16 * idx + li) * ldm + lk;       // ONE element offset for the staged tile and the result, both through the LDS-qualified base
+                                                                     // (tile_load on it beside tile_store on the generic pointer computed the offset twice: 1 % of the pass)
+                    if constexpr (STAGE) { for (int r4 = 0; r4 < 4; ++r4) acc[r4] += S3[LD::oGux + eo + 4 * r4]; }
+                    for (int r4 = 0; r4 < 4; ++r4) S3[LD::oQux + eo + 4 * r4] = acc[r4];
+                    if constexpr (VPAD) {                                    // Qx = fxᵀp′ + gx (:44-46): row nu of the tile
+                        const int j = 16 * idx + li;
+                        if (lk == VK && j < n) sQx[j] = acc[VR] + (STAGE ? sG[j] : (double)A.gx[tcur * n + j]);
+                    }
+                } else {                                                 // Quu = ûx fu + guu (:58-59)
+                    double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
+                    const int eo = li * ldm + lk;
+                    if constexpr (STAGE) { for (int r4 = 0; r4 < 4; ++r4) acc[r4] += S3[LD::oGuu + eo + 4 * r4]; }
+                    for (int r4 = 0; r4 < 4; ++r4) S3[LD::oQuu + eo + 4 * r4] = acc[r4];
+                    if constexpr (VPAD) {                                    // Qu = fuᵀp′ + gu (:47-49): row nu of the tile
+                        if (lk == VK && li < m) sQu[li] = acc[VR] + (STAGE ? sG[n + li] : (double)A.gu[tcur * m + li]);
+                    }
+                }
+            }
+        });
+    };
+    if constexpr (XA) {
+        // prologue of the three-window schedule: ûx of the first step from P[H] in LDS (the tiles of the old window A)
+        if (N > 0) wave_switch(wave, [&](auto Wc) { run_tiles(Wc, IntC<0>{}); });
+        __syncthreads();
+        if constexpr (VPAD) {
+            for (int i = tid; i < n; i += NT) sUh[i * ldm + m] = sp[i];    // p′ = p[H] as row nu of ûx
+            __syncthreads();
+        }
+    }
     // wave 0 carries the step's critical path in every window (ûx, Qux, the chain, a P tile) and shares its SIMD with a wave of the
     // CU's other instance: its instructions go first whenever they can issue
     if (NWV > 1 && wave == 0) __builtin_amdgcn_s_setprio(3);
     for (int t = N - 1; t >= 0; --t) {                                    // (:42)
         ILQR_SUB_BEGIN();
+        tcur = t;
         const int tn = t > 0 ? t - 1 : 0;                                 // (t = 0: a harmless re-read instead of a branch)
         // operands of the NEXT step, requested now (issuing them in the shadow of the window's first tile instead was measured:
         // the window got 450 clk longer)
@@ -754,34 +809,6 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             for (int j = 0; j < EJ; ++j) pval[j] = poff[j] >= 0 ? A.fv[tn * JVP + (tid - FOFF) + NS * j] : 0.0;
         }
         // ------------------------------------------------ window A: ûx = fuᵀP′ (:57) | T = fxᵀP′ (:52)
-        auto run_tiles = [&](auto Wc, auto WINc) {                        // window WIN's tasks of wave W, all compile-time
-            constexpr int W = decltype(Wc)::value, WIN = decltype(WINc)::value;
-            static_for<0, RS::MAXL>([&](auto Ic) {
-                constexpr int task = WIN == 0 ? RS::tab.a[W][decltype(Ic)::value] : WIN == 1 ? RS::tab.b[W][decltype(Ic)::value] : RS::tab.ct[W][decltype(Ic)::value];
-                if constexpr (task >= 0) {
-                    constexpr int kind = task & 0xe0, idx = task & 0x1f;
-                    if constexpr (kind == RIC_UH) {
-                        const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFu, sP + ld * 16 * idx, li, lk);
-                        tile_store<ldm>(sUh, acc, 0, 16 * idx, li, lk);
-                    } else if constexpr (kind == RIC_T) {
-                        constexpr int a = idx / TN, c = idx % TN;
-                        const double4_t acc = tile_mm<n4, ld, 1, 1, ld>(sFx + ld * 16 * a, sP + ld * 16 * c, li, lk);
-                        tile_store<ld>(sT, acc, 16 * a, 16 * c, li, lk);
-                    } else if constexpr (kind == RIC_QUX) {                  // Qux = ûx fx + gux (:63-64)
-                        double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFx + ld * 16 * idx, li, lk);
-                        const int eo = (16 * idx + li) * ldm + lk;       // ONE element offset for the staged tile and the result, both through the LDS-qualified base
-                                                                         // (tile_load on it beside tile_store on the generic pointer computed the offset twice: 1 % of the pass)
-                        if constexpr (STAGE) { for (int r4 = 0; r4 < 4; ++r4) acc[r4] += S3[LD::oGux + eo + 4 * r4]; }
-                        for (int r4 = 0; r4 < 4; ++r4) S3[LD::oQux + eo + 4 * r4] = acc[r4];
-                    } else {                                                 // Quu = ûx fu + guu (:58-59)
-                        double4_t acc = tile_mm<n4, 1, ldm, 1, ld>(sUh, sFu, li, lk);
-                        const int eo = li * ldm + lk;
-                        if constexpr (STAGE) { for (int r4 = 0; r4 < 4; ++r4) acc[r4] += S3[LD::oGuu + eo + 4 * r4]; }
-                        for (int r4 = 0; r4 < 4; ++r4) S3[LD::oQuu + eo + 4 * r4] = acc[r4];
-                    }
-                }
-            });
-        };
         if constexpr (PAIRED) {
             // one wave, one tile per product: ûx = fuᵀP′ and T = fxᵀP′ share their B operand. Fragments of both tiles are read once,
             // their MFMAs alternate (two independent accumulators keep the matrix pipe busy where one waits for itself); every
@@ -800,11 +827,11 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             }
             tile_store<ldm>(sUh, au, 0, 0, li, lk);
             tile_store<ld>(sT, at, 0, 0, li, lk);
-        } else {
+        } else if constexpr (!XA) {
             role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<0>{}); });
         }
         ILQR_SUB_MARK2(I, 0);
-        __syncthreads();                                                  // (B1) ûx complete
+        if constexpr (!XA) __syncthreads();                               // (B1) ûx complete (three-window schedule: it was formed in the previous step's window D)
         ILQR_SUB_MARK1(I, 0); ILQR_SUB_MARK2(I, 1);
         // ------------------------------------------------ window B: Qux = ûx fx (:63), Quu = ûx fu (:58), Qu (:47-49) | T
         if constexpr (PAIRED) {
@@ -850,7 +877,8 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             role_switch<NWV>(wave, [&](auto Wc) { run_tiles(Wc, IntC<1>{}); });
         }
         // wave 3 (no tile in this window when nx <= 32): the two matrix-vector products of the step
-        if (NWV == 1 || wave == 3) {
+        // (three-window schedule: they come out of the Qux / Quu tiles, see VPAD)
+        if (!VPAD && (NWV == 1 || wave == 3)) {
             {
                 // Qu = fuᵀp′ + gu (:47-49): action i on lanes i, i + 16, i + 32, i + 48, each a quarter of the sum
                 constexpr int JP = (n + 3) / 4;
@@ -906,6 +934,10 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             if (STORE_VALUE && Qv != nullptr) {                           // policy.action_value.* (src/data/policy.jl:58-64)
                 for (int e = lane; e < m * n; e += 64) Qv[QL.Qux + (size_t)t * m * n + e] = sQux[(e / m) * ldm + e % m];
                 for (int e = lane; e < m * m; e += 64) Qv[QL.Quu + (size_t)t * m * m + e] = sQuu[(e / m) * ldm + e % m];
+                if constexpr (VPAD) {
+                    if (lane < m) Qv[QL.Qu + t * m + lane] = sQu[lane];
+                    if (lane < n) Qv[QL.Qx + t * n + lane] = sQx[lane];
+                }
             }
             // potrf('U') (info ignored, :68-69) and potrs('U') on [Qux | Qu] (:70-75) fused: column c of Quu on lanes c, c + 16, ...,
             // column j of [Qux | Qu] per lane (Qu is column NP of the LDS matrix, k of K's; nx = 64 leaves no lane for k: lane 0 carries
@@ -991,8 +1023,15 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                     if (STORE_VALUE) A.p[t * n + lane] = pn;
                 }
                 if (lane < m) A.Lu[t * m + lane] = Luv;
+                if constexpr (VPAD) { if (lane < n) sp[lane] = pn; }        // p′ of the next step: window D puts it into row nu of ûx (nobody reads sp in this window)
             }
             ILQR_SUB_MARK1(I, 3);
+        }
+        if constexpr (XA) {
+            // ûx of this step has been consumed (window B): zero the buffer for the partial sums window D adds into it
+            if (wave >= 2) {
+                for (int e = (wave - 2) * 64 + lane; e < NP * ldm; e += 128) sUh[e] = 0.0;
+            }
         }
         if constexpr (!PAIRED) if (NWV == 1 || wave != 0) role_switch<NWV>(wave, [&](auto Wc) {
             constexpr int W = decltype(Wc)::value;
@@ -1034,6 +1073,14 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
             });
         });
+        if constexpr (XA) {
+            // the next step's state-dependent entries of fu: window D reads them (partial ûx), nobody reads fu in this window
+            if (wave != 0) {
+#pragma unroll
+                for (int j = 0; j < EJ; ++j)
+                    if (poff[j] >= LD::oFu) S[poff[j]] = pval[j];
+            }
+        }
         __syncthreads();                                                  // (B3) K, k, Qx in LDS; T, fx, fu no longer needed
         ILQR_SUB_MARK1(I, 4); ILQR_SUB_MARK2(I, 4);
         // ------------------------------------------------ window D: P (:79-84) | p, ∇L (:86-89, src/solve.jl:73-81); next step's Jacobian entries
@@ -1048,7 +1095,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
             placed = true;
 #pragma unroll
             for (int j = 0; j < EJ; ++j)
-                if (poff[j] >= 0) S[poff[j]] = pval[j];
+                if (poff[j] >= 0 && (!XA || poff[j] < LD::oFu)) S[poff[j]] = pval[j];       // (three-window schedule: the fu entries went in in window C)
             if (STAGE) stage_store(rval);
         };
         role_switch<NWV>(wave, [&](auto Wc) { static_for<0, SLOTS>([&](auto Sc) {
@@ -1070,6 +1117,14 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 for (int sx = 0; sx < KS; ++sx) { fU[sx] = pU[4 * ldm * sx]; fKc[sx] = pKc[4 * sx]; fKa[sx] = pKa[4 * sx]; fQc[sx] = pQc[4 * sx]; fQa[sx] = pQa[4 * sx]; }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) qxx[r] = pq[4 * r];
+                // (three-window schedule) the next step's fu, rows 16a .. 16a + 15 of it: A(i, k) = fu[16a + k][i]
+                double fF[4], pnext = 0.0;
+                if constexpr (XA) {
+                    const double* pF = sFu + ld * li + 16 * a + lk;
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) fF[sx] = pF[4 * sx];
+                    if constexpr (VPAD && a == 0) pnext = sp[16 * c + li];      // p[t] (stored at the end of the chain): row nu of the next step's ûx
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 double4_t ux = double4_t{0, 0, 0, 0}, acc = double4_t{0, 0, 0, 0};
 #pragma unroll
@@ -1083,6 +1138,17 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 if constexpr (first) place_next();
                 const double4_t v = acc + qxx;
                 tile_store<ld>(sP, v, 16 * a, 16 * c, li, lk);
+                if constexpr (XA) {
+                    // ûx(t - 1)(., 16c .. 16c + 15) += fu(t - 1)[16a .. 16a + 15, .]ᵀ P(a, c): the tile in registers is the B operand
+                    // (row lk + 4 sx of the tile in register sx = k-slice sx); rows a = 0 and a = 1 go to separate buffers
+                    double4_t au = double4_t{0, 0, 0, 0};
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) au = __builtin_amdgcn_mfma_f64_16x16x4f64(fF[sx], v[sx], au, 0, 0, 0);
+                    if constexpr (VPAD && a == 0) au[VR] = lk == VK ? pnext : au[VR];     // (fu's rows beyond nu are zero padding: that row of the product is free)
+                    ldsd* pu_ = S3 + LD::oUh + (16 * c + li) * ldm + lk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(pu_ + 4 * r, au[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 if (STORE_VALUE) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1092,7 +1158,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
                 }
             }
         }); });
-        if ((NWV == 1 || wave == 0) && lane < n) sp[lane] = pn;                         // p' of the next step (its readers of this step are past B3)
+        if (!VPAD && (NWV == 1 || wave == 0) && lane < n) sp[lane] = pn;               // p' of the next step (its readers of this step are past B3)
         __syncthreads();                                                  // (B0) P′, p′, patched fx, fu visible
         ILQR_SUB_MARK1(I, 5); ILQR_SUB_MARK2(I, 5);
     }

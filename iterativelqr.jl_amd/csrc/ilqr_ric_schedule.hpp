@@ -20,13 +20,21 @@ struct RicSchedule {
             for (int i = 0; i < SLOTS; ++i) { t.qxx[w][i] = -1; t.p[w][i] = -1; }
         }
         if (TN == 2) {
-            // A: ûx | T(0,.)   B: Qux, Quu | (wave 3: Qu, Qx)   C: chain | T(1,.), Qxx   D: P
-            t.a[0][na[0]++] = RIC_UH + 0; t.a[1][na[1]++] = RIC_UH + 1; t.a[2][na[2]++] = RIC_T + 0; t.a[3][na[3]++] = RIC_T + 1;
-            t.b[0][nb[0]++] = RIC_QUX + 0; t.b[1][nb[1]++] = RIC_QUX + 1; t.b[2][nb[2]++] = RIC_QUU;
-            t.ct[2][nc[2]++] = RIC_T + 2; t.ct[3][nc[3]++] = RIC_T + 3;
-            // Qxx(1,.) needs T(1,0) and T(1,1), formed in this same window by waves 2 and 3: those tiles wait for the flags of the
-            // OTHER waves that form T here (RIC_WAIT_T)
-            t.qxx[1][nq[1]++] = 0; t.qxx[1][nq[1]++] = 2 | RIC_WAIT_T; t.qxx[2][nq[2]++] = 1; t.qxx[3][nq[3]++] = 3 | RIC_WAIT_T;
+            // Round 5: THREE windows per step. Window A is gone: every wave forms ONE tile of P in window D and, straight from that
+            // tile's registers (the D layout of a tile is the B layout of the next MFMA), its share of the next step's ûx = fuᵀP′ —
+            // the partial sum over the tile's 16 rows of P′; the consumers (Qux, Quu in window B) add the two partial sums of a
+            // column block when they read their A fragments. One LDS round trip, one barrier and four of ûx's eight dependent MFMAs
+            // are off the critical path. The two matrix-vector products of the step ride in the PADDING of those tiles: p′ᵀ is row
+            // nu of ûx (nu < 16), so row nu of Qux = ûx fx is (fxᵀp′)ᵀ and row nu of Quu = ûx fu is (fuᵀp′)ᵀ — wave 3, which used to
+            // form them in window B, takes a tile of T there instead. The list `a` is the PROLOGUE's: ûx of the first step from
+            // P[H] in LDS.
+            //   B: Qux, Quu (with Qx, Qu) | wave 3: T(0,0)   C: chain | T(0,1), T(1,0), T(1,1), Qxx   D (+A): P, partial ûx
+            t.a[0][na[0]++] = RIC_UH + 0; t.a[1][na[1]++] = RIC_UH + 1;
+            t.b[0][nb[0]++] = RIC_QUX + 0; t.b[1][nb[1]++] = RIC_QUX + 1; t.b[2][nb[2]++] = RIC_QUU; t.b[3][nb[3]++] = RIC_T + 0;
+            t.ct[1][nc[1]++] = RIC_T + 1; t.ct[2][nc[2]++] = RIC_T + 2; t.ct[3][nc[3]++] = RIC_T + 3;
+            // Qxx(0,.) reads T(0,0) (window B) and T(0,1) (its own wave's); Qxx(1,.) needs T(1,0) and T(1,1), formed in this same
+            // window by waves 2 and 3: those tiles wait for the flags of the OTHER waves that form T here (RIC_WAIT_T)
+            t.qxx[1][nq[1]++] = 0; t.qxx[1][nq[1]++] = 1; t.qxx[2][nq[2]++] = 2 | RIC_WAIT_T; t.qxx[3][nq[3]++] = 3 | RIC_WAIT_T;
             t.p[0][np[0]++] = 3; t.p[1][np[1]++] = 0; t.p[2][np[2]++] = 1; t.p[3][np[3]++] = 2;
         } else {
             for (int c = 0; c < TN; ++c) { const int w = c % 2; t.a[w][na[w]++] = RIC_UH + c; }

@@ -14,4 +14,4 @@ def test_riccati_schedule_invariants(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert out.returncode == 0, out.stderr.decode()
     lines = out.stdout.decode().splitlines()
-    assert len(lines) == 4 and lines[1].startswith("TN=2: 4 T, 4 Qxx, 4 P tiles") and lines[1].endswith("per wave 2 2 2")
+    assert len(lines) == 4 and lines[1].startswith("TN=2: 4 T, 4 Qxx, 4 P tiles") and lines[1].endswith("per wave 3 2 2")
