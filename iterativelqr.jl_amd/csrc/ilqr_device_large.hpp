@@ -609,7 +609,14 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     int potrf_info = 0;
     gdbl* const Qv = (STORE_VALUE && Qbase != nullptr) ? uniform_ptr(Qbase) : nullptr;   // optional action-value buffers (stage kernel only)
     const QLayout QL = make_qlayout(n, m, A.T);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef ILQR_LARGE_ROT
+#define ILQR_LARGE_ROT 2
+#endif
+    // The roles of the four waves are rotated by two for every other workgroup: the MFMA load of the roles is uneven (20 / 44 / 36 / 36
+    // instructions per step in the three-window schedule) and the two instances of a CU share its SIMDs. Measured on
+    // synth32_tight11:512, same box, rotation 0 / 1 / 2 / 3: 45.81 / 45.85 / 45.27 / 46.30 ms.
+    const int hwv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = NWV == 1 ? hwv : ((hwv + (int)(blockIdx.x & 1) * ILQR_LARGE_ROT) & 3), tid = wave * 64 + lane;
     const int N = A.N, li = lane & 15, lk = lane >> 4;
     double* S = lds_dyn;
     double *sFx = S + LD::oFx, *sFu = S + LD::oFu, *sP = S + LD::oP, *sT = S + LD::oT, *sUh = S + LD::oUh, *sQux = S + LD::oQux,
