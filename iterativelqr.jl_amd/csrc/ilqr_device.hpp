@@ -645,12 +645,6 @@ __device__ __forceinline__ void mfma_block_boundary_guard() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-#ifndef ILQR_BW_PTR_LOADS
-#define ILQR_BW_PTR_LOADS 1
-#endif
-#ifndef ILQR_BW_PTR_STORES
-#define ILQR_BW_PTR_STORES 1
-#endif
 // ROLE 0: the whole recursion on one wave (throughput variant). With two waves per instance the recursion is
 // split along its data flow — the value-function MATRIX chain (W, Wu, Qxx, Qux, Quu, potrf, K, ux_tmp, P) never
 // reads the VECTOR chain (Qx, Qu, k, p, ∇L), which only consumes Quu, Qux, ux_tmp and K of the same timestep:
@@ -684,12 +678,10 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
     const double* buu = vmm ? I.guu + c * m + r : I.gzero;   const int suu = vmm ? m * m : 0;
     const double* bux = vmn ? I.gux + c * m + r : I.gzero;   const int sux = vmn ? m * n : 0;
     const bool b0 = blk == 0;
-#if ILQR_BW_PTR_STORES
     double* qK = (b0 && vmn) ? I.K + (N - 1) * m * n + c * m + r : I.zs + 1;   const int sK = (b0 && vmn) ? m * n : 0;
     double* qk = (b0 && vm1) ? I.k + (N - 1) * m + r : I.zs + 1;               const int sk = (b0 && vm1) ? m : 0;
     double* qLu = (b0 && vm1) ? I.Lu + (N - 1) * m + r : I.zs + 1;
     double* qLx = (b0 && vn1) ? I.Lx + (N - 1) * n + r : I.zs + 1;             const int sLx = (b0 && vn1) ? n : 0;
-#endif
     // two-wave hand-over: element (r, c) of {Quu, Qux, ux_tmp} of ring slot s at ring[s*48 + q*16 + r*4 + c]
     double* wring = (ROLE == 1 && b0) ? I.ring + r * 4 + c : I.zs + 1;   const int swr = (ROLE == 1 && b0) ? 1 : 0;   // writer (block 0)
     const double* rring = I.ring + r * 4 + c;                                                                      // reader (every block)
@@ -715,18 +707,9 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
         else { o.gx = 0.0; o.gu = 0.0; }
     };
     auto fetch_prev = [&](Opnd& o, int tp) {     // operands of step tp = (previously fetched step) - 1
-#if ILQR_BW_PTR_LOADS
         if constexpr (!SL) { pfx -= sfx; pfu -= sfu; }
         pgx -= sgx; pgu -= sgu;
         fetch_first(o, tp);
-#else
-        const int rn = r < n ? r : n - 1, cn = c < n ? c : n - 1, rm = r < m ? r : m - 1, cm = c < m ? c : m - 1;
-        o.gxx = I.gxx[tp * n * n + cn * n + rn]; o.guu = I.guu[tp * m * m + cm * m + rm]; o.gux = I.gux[tp * m * n + cn * m + rm];
-        o.fx = I.fx[tp * n * n + cn * n + rn]; o.fu = I.fu[tp * n * m + cm * n + rn];
-        o.gx = I.gx[tp * n + rn]; o.gu = I.gu[tp * m + rm];
-        o.gxx = vnn ? o.gxx : 0.0; o.guu = vmm ? o.guu : 0.0; o.gux = vmn ? o.gux : 0.0;
-        o.fx = vnn ? o.fx : 0.0; o.fu = vnm ? o.fu : 0.0; o.gx = vn1 ? o.gx : 0.0; o.gu = vm1 ? o.gu : 0.0;
-#endif
     };
     // potrs('U') of one right-hand-side set held as Y(r, c) (rows on lanes 16 apart), given the factor   (:70-75)
     auto solve = [&](double Y, const double (&Uc)[m * m], const double (&Ur)[m], int info) {
@@ -822,11 +805,7 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             Pn = mfma444(Qux, K, Pn);
             Pn = mfma444(K, uxt, Pn);
             if (b0) {
-#if ILQR_BW_PTR_STORES
                 *qK = K; qK -= sK;
-#else
-                if (vmn) I.K[t * m * n + c * m + r] = K;
-#endif
                 if (STORE_VALUE && vnn) I.P[t * n * n + c * n + r] = Pn;
                 if (STORE_VALUE && I.Q != nullptr) {                    // policy.action_value.* (src/data/policy.jl:58-64)
                     if (vnn) I.Q[I.QL.Qxx + t * n * n + c * n + r] = Qxx;
@@ -852,13 +831,8 @@ __device__ void backward_pass_mfma(Inst<M>& I) {
             gmax = fmax(gmax, fabs(Qu));
             gnan |= (Lx != Lx) | (Qu != Qu);
             if (b0) {
-#if ILQR_BW_PTR_STORES
                 *qk = k; *qLu = Qu; *qLx = Lx;
                 qk -= sk; qLu -= sk; qLx -= sLx;
-#else
-                if (vn1) I.Lx[t * n + r] = Lx;
-                if (vm1) { I.Lu[t * m + r] = Qu; I.k[t * m + r] = k; }
-#endif
                 if (STORE_VALUE && vn1) I.p[t * n + r] = pn;
                 if (STORE_VALUE && I.Q != nullptr) {
                     if (vn1) I.Q[I.QL.Qx + t * n + r] = Qx;
@@ -1294,9 +1268,6 @@ __device__ bool backward_pass_m1(Inst<M>& I) {
             ILQR_BAR_END(I, PROF_DELTA);
             if (t < 0) break;
         }
-#ifdef ILQR_M1_NOREDO
-        if (lane == 0) { I.scal[S_PROF] = qmin; I.scal[S_PROF + 1] = (double)__popcll(__builtin_amdgcn_ballot_w64(P != P)); I.scal[S_PROF + 2] = (double)__popcll(__builtin_amdgcn_ballot_w64(!(qmin > 0.0))); }
-#endif
         return __builtin_amdgcn_ballot_w64(!(qmin > 0.0) || P != P) != 0;
     } else {
         unsigned agx = vr ? lds(I.gx + tl * n + r) : zero;             const unsigned dgx = vr ? 32u * n : 0u;
@@ -1411,9 +1382,6 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
                 }
                 __syncthreads();
                 literal = I.zs[6] != 0.0;
-#ifdef ILQR_M1_NOREDO
-                literal = false;                                        // debugging aid: what the short form alone produces
-#endif
 #ifdef ILQR_PROFILE
                 if (literal) I.prof[PROF_DELTA] += 1.0;                 // (slot unused by the two-wave kernel: counts repeated passes)
 #endif

@@ -585,11 +585,7 @@ __attribute__((noinline)) __device__ RiccatiOut backward_pass_large_fn(gdbl* bas
     constexpr int EU = (HUU + HUX + 63) / 64 > 0 ? (HUU + HUX + 63) / 64 : 1;      // guu / gux entries per lane of wave 0
     typedef RicSchedule<TN> RS;
     constexpr int SLOTS = RS::SLOTS;                       // Qxx / P tiles per wave (waves 1..3)
-#ifdef ILQR_MID_UNPAIRED                                   // A/B switch: the one-wave variant with the roles' tiles strictly in turn
-    constexpr bool PAIRED = false;
-#else
     constexpr bool PAIRED = NWV == 1;                      // one wave: independent tiles of a window share their fragment reads and interleave their MFMAs
-#endif
     // Three windows per step (RicSchedule<2>, 17 <= nx <= 32 on four waves): window A is merged into window D — every wave forms its
     // share of the next step's ûx from the P tile it holds in registers (partial sum over the tile's rows of P′) and ADDS it into
     // the zeroed ûx buffer with ds_add_f64: two contributions per element, a + b = b + a bitwise, so the order the waves arrive in

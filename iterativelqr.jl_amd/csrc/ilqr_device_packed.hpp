@@ -415,11 +415,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     const int blk0 = (lane & 12);
     struct Opnd { double gxx, guu, gux, fx, fu, gx, gu; };
     auto fetch = [&](Opnd& o) {          // operands at the walking addresses (timesteps are fetched in descending order), then one step back
-#ifdef PK_X_NOLOAD
-        o.gxx = (r == c) ? 1.0 : 0.0; o.guu = (r == c) ? 1.0 : 0.0; o.gux = 0.0;
-#else
         o.gxx = GL(oxx); o.guu = GL(ouu); o.gux = GL(oux);
-#endif
         oxx -= sxx; ouu -= suu; oux -= sux;
         o.fx = LDr(afx); o.fu = LDr(afu); o.gx = LDr(agx); o.gu = LDr(agu);
         afx -= sfx; afu -= sfu; agx -= sgx; agu -= sgu;
@@ -509,9 +505,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         double nun = mfma444(fx, nu, Lx);
         nun = mfma444(K, wv, nun);
         nu = nun;
-#ifndef PK_X_NOSTORE
         GS(oK, K); GS(ok_, k); GS(oLu, Qu); GS(oLx, Lx);
-#endif
         oK -= sK; ok_ -= sk; oLu -= sk; oLx -= sLx;
         P = Pn; p = pn;
     };
@@ -522,9 +516,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         if constexpr (!TWO) {
             if (act_row && I.j < cnt) {
                 LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + I.j, I.q * LD::IB, I.j, constrained ? 1 : 0};
-#ifndef PK_X_NOLIN
                 linearise_stage<M>(la);
-#endif
             }
         }
         pk_sync<M>(I);
