@@ -77,6 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
+    ap.add_argument("--generator", default="pcg64", choices=["pcg64", "splitmix64"],
+                    help="synthetic inputs: numpy PCG64 streams (the inputs of every earlier round's figures) or the library's own "
+                         "ilqr_synthetic_inputs (SURVEY 8(d): splitmix64 / Box-Muller — what a Julia or C host generates)")
     ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed", "mid", "packed1", "packed2"])
     ap.add_argument("--shared-step", action="store_true",
                     help="optional mode, NOT the reference's behaviour and not the headline: one Armijo step size per inner iteration "
@@ -97,7 +100,7 @@ def pmc_child(args):
     (no torch: the counters are per kernel dispatch, the init path does not matter)."""
     from ilqr_amd_loader import load_package
     pkg = load_package()
-    model, T, x1, ub = pkg.workloads.make_inputs(args.config, args.batch)
+    model, T, x1, ub = pkg.workloads.make_inputs(args.config, args.batch, generator=args.generator)
     sol = pkg.Solver(model=model, horizon=T, batch=args.batch,
                      options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
     sol.set_kernel_variant_(args.variant)
@@ -245,12 +248,12 @@ def worker(args, solver_factory=None):
     distinct = bool(args.distinct_shards) or not bool(getattr(args, "same_instances", False))
     args.distinct_shards = distinct
     lo, _ = pkg.distributed.shard_range(rank, B)
-    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if distinct else 0))
+    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if distinct else 0, generator=args.generator))
     if sharded:
         # one handle, ndev contiguous ranges of B instances: the same B instances on every device (fixed per-GPU work, like the
         # process-per-GPU default) or ndev * B distinct ones
         if args.distinct_shards:
-            model, T, x1, ub = pkg.workloads.make_inputs(args.config, ndev * B)
+            model, T, x1, ub = pkg.workloads.make_inputs(args.config, ndev * B, generator=args.generator)
         else:
             x1, ub = np.tile(x1, (ndev, 1)), np.tile(ub, (ndev, 1, 1))
     if stub:
@@ -346,7 +349,7 @@ def worker(args, solver_factory=None):
             # the other instance assignment than the timed one: distinct shards when the run was --same-instances, the same [0, B) on
             # every rank when it was distinct (only differs from the timed run for N > 1)
             other_lo = lo if not args.distinct_shards else 0
-            m2, T2, x1b, ubb = pkg.workloads.make_inputs(args.config, B, offset=other_lo)
+            m2, T2, x1b, ubb = pkg.workloads.make_inputs(args.config, B, offset=other_lo, generator=args.generator)
             if stub:
                 d2 = (None, None)
             else:
@@ -423,7 +426,7 @@ def worker(args, solver_factory=None):
                   else "trajectories/sec (whole node), %s T=%d batch=%d/GPU (NOT the BASELINE metric's configuration)" % (args.config, T, B),
         "value": value, "unit": "trajectories/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic (%s)" % args.generator,
         "config": {"workload": "%s (nx=%d, nu=%d, T=%d) AL-iLQR solve!, batch=%d per GPU, fp64, faithful reference semantics"
                                % (args.config, sol.nx, sol.nu, T, B),
                    "global_batch": n_gpus * B, "horizon": T,

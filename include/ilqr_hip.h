@@ -160,7 +160,7 @@ enum {
      *                             of three doubles) and tests  sum J <= sum J_prev + 1e-4 alpha sum delta  (:44)
      *   SS_FINISH(alpha, accept)  update_nominal_trajectory! or line-search failure, then src/solve.jl:27-51 per instance
      *   SS_OUTER                  src/solve.jl:113-122 per instance
-     * (ilqr_run_stage_param; Python: Solver.solve_shared_step_). With a batch of one it reproduces solve! exactly. */
+     * (ilqr_run_stage_param; the whole loop: ilqr_solve_shared_step below). With a batch of one it reproduces solve! exactly. */
     ILQR_STAGE_SS_INNER_BEGIN = 9,
     ILQR_STAGE_SS_TRIAL = 10,
     ILQR_STAGE_SS_FINISH = 11,
@@ -168,6 +168,19 @@ enum {
 };
 int ilqr_run_stage(ilqr_handle* h, int32_t stage);
 int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t flag);
+
+/* solve! with ONE step size per inner iteration for the whole batch — over every rank of a multi-GPU job when `reduce` sums across
+ * them. Not a reference behaviour (every reference Solver line-searches alone; a shared step changes every iterate): the optional
+ * mode of the north star, "at most an all-reduce of the line-search merit for a shared step size". The Armijo loop of
+ * forward_pass! (src/forward_pass.jl:26-52) runs here, on the host, over the SUMMED merit of the instances still in their inner
+ * loop: per trial one SS_TRIAL launch, one reduction of three doubles {sum J(alpha), sum J_prev, sum grad_L' dz}, then SS_FINISH;
+ * linearisation, Riccati pass, convergence tests and dual updates stay per instance on the device (stages SS_* above).
+ *   reduce(values, n, ctx): replace values[0..n) by their sum over all ranks, return 0 (an RCCL / MPI all-reduce in a host with
+ *     several processes; NULL = one process: the identity). It is called the same number of times on every rank.
+ *   steps / steps_cap / n_steps (optional): the accepted step size of every inner iteration (0 = line search failed), in order.
+ * With a batch of ONE instance the mode reproduces ilqr_solve exactly. Constrained solvers only. Synchronous. */
+typedef int (*ilqr_allreduce_sum_fn)(double* values, int32_t n, void* ctx);
+int ilqr_solve_shared_step(ilqr_handle* h, ilqr_allreduce_sum_fn reduce, void* ctx, double* steps, int32_t steps_cap, int32_t* n_steps);
 
 /* get_trajectory(solver) — src/solver.jl:48-50: nominal states [B][T][nx] and
  * actions [B][T-1][nu]. */
@@ -380,6 +393,17 @@ int ilqr_compile_model_stages(const char* name, const ilqr_stage_kinds* kinds, c
  * writes it into the last n_selectors parameter columns of every instance, now and on every ilqr_set_parameters — which from
  * here on takes the USER's parameters only, w: [B][T][nw - n_selectors], as ilqr_get_dims reports them. n_selectors = 0 detaches. */
 int ilqr_set_stage_selectors(ilqr_handle* h, const double* selectors, int32_t n_selectors);
+
+/* Synthetic inputs of the benchmark workloads, generated on the host by ONE function that every host language
+ * can call, so that a Julia or C program solves the same instances as the Python bench: value (b, t, j) is a pure function of
+ * (seed, b, t, j) — key = seed ^ (b * 2^20 + t * 2^4 + j), splitmix64(key) -> U(0,1), a second splitmix64 round for the Box-Muller
+ * partner, z = sqrt(-2 ln u1) cos(2 pi u2) — so shards [first, first + B) of a larger batch are slices of it.
+ *   model: "particle" (u = 0.1 z, examples/particle.jl:30), "acrobot" (u = z, test/acrobot.jl:86-88), "car" / "car_goal" / "car_obs"
+ *   (instance 0: test/car.jl:24-29 exactly; b >= 1: u scaled by 1 + 0.5 U(-1,1)_b, (x, y) of x1 jittered by 0.05 z), "synth32"
+ *   (x1 = 0.5 z, u = 0), "synth12" (x1 = 0.5 z, u = 0.1 z). x1: [B][nx], ubar: [B][T-1][nu] of that model. No device needed.
+ * (The Python bench draws from numpy's PCG64 by default, as in earlier rounds; `bench.py --generator splitmix64` and
+ * workloads.make_inputs(generator = "splitmix64") use this function.) */
+int ilqr_synthetic_inputs(const char* model, int32_t horizon, uint64_t seed, int64_t first_instance, int32_t batch, double* x1, double* ubar);
 
 /* Test hook: evaluates one of the device-side scalar routines of csrc/ilqr_math.hpp on cuda device 0 — "recip_fast",
  * "rsqrt_fast", "sqrt_fast" (the d of sqrt_rsqrt_fast), "sin_fast", "cos_fast" — elementwise, y[i] = f(x[i]). These replace

@@ -11,6 +11,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 c_double_p = C.POINTER(C.c_double)
+ALLREDUCE_SUM_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p)       # ilqr_allreduce_sum_fn
 
 
 class Options(C.Structure):
@@ -120,6 +121,7 @@ SYMBOLS = {
     "ilqr_initialize_rollout_resident": (C.c_int, [C.c_void_p]),
     "ilqr_solve": (C.c_int, [C.c_void_p]),
     "ilqr_synchronize": (C.c_int, [C.c_void_p]),
+    "ilqr_solve_shared_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_double_p, C.c_int32, C.POINTER(C.c_int32)]),
     "ilqr_run_stage": (C.c_int, [C.c_void_p, C.c_int32]),
     "ilqr_run_stage_param": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32]),
     "ilqr_get_trajectory": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
@@ -145,6 +147,7 @@ SYMBOLS = {
     "ilqr_compile_model_stages": (C.c_int, [C.c_char_p, C.POINTER(StageKinds), C.c_char_p, C.POINTER(StagePlan), c_double_p, C.c_size_t,
                                             c_int32_p, c_int32_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "ilqr_set_stage_selectors": (C.c_int, [C.c_void_p, c_double_p, C.c_int32]),
+    "ilqr_synthetic_inputs": (C.c_int, [C.c_char_p, C.c_int32, C.c_uint64, C.c_int64, C.c_int32, c_double_p, c_double_p]),
     "ilqr_device_math": (C.c_int, [C.c_char_p, c_double_p, c_double_p, C.c_int32]),
     "ilqr_register_model": (C.c_int, [C.c_void_p]),
     "ilqr_model_count": (C.c_int, []),

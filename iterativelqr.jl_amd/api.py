@@ -217,39 +217,27 @@ class Solver:
         (Σ J(α), Σ J_prev, Σ ∇Lᵀ·Δz over the instances still in their inner loop) — `allreduce_sum(np.ndarray) -> np.ndarray`,
         e.g. distributed.torch_allreduce_sum(dist, device) for RCCL; identity on one rank. Everything else (linearisation,
         Riccati pass, convergence tests, dual updates) stays per instance on the device. With a batch of one instance it
-        reproduces solve_ exactly. Constrained solvers only. Returns the list of accepted step sizes."""
+        reproduces solve_ exactly. Constrained solvers only. Returns the list of accepted step sizes.
+        The loop itself lives in the library (ilqr_solve_shared_step: a Julia or C host passes its RCCL / MPI reducer as a C
+        callback); this method only wraps `allreduce_sum` into that callback."""
         L = _ffi.lib()
-        ar = allreduce_sum if allreduce_sum is not None else (lambda v: v)
-        slot = {k: L.ilqr_scalar_slot(k.encode()) for k in ("objective", "j_prev", "delta_grad_product", "inner_done", "done")}
-        opt = self.options
-        steps = []
-        self.run_stage_("al_begin")
-        for _ in range(int(opt.max_dual_updates)):
-            self.run_stage_("ss_inner_begin")
-            for _it in range(int(opt.max_iterations)):
-                sc = self.buffer("_scalars")
-                active = (sc[:, slot["done"]] == 0.0) & (sc[:, slot["inner_done"]] == 0.0)
-                if ar(np.array([float(active.sum())]))[0] == 0.0:
-                    break
-                alpha, first, accepted, trials = 1.0, 1, 0, 1
-                while alpha >= opt.min_step_size and trials <= 25:                       # src/forward_pass.jl:28-29
-                    self.run_stage_param_("ss_trial", alpha, first)
-                    sc = self.buffer("_scalars")
-                    sums = ar(np.array([sc[active, slot["objective"]].sum(), sc[active, slot["j_prev"]].sum(),
-                                        sc[active, slot["delta_grad_product"]].sum()]))    # the data-path collective
-                    if sums[0] <= sums[1] + 1.0e-4 * alpha * sums[2]:                       # (:44) NaN ⇒ reject
-                        accepted = 1
-                        break
-                    alpha *= 0.5                                                          # (:51)
-                    first = 0
-                    trials += 1
-                self.run_stage_param_("ss_finish", alpha, accepted)
-                steps.append(alpha if accepted else 0.0)
-            self.run_stage_("ss_outer")
-            sc = self.buffer("_scalars")
-            if ar(np.array([float((sc[:, slot["done"]] == 0.0).sum())]))[0] == 0.0:
-                break
-        return steps
+        _ffi.check(L.ilqr_set_options(self._h, C.byref(self.options)))
+        cb = None
+        if allreduce_sum is not None:
+            def reduce(values, n, _ctx):
+                try:
+                    v = np.ctypeslib.as_array(values, shape=(n,))
+                    v[:] = np.asarray(allreduce_sum(v.copy()), dtype=np.float64)
+                    return 0
+                except Exception:                  # nothing may propagate through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = _ffi.ALLREDUCE_SUM_FN(reduce)
+        cap = int(self.options.max_dual_updates) * int(self.options.max_iterations)
+        steps = np.zeros(max(cap, 1)); n = C.c_int32(0)
+        _ffi.check(L.ilqr_solve_shared_step(self._h, C.cast(cb, C.c_void_p) if cb is not None else None, None, _p(steps), cap, C.byref(n)))
+        return [float(a) for a in steps[:n.value]]
 
     def synchronize(self):
         _ffi.check(_ffi.lib().ilqr_synchronize(self._h))

@@ -308,6 +308,45 @@ int ilqr_device_math(const char* fn, const double* x, double* y, int32_t n) {
     return ILQR_OK;
 }
 
+// the synthetic inputs as a pure function of (seed, instance, timestep, component)
+int ilqr_synthetic_inputs(const char* model, int32_t T, uint64_t seed, int64_t first, int32_t B, double* x1, double* ub) {
+    if (!model || !x1 || !ub || T < 2 || B < 0 || first < 0) return fail(ILQR_ERR_INVALID, "ilqr_synthetic_inputs: bad argument");
+    struct Kind { const char* name; int n, m, kind; };
+    static const Kind kinds[] = {{"particle", 2, 1, 0}, {"acrobot", 4, 1, 1}, {"car", 3, 2, 2}, {"car_goal", 3, 2, 2}, {"car_obs", 3, 2, 2},
+                                 {"synth32", 32, 8, 3}, {"synth12", 12, 5, 4}};
+    const Kind* k = nullptr;
+    for (const Kind& q : kinds) if (!std::strcmp(q.name, model)) k = &q;
+    if (!k) return fail(ILQR_ERR_MODEL, std::string("ilqr_synthetic_inputs: no workload for model '") + model + "'");
+    auto mix = [](uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    auto unif = [](uint64_t h) { return ((double)(h >> 11) + 0.5) / 9007199254740992.0; };          // (0, 1)
+    auto key = [&](int64_t b, int t, int j) { return seed ^ (uint64_t)(b * (1ll << 20) + (int64_t)t * 16 + j); };
+    auto U = [&](int64_t b, int t, int j) { return unif(mix(key(b, t, j))); };
+    auto Z = [&](int64_t b, int t, int j) { const uint64_t h1 = mix(key(b, t, j)), h2 = mix(h1); return std::sqrt(-2.0 * std::log(unif(h1))) * std::cos(6.283185307179586 * unif(h2)); };
+    const int n = k->n, m = k->m, N = T - 1;
+    for (int i = 0; i < B; ++i) {
+        const int64_t b = first + i;
+        double* x = x1 + (size_t)i * n;
+        double* u = ub + (size_t)i * N * m;
+        for (int j = 0; j < n; ++j) x[j] = 0.0;
+        for (int e = 0; e < N * m; ++e) u[e] = 0.0;
+        switch (k->kind) {
+            case 0: for (int t = 0; t < N; ++t) u[t] = 0.1 * Z(b, t, 0); break;
+            case 1: for (int t = 0; t < N; ++t) u[t] = Z(b, t, 0); break;
+            case 2: {
+                const double sc = b > 0 ? 1.0 + 0.5 * (2.0 * U(b, 0, 8) - 1.0) : 1.0;
+                for (int t = 0; t < N; ++t) { u[t * 2] = 1.0e-2 * sc; u[t * 2 + 1] = 1.0e-3 * sc; }
+                if (b > 0) { x[0] = 0.05 * Z(b, 0, 9); x[1] = 0.05 * Z(b, 0, 10); }
+                break;
+            }
+            case 3: break;                                                  // x1 below; u = 0
+            default:
+                for (int t = 0; t < N; ++t) for (int j = 0; j < m; ++j) u[t * m + j] = 0.1 * Z(b, t, j);
+        }
+        if (k->kind >= 3) for (int j = 0; j < n; ++j) x[j] = 0.5 * Z(b, T + j / 16, j % 16);     // component j of x1: key slot (T + j / 16, j % 16), behind the horizon's
+    }
+    return ILQR_OK;
+}
+
 int ilqr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1186,6 +1225,66 @@ int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t fl
     } else if (h->vt->launch_stage(&a, h->lds_bytes, h->stream) != 0) return fail(ILQR_ERR_HIP, "stage launch failed");
     if (h->vt->launch_mirror) h->full_stale = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return ILQR_OK;
+}
+
+// solve! with one step size per inner iteration for the whole (multi-rank) batch: forward_pass!'s Armijo loop on the host over the
+// summed merit (see ilqr_hip.h). The loop is the reference's (src/solve.jl:88-129 around :1-54, src/forward_pass.jl:26-52) with
+// the per-instance phases as stage launches.
+int ilqr_solve_shared_step(ilqr_handle* h, ilqr_allreduce_sum_fn reduce, void* ctx, double* steps, int32_t steps_cap, int32_t* n_steps) {
+    if (!h) return fail(ILQR_ERR_INVALID, "null handle");
+    if (!h->constrained) return fail(ILQR_ERR_INVALID, "shared-step mode: constrained solvers only");
+    const int B = h->B, NS = ilqr::S_COUNT;
+    std::vector<double> sc((size_t)B * NS);
+    auto scalars = [&]() { return ilqr_get_buffer(h, "_scalars", sc.data()); };
+    auto allsum = [&](double* v, int n) -> int {
+        if (!reduce) return ILQR_OK;
+        return reduce(v, n, ctx) == 0 ? ILQR_OK : fail(ILQR_ERR_INVALID, "shared-step mode: the reduction callback failed");
+    };
+    const ilqr_options opt = h->opt;
+    int count = 0, rc;
+    if ((rc = ilqr_run_stage(h, ILQR_STAGE_AL_BEGIN)) != ILQR_OK) return rc;
+    for (int outer = 0; outer < opt.max_dual_updates; ++outer) {
+        if ((rc = ilqr_run_stage(h, ILQR_STAGE_SS_INNER_BEGIN)) != ILQR_OK) return rc;
+        for (int it = 0; it < opt.max_iterations; ++it) {
+            if ((rc = scalars()) != ILQR_OK) return rc;
+            std::vector<char> active(B);
+            double n_active = 0.0;
+            for (int b = 0; b < B; ++b) {
+                active[b] = sc[(size_t)b * NS + ilqr::S_DONE] == 0.0 && sc[(size_t)b * NS + ilqr::S_INNER_DONE] == 0.0;
+                n_active += active[b];
+            }
+            if ((rc = allsum(&n_active, 1)) != ILQR_OK) return rc;
+            if (n_active == 0.0) break;
+            double alpha = 1.0;
+            int first = 1, accepted = 0, trials = 1;
+            while (alpha >= opt.min_step_size && trials <= 25) {                          // src/forward_pass.jl:28-29
+                if ((rc = ilqr_run_stage_param(h, ILQR_STAGE_SS_TRIAL, alpha, first)) != ILQR_OK) return rc;
+                if ((rc = scalars()) != ILQR_OK) return rc;
+                double sums[3] = {0.0, 0.0, 0.0};
+                for (int b = 0; b < B; ++b)
+                    if (active[b]) {
+                        sums[0] += sc[(size_t)b * NS + ilqr::S_OBJECTIVE]; sums[1] += sc[(size_t)b * NS + ilqr::S_J_PREV];
+                        sums[2] += sc[(size_t)b * NS + ilqr::S_DELTA];
+                    }
+                if ((rc = allsum(sums, 3)) != ILQR_OK) return rc;                          // the data-path collective: three doubles
+                if (sums[0] <= sums[1] + 1.0e-4 * alpha * sums[2]) { accepted = 1; break; }  // (:44) NaN ⇒ reject
+                alpha *= 0.5;                                                            // (:51)
+                first = 0;
+                ++trials;
+            }
+            if ((rc = ilqr_run_stage_param(h, ILQR_STAGE_SS_FINISH, alpha, accepted)) != ILQR_OK) return rc;
+            if (steps && count < steps_cap) steps[count] = accepted ? alpha : 0.0;
+            ++count;
+        }
+        if ((rc = ilqr_run_stage(h, ILQR_STAGE_SS_OUTER)) != ILQR_OK) return rc;
+        if ((rc = scalars()) != ILQR_OK) return rc;
+        double n_open = 0.0;
+        for (int b = 0; b < B; ++b) n_open += sc[(size_t)b * NS + ilqr::S_DONE] == 0.0;
+        if ((rc = allsum(&n_open, 1)) != ILQR_OK) return rc;
+        if (n_open == 0.0) break;
+    }
+    if (n_steps) *n_steps = count;
     return ILQR_OK;
 }
 

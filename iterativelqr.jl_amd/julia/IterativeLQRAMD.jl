@@ -14,7 +14,7 @@
 module IterativeLQRAMD
 
 export Options, Solver, Dynamics, Cost, Constraint, initialize_controls!, initialize_states!, initialize_rollout!,
-       set_parameters!, solve!, get_trajectory, get_policy, stats, set_kernel_variant!, set_handover!, set_handover_live!, enable_trace!, trace
+       set_parameters!, solve!, solve_shared_step!, get_trajectory, get_policy, stats, set_kernel_variant!, set_handover!, set_handover_live!, enable_trace!, trace
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "lib", "libilqr_hip.so"))
 
@@ -345,6 +345,27 @@ function solve!(s::Solver, augmented_lagrangian_callback!::Function)
         augmented_lagrangian_callback!(s)
     end
     return nothing
+end
+
+# solve! with ONE step size per inner iteration for the whole batch, over every process of a multi-GPU job (not a reference behaviour:
+# the optional mode of include/ilqr_hip.h, ilqr_solve_shared_step). `reduce!(v::Vector{Float64})` sums v in place over all processes
+# (MPI.Allreduce!(v, +, comm), an RCCL binding, ...); without it the batch of this handle shares its step size alone.
+function solve_shared_step!(s::Solver, reduce!::Union{Function,Nothing} = nothing)
+    check(ccall((:ilqr_set_options, LIB[]), Cint, (Ptr{Cvoid}, Ref{Options}), s.handle, s.options))
+    cap = Int(s.options.max_dual_updates) * Int(s.options.max_iterations)
+    steps = zeros(Float64, max(cap, 1)); n = Ref{Int32}(0)
+    if reduce! === nothing
+        check(ccall((:ilqr_solve_shared_step, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int32, Ref{Int32}),
+                    s.handle, C_NULL, C_NULL, steps, cap, n))
+    else
+        cb = function (values::Ptr{Float64}, len::Int32, ::Ptr{Cvoid})::Cint
+            v = unsafe_wrap(Array, values, Int(len)); reduce!(v); return Cint(0)
+        end
+        cfn = @cfunction($cb, Cint, (Ptr{Float64}, Int32, Ptr{Cvoid}))
+        GC.@preserve cfn check(ccall((:ilqr_solve_shared_step, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int32, Ref{Int32}),
+                                     s.handle, cfn, C_NULL, steps, cap, n))
+    end
+    return steps[1:n[]]
 end
 
 # 0 = auto, 1 = latency, 2 = throughput, 3 = packed (four instances per wave, no horizon limit)

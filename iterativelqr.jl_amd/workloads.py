@@ -30,13 +30,23 @@ DIMS = {"particle": (2, 1), "acrobot": (4, 1), "car": (3, 2), "car_goal": (3, 2)
         "pendulum_euler": (2, 1), "synth32": (32, 8), "synth12": (12, 5)}
 
 
-def make_inputs(config, batch, seed=SEED, offset=0):
+def make_inputs(config, batch, seed=SEED, offset=0, generator="pcg64"):
     """Returns (model, T, x1[B,n], ubar[B,T-1,m]). `offset` shifts the instance
-    index so that shards of a larger batch draw disjoint, reproducible instances."""
+    index so that shards of a larger batch draw disjoint, reproducible instances.
+    generator: "pcg64" — one numpy PCG64 stream per instance (the inputs of every profile of rounds 1-5) — or "splitmix64" — the
+    library's own generator (ilqr_synthetic_inputs: SURVEY §8(d)'s splitmix64 / Box-Muller as a pure function of (seed, b, t, j)),
+    which a Julia or C host calls for the same instances."""
     model, T, _ = CONFIGS[config]
     n, m = DIMS[model]
     x1 = np.zeros((batch, n))
     ub = np.zeros((batch, T - 1, m))
+    if generator == "splitmix64":
+        import ctypes as C
+        from . import _ffi
+        _ffi.check(_ffi.lib().ilqr_synthetic_inputs(model.encode(), T, seed, offset, batch, x1.ctypes.data_as(_ffi.c_double_p),
+                                                    ub.ctypes.data_as(_ffi.c_double_p)))
+        return model, T, x1, ub
+    assert generator == "pcg64", generator
     for b in range(batch):
         rng = np.random.default_rng([seed, offset + b])
         if model == "particle":

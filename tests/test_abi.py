@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 from ilqr_amd_loader import load_package
@@ -180,3 +181,23 @@ def test_issue_model_is_a_product_of_the_build_and_goes_stale_with_the_sources(p
     monkeypatch.setattr(pkg._ffi, "device_source_hash", lambda: "0" * 16)      # as if a kernel header had been edited
     im2, why2 = pkg._ffi.issue_model("acrobot")
     assert im2 is None and "stale" in why2
+
+
+def test_synthetic_inputs_are_a_pure_function_of_seed_instance_timestep_component(pkg):
+    """ilqr_synthetic_inputs (splitmix64 -> U(0,1) -> Box-Muller; no device needed): shards of a larger batch are slices
+    of it, the values are standard normals at the reference's scales, the car's instance 0 is test/car.jl:24-29 exactly."""
+    W = pkg.workloads
+    model, T, x1, ub = W.make_inputs("acrobot", 2048, generator="splitmix64")
+    assert not x1.any() and abs(ub.mean()) < 0.01 and abs(ub.std() - 1.0) < 0.01 and np.isfinite(ub).all()
+    _, _, x1s, ubs = W.make_inputs("acrobot", 32, offset=1000, generator="splitmix64")
+    assert np.array_equal(ubs, ub[1000:1032])
+    _, _, _, ub2 = W.make_inputs("acrobot", 8, seed=1, generator="splitmix64")
+    assert not np.array_equal(ub2, ub[:8])
+    _, _, x1c, ubc = W.make_inputs("car", 64, generator="splitmix64")
+    assert not x1c[0].any() and np.array_equal(ubc[0], np.tile([1.0e-2, 1.0e-3], (50, 1)))
+    sc = ubc[1:, 0, 0] / 1.0e-2
+    assert (sc > 0.5).all() and (sc < 1.5).all() and np.allclose(ubc[1:, :, 1], 0.1 * ubc[1:, :, 0]) and (x1c[1:, 2] == 0).all()
+    _, _, x1y, uby = W.make_inputs("synth32", 512, generator="splitmix64")
+    assert not uby.any() and abs(x1y.std() - 0.5) < 0.01 and abs(np.corrcoef(x1y[:, 0], x1y[:, 16])[0, 1]) < 0.15
+    L = pkg._ffi.lib()
+    assert L.ilqr_synthetic_inputs(b"no_such_model", 11, 1, 0, 1, pkg._ffi.c_double_p(), pkg._ffi.c_double_p()) < 0
