@@ -248,7 +248,7 @@ def worker(args, solver_factory=None):
     distinct = bool(args.distinct_shards) or not bool(getattr(args, "same_instances", False))
     args.distinct_shards = distinct
     lo, _ = pkg.distributed.shard_range(rank, B)
-    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if distinct else 0, generator=args.generator))
+    model, T, x1, ub = pkg.workloads.make_inputs(args.config, B, offset=(lo if distinct else 0), generator=args.generator)
     if sharded:
         # one handle, ndev contiguous ranges of B instances: the same B instances on every device (fixed per-GPU work, like the
         # process-per-GPU default) or ndev * B distinct ones
@@ -503,9 +503,10 @@ def worker(args, solver_factory=None):
                             "note": "achieved / frac: v_mfma_f64_16x16x4_f64 flops INCLUDING the zero padding of the tiles (what the matrix pipe "
                                     "executes); useful_*: the recursion's own flops (SURVEY Appendix D); backward passes counted as inner "
                                     "iterations + one per ilqr_solve! call; the matrix pipe is shared by the two instances of a CU"}
-            roof["actual_bound"] = ("per-timestep latency of the Riccati step: four MFMA-tile windows around the serial potrf / potrs chain "
-                                    "(about 8 k clk per timestep for one instance alone, of which 2.2 k are MFMA pipe time per SIMD); "
-                                    "the launch lasts as long as its slowest instance")
+            roof["actual_bound"] = ("per-timestep latency of the Riccati step: MFMA-tile windows (three for 17 <= nx <= 32, four otherwise) around the "
+                                    "serial potrf / potrs chain — 6.7 k ticks per timestep with two instances per CU (tools/subphase_cycles.py), of which "
+                                    "4.9 k are the matrix pipe's floor (136 MFMAs x 71.5 clk x 2 instances over 4 SIMDs); the launch lasts as long as "
+                                    "its slowest instance")
         # instruction-issue model of the critical path: the per-step instruction lists of the serial loops, read off the assembly
         # the library's own compilation kept (csrc/Makefile -> lib/issue_model.json, stamped with the device-source hash)
         im, why_not = pkg._ffi.issue_model(model)

@@ -1115,7 +1115,8 @@ int ilqr_initialize_rollout(ilqr_handle* h, const double* x1, const double* u) {
     return ILQR_OK;
 }
 
-// Large models whose matrices are single tiles (nx, nu <= 16): the four-wave kernel holds 2 instances per CU, the one-wave kernel 8.
+// Large models whose matrices are single tiles (nx, nu <= 16): the four-wave kernel holds 2 instances per CU, the one-wave kernel SIX
+// (248 VGPRs and 25 KB of LDS per wave: profiles/r04_synth12_b4096_mid_rocprofv3.txt).
 // An instance alone is faster on four waves (its windows run their tiles side by side: 3.9 k against 5.3 k clk per Riccati step on
 // synth12, the rollout beside the sensitivity sweep instead of behind it), so auto takes one wave per instance only where residency
 // wins: beyond 8 instances per CU the four-wave kernel works in more than four rounds (tools/mid_bench.py: equal at 2048 instances

@@ -11,12 +11,15 @@
 //   * the full jacobian_* / hessian_* arrays of the reference are a host-visible mirror, written on demand by
 //     mirror_large_kernel and read back into the compact form by it after a host write.
 // Riccati step (src/backward_pass.jl:42-90): 136 v_mfma_f64_16x16x4_f64 for n = 32, m = 8 around the serial Cholesky chain,
-// scheduled statically (RicSchedule) over the four waves in four windows, one workgroup barrier each, and compiled into one
-// straight-line instruction stream per wave (tile coordinates are immediates). For 17 <= nx <= 32:
-//     A   waves 0,1: ûx = fuᵀP′ (the tiles the chain waits for)          waves 2,3: T(0,.) = fxᵀP′
-//     B   waves 0,1: Qux = ûx fx + gux    wave 2: Quu = ûx fu + guu      wave 3: Qu = fuᵀp′ + gu, Qx = fxᵀp′ + gx
-//     C   wave 0: potrf and potrs fused in registers → K, k; p, ∇L       waves 1-3: T(1,.) (flags in LDS), Qxx = T fx + gxx
-//     D   every wave one tile of P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx; the next step's operands go into LDS in its shadow
+// scheduled statically (RicSchedule) over the four waves in windows that end in one workgroup barrier each, and compiled into one
+// straight-line instruction stream per wave (tile coordinates are immediates). For 17 <= nx <= 32 (round 5: THREE windows):
+//     B   waves 0,1: Qux = ûx fx + gux    wave 2: Quu = ûx fu + guu      wave 3: T(0,0) = fxᵀP′
+//         (row nu of ûx is p′ᵀ: row nu of the Qux / Quu tiles is Qx - gx / Qu - gu — the step's two matrix-vector products for free)
+//     C   wave 0: potrf and potrs fused in registers → K, k; p, ∇L       waves 1-3: T(0,1), T(1,.) (flags in LDS), Qxx = T fx + gxx
+//     D   every wave one tile of P = Kᵀûxt + KᵀQux + QuxᵀK + Qxx and, straight from that tile's registers, its share of the NEXT
+//         step's ûx = fuᵀP′ (ds_add_f64 into the zeroed buffer: two contributions per element); the next step's operands go
+//         into LDS in its shadow
+//     other sizes keep the four-window schedule: A  ûx = fuᵀP′ | T   B  Qux, Quu | T, (Qu, Qx)   C  chain | T, Qxx   D  P
 // Operand fragments are read from zero-padded LDS matrices with odd leading dimensions (transposition = stride pattern, no
 // bounds checks), all fragments of a tile before its first MFMA, the MFMAs of a tile back to back.
 // Forward sweep: wave 0 runs the closed-loop rollout, wave 1 the sensitivity recursion Δz with ∇Lᵀ·Δz, waves 2,3 stage K_t, a_t,
