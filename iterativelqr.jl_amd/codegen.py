@@ -885,3 +885,49 @@ def generate_model_source(name, dynamics, cost_stage, cost_term, con_stage=None,
 
 def source_hash(src):
     return hashlib.sha256(src.encode()).hexdigest()[:16]
+
+
+# --------------------------------------------------------------------------- symbolic objects as C callables (the C-source seam)
+def c_callable(name, exprs, obj, terminal=False):
+    """One `ILQR_MODEL_FN void name(double* out, const double* x, const double* u, const double* w)` of the reference's in-place
+    callable contract (src/dynamics.jl:55-60, src/costs.jl:1-15, src/constraints.jl:54-64) from symbolic expressions — what the Julia
+    wrapper gets from Symbolics.build_function(...; target = CTarget()). `exprs`: flat list in the callable's COLUMN-MAJOR output
+    order; zero entries are not written (out arrives zeroed). Plain C (math.h), no dependence on the device headers."""
+    from sympy.printing.c import C99CodePrinter
+    pr = C99CodePrinter({"strict": False})
+    exprs = [sp.sympify(e) for e in exprs]
+    repl, red = sp.cse(exprs, symbols=sp.numbered_symbols("t")) if exprs else ([], [])
+    sub = {s_: sp.Symbol("x[%d]" % i) for i, s_ in enumerate(obj.x)}
+    if not terminal:
+        sub.update({s_: sp.Symbol("u[%d]" % i) for i, s_ in enumerate(obj.u)})
+    sub.update({s_: sp.Symbol("w[%d]" % i) for i, s_ in enumerate(obj.w)})
+    body = ["    const double %s = %s;" % (sym, pr.doprint(e.xreplace(sub))) for sym, e in repl]
+    body += ["    out[%d] = %s;" % (i, pr.doprint(e.xreplace(sub))) for i, e in enumerate(red) if e != 0]
+    return "ILQR_MODEL_FN void %s(double* out, const double* x, const double* u, const double* w) {\n%s\n}\n" % (name, "\n".join(body))
+
+
+def _colmajor(rows):
+    """[row][col] -> flat column-major list"""
+    return [rows[i][j] for j in range(len(rows[0]) if rows else 0) for i in range(len(rows))]
+
+
+def c_dynamics(prefix, d):
+    return (c_callable(prefix, d.evaluate, d) + c_callable(prefix + "_jacobian_state", _colmajor(d.jacobian_state), d) +
+            c_callable(prefix + "_jacobian_action", _colmajor(d.jacobian_action), d))
+
+
+def c_cost(prefix, c, terminal=False):
+    src = (c_callable(prefix, [c.evaluate], c, terminal) + c_callable(prefix + "_gradient_state", c.gradient_state, c, terminal) +
+           c_callable(prefix + "_hessian_state_state", _colmajor(c.hessian_state_state), c, terminal))
+    if not terminal:
+        src += (c_callable(prefix + "_gradient_action", c.gradient_action, c) +
+                c_callable(prefix + "_hessian_action_action", _colmajor(c.hessian_action_action), c) +
+                c_callable(prefix + "_hessian_action_state", _colmajor(c.hessian_action_state), c))
+    return src
+
+
+def c_constraint(prefix, k, terminal=False):
+    src = c_callable(prefix, k.evaluate, k, terminal) + c_callable(prefix + "_jacobian_state", _colmajor(k.jacobian_state), k, terminal)
+    if not terminal:
+        src += c_callable(prefix + "_jacobian_action", _colmajor(k.jacobian_action), k)
+    return src

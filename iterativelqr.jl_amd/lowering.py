@@ -141,3 +141,18 @@ def lower(dynamics, costs, constraints=None):
             con_term_l = Constraint()
     return dict(dynamics=dyn, cost_stage=cost_stage, cost_term=cost_term_l, con_stage=con_stage, con_term=con_term_l,
                 num_user_parameter=nwu, selectors=sel, constraint_rows=rows, state_dims=n_t, action_dims=m_t)
+
+
+def c_stage_sources(dynamics, costs, constraints=None):
+    """The problem's per-step objects as (StageKinds, C source of the distinct kinds' callables) for ilqr_compile_model_stages — the
+    route of a host without the symbolic device-code generator (the Julia wrapper does the same with Symbolics' C target): the
+    LIBRARY lowers the kinds onto its one-stage template. Solver(stage_sources = c_stage_sources(...))."""
+    from . import codegen
+    kinds, (dk, ck, kk, ki, cost_term, con_term, nwu) = stage_kinds(dynamics, costs, constraints)
+    src = "".join(codegen.c_dynamics("dynamics_%d" % q, d) for q, d in enumerate(dk))
+    src += "".join(codegen.c_cost("cost_stage_%d" % q, c) for q, c in enumerate(ck))
+    src += "".join(codegen.c_constraint("constraint_stage_%d" % q, c) for q, c in enumerate(kk) if c.num_constraint > 0)
+    src += codegen.c_cost("cost_terminal", cost_term, terminal=True)
+    if con_term is not None and con_term.num_constraint > 0:
+        src += codegen.c_constraint("constraint_terminal", con_term, terminal=True)
+    return kinds, src

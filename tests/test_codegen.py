@@ -356,3 +356,21 @@ def test_large_model_structure_detection():
     m12 = pkg.models.synth12()
     _, s12 = pkg.codegen.generate_model_source("synth12_t", m12["dynamics"], m12["cost_stage"], m12["cost_term"], m12["con_stage"], m12["con_term"])
     assert "static constexpr bool JAC_VAR_ELEMENTWISE = false;" in s12 and "dyn_jac_var_own" not in s12 and "static void dyn_jac_var(" in s12
+
+
+def test_c_stage_sources_of_distinct_objects_compile(tmp_path):
+    """lowering.c_stage_sources: symbolic per-step objects -> C callables per kind -> ilqr_compile_model_stages (all three selector
+    categories, stacked constraint kinds). Compiles without a GPU."""
+    import ctypes as C
+    from ilqr_amd_loader import load_package
+    pkg = load_package()
+    F, L = pkg._ffi, pkg._ffi.lib()
+    T = 13
+    kinds, src = pkg.lowering.c_stage_sources(*pkg.models.car_tv(T))
+    assert "dynamics_1_jacobian_action" in src and "constraint_stage_2_jacobian_state" in src and "constraint_stage_1" not in src
+    cap = T * (kinds.n_dynamics + kinds.n_costs + kinds.n_constraints)
+    plan, sel = F.StagePlan(), (C.c_double * cap)()
+    reg, path = C.create_string_buffer(160), C.create_string_buffer(1024)
+    rc = L.ilqr_compile_model_stages(b"car_tv_c", C.byref(kinds), src.encode(), C.byref(plan), sel, cap, None, None, reg, 160, path, 1024)
+    assert rc == 0, L.ilqr_last_error().decode()
+    assert (plan.nx, plan.nu, plan.nw, plan.nc_stage, plan.nc_term, plan.n_selectors) == (3, 2, 7, 6, 4, 7)

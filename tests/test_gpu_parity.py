@@ -610,6 +610,37 @@ def test_time_varying_stage_objects(pkg, oracle):
     sol.close()
 
 
+def test_time_varying_stage_objects_from_c_sources_per_kind(pkg, oracle):
+    """car_tv (two dynamics, two stage costs, three stage constraints: 5 inequalities / none / 1 equality) the way a Julia or C host
+    hands it over: C callables per kind (here printed from the symbolic objects, as the Julia wrapper prints Symbolics' C target),
+    lowered by the LIBRARY — selector branches for all three categories, constraint kinds stacked row-wise with shifted inequality
+    masks (ilqr_compile_model_stages). Against the oracle's genuinely per-step problem, and close to the symbolic route's result."""
+    T, B = 51, 48
+    _, _, x1, ub = pkg.workloads.make_inputs("car", B)
+    dynamics, costs, constraints = pkg.models.car_tv(T)
+    sol = pkg.Solver(stage_sources=pkg.lowering.c_stage_sources(dynamics, costs, constraints), batch=B, options=pkg.Options(verbose=0),
+                     name="car_tv_c")
+    assert (sol.nx, sol.nu, sol.nc_stage, sol.nc_term, sol.num_user_parameter, sol.nw) == (3, 2, 6, 4, 0, 0)
+    assert sol.constraint_rows[0] == [0, 1, 2, 3, 4] and sol.constraint_rows[1] == [] and sol.constraint_rows[2] == [5]
+    sol.initialize_rollout_(x1, ub)
+    xb0 = np.stack([oracle.Problem("car_tv", T).rollout(x1[b], ub[b]) for b in range(4)])
+    assert np.abs(sol.buffer("nominal_states").reshape(B, T, 3)[:4] - xb0).max() < 1e-12
+    sol.solve_()
+    x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
+    ref = oracle.solve_batch("car_tv", T, x1, ub, nthreads=4)
+    same = (st["iterations"] == ref["stats"]["iterations"]) & (st["rollouts"] == ref["stats"]["rollouts"])
+    assert same.mean() >= 0.97, same.mean()
+    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
+    assert np.abs(K - ref["K"])[same].max() <= 5e-7 * np.abs(ref["K"]).max()
+    assert np.allclose(st["max_violation"][same], ref["stats"]["max_violation"][same], atol=1e-8)
+    c = sol.buffer("violations").reshape(B, -1)[:, :(T - 1) * 6].reshape(B, T - 1, 6)
+    lam = sol.buffer("constraint_dual").reshape(B, -1)[:, :(T - 1) * 6].reshape(B, T - 1, 6)
+    for t in range(T - 1):
+        off = [i for i in range(6) if i not in sol.constraint_rows[t]]
+        assert (c[:, t, off] == 0).all() and (lam[:, t, off] == 0).all()
+    sol.close()
+
+
 def test_large_path_odd_dimensions_and_terminal_constraint(pkg, oracle):
     """synth12: nx = 12, nu = 5 (not multiples of the 16x16 MFMA tile or of the k-step: the zero-padded
     tile paths), state-dependent fu entries (bilinear term), a terminal equality (al_t on the large path) and
