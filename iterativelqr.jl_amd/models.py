@@ -233,7 +233,7 @@ def ragged_c_stages(T):
         if kc not in ck:
             ck.append(kc)
         di.append(dk.index(kd)); ci.append(ck.index(kc))
-    src = ["/* GENERATED by iterativelqr.jl_amd/models.py:ragged_c_stages(%d): per-kind callables, each in its own dimensions, `out` column-major and zeroed */" % T]
+    src = ["/* GENERATED by iterativelqr.jl_amd/models.py:ragged_c_stages: per-kind callables, each in its own dimensions, `out` column-major and zeroed */"]
     g = lambda v: "%.17g" % v
     for q, (n0, m0, n1) in enumerate(dk):
         A, Bm = _ragged_tables(n0, m0, n1)

@@ -39,6 +39,17 @@ def main(verbose=True):
                 raise RuntimeError("ilqr_compile_model(%s, probe=%s): %s" % (name.decode(), probe, L.ilqr_last_error().decode()[-600:]))
             if verbose:
                 print("model module %s (%s tables): %s" % (reg.value.decode(), "probed" if probe else "dense", os.path.basename(path.value.decode())))
+        # per-step objects through ilqr_compile_model_stages (the GPU tests' ragged_c and car_tv_c; horizon 41 / 51 as there)
+        F = pkg._ffi
+        for name, (kinds, src) in ((b"ragged_c", pkg.models.ragged_c_stages(41)), (b"car_tv_c", pkg.lowering.c_stage_sources(*pkg.models.car_tv(51)))):
+            cap = kinds.horizon * (kinds.n_dynamics + kinds.n_costs + kinds.n_constraints)
+            plan, sel = F.StagePlan(), (C.c_double * max(cap, 1))()
+            reg = C.create_string_buffer(160); path = C.create_string_buffer(1024)
+            rc = L.ilqr_compile_model_stages(name, C.byref(kinds), src.encode(), C.byref(plan), sel, cap, None, None, reg, 160, path, 1024)
+            if rc != 0:
+                raise RuntimeError("ilqr_compile_model_stages(%s): %s" % (name.decode(), L.ilqr_last_error().decode()[-600:]))
+            if verbose:
+                print("model module %s (per-step kinds): %s" % (reg.value.decode(), os.path.basename(path.value.decode())))
     finally:
         if old is None:
             os.environ.pop("ILQR_NO_STRUCTURE_PROBE", None)
