@@ -246,9 +246,22 @@ int ilqr_resolved_kernel_variant(ilqr_handle* h, int32_t* variant);
  *     when it ENTERS outer iteration k leaves at that boundary.
  *   ilqr_set_handover_live(live), used when outer = -1: once no more than `live` instances of the batch are still running,
  *     every survivor leaves at its next resumable point. -1 auto = min(1024, batch / 4), what the latency kernel holds at full
- *     speed; 0 off; n >= 1 as given. */
+ *     speed; 0 off; n >= 1 as given.
+ * One wave per pack (the packed kernel's form above four packs per CU, two packs per workgroup): the workgroups finish the
+ * handed-over instances THEMSELVES — once both its packs are through, a workgroup takes instances from a device-wide queue
+ * and runs the latency kernel's code on each, so the second launch finds nothing left (it stays as the net) — and a straggler
+ * does not wait for the head count: under that rule
+ *   ilqr_set_handover_mark(rejected): an instance whose rejected line-search trials (src/forward_pass.jl:51; those of forward
+ *     passes that ended in an acceptance) exceed the mean over the batch so far by `rejected`, while more than half the batch is
+ *     still running, is marked at the head of its next
+ *     inner iteration; its workgroup's two packs leave at their next resumable points and the workgroup finishes the marked
+ *     instance at once (BASELINE config 4: instance 2300 of shard 2 — 682 iterations, 1354 rollouts, the others 347 — is
+ *     marked in its second iteration). -1 auto = 6; 0 never; n >= 1 as given. */
 int ilqr_set_handover(ilqr_handle* h, int32_t outer);
 int ilqr_set_handover_live(ilqr_handle* h, int32_t live);
+int ilqr_set_handover_mark(ilqr_handle* h, int32_t rejected);
+/* What the last ilqr_solve did there: instances that went through the queue, instances marked as stragglers. */
+int ilqr_get_handover_stats(ilqr_handle* h, int32_t* queued, int32_t* marked);
 
 /* Per-iteration record of what the reference prints when `verbose` (src/solve.jl:40-45): for every
  * instance up to `capacity` rows of 8 doubles {outer, inner, objective, gradient_norm, max_violation,

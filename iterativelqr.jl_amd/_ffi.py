@@ -136,6 +136,8 @@ SYMBOLS = {
     "ilqr_resolved_kernel_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "ilqr_set_handover": (C.c_int, [C.c_void_p, C.c_int32]),
     "ilqr_set_handover_live": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ilqr_set_handover_mark": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ilqr_get_handover_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_enable_trace": (C.c_int, [C.c_void_p, C.c_int32]),
     "ilqr_get_trace": (C.c_int, [C.c_void_p, c_double_p]),
     "ilqr_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -308,6 +308,16 @@ class Solver:
         """Hand-over by head count (see ilqr_set_handover_live): -1 auto, 0 off, n = survivors of the batch at which they all leave."""
         _ffi.check(_ffi.lib().ilqr_set_handover_live(self._h, int(live)))
 
+    def set_handover_mark_(self, rejected):
+        """Early leave of stragglers (see ilqr_set_handover_mark): -1 auto, 0 never, n = rejected line-search trials above the batch's mean."""
+        _ffi.check(_ffi.lib().ilqr_set_handover_mark(self._h, int(rejected)))
+
+    def handover_stats(self):
+        """(instances the packed kernel's workgroups took from their queue, instances marked as stragglers) of the last solve_."""
+        q = C.c_int32(0); m = C.c_int32(0)
+        _ffi.check(_ffi.lib().ilqr_get_handover_stats(self._h, C.byref(q), C.byref(m)))
+        return q.value, m.value
+
     def enable_trace_(self, capacity):
         """Record per-iteration rows (what `verbose` prints in the reference) during solve_."""
         self._trace_cap = int(capacity)

@@ -110,6 +110,8 @@ struct ilqr_handle {
     int handover;         // straggler hand-over of the packed kernel: -1 auto (by head count), 0 off, k > 1 = instances entering outer iteration k
     int handover_live;    // head-count rule: survivors of the batch at which they all leave (-1 auto, 0 off)
     int* done_counter;    // device counter of finished instances for that rule
+    int* pool;            // one-wave form of the packed kernel: queue of handed-over instances its workgroups finish themselves (POOL_Q + B ints)
+    int handover_mark;    // rejected line-search trials above the batch's mean at which an instance is marked a straggler (-1 auto, 0 never)
     int variant;          // 0 auto, 1 latency kernel (all-LDS, 2 waves per instance; large models: four waves per instance), 2 throughput kernel (slim), 3 packed kernel (4 instances per wave, no LDS), 4 one wave per instance of a large model with nx, nu <= 16
     bool lds_fits;        // the LDS-resident kernels can hold this horizon (otherwise only the packed kernel runs it)
     int num_simds;
@@ -141,6 +143,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.qv = h->qv; a.QL = h->QL;
     a.stage_param = 0.0; a.stage_flag = 0;
     a.handover_outer = 0; a.resume = 0; a.handover_live = 0; a.done_counter = h->done_counter;
+    a.pool = nullptr; a.pool_mark = 0; a.pool_lds = 0; a.pool_ctl = 0;
     return a;
 }
 
@@ -909,7 +912,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->lds_bytes = ilqr::is_large_model(vt->nx, vt->nu) ? (size_t)ilqr::large_lds_doubles(vt->nx, vt->nu, vt->hess_nnz) * 8
                                                           : (size_t)h->L.lds_doubles * 8;
     h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr;
-    h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024; h->handover = -1; h->handover_live = -1; h->done_counter = nullptr;
+    h->trace = nullptr; h->trace_cap = 0; h->variant = 0; h->num_simds = 1024; h->handover = -1; h->handover_live = -1; h->done_counter = nullptr; h->pool = nullptr; h->handover_mark = -1;
     h->qv = nullptr; h->QL = ilqr::make_qlayout(vt->nx, vt->nu, d->horizon); h->full_stale = false; h->P_dirty = false;
     ilqr_default_options(&h->opt);
     fill_buffers(h);
@@ -936,6 +939,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->ws_bytes = (size_t)h->B * (size_t)h->L.stride * 8;
     if ((e = hipMalloc((void**)&h->ws, h->ws_bytes)) != hipSuccess) return bail(e, "hipMalloc(workspace)");
     if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->done_counter, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(hand-over counter)");
+    if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->pool, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B))) != hipSuccess) return bail(e, "hipMalloc(hand-over queue)");
     if ((e = hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     *out = h;
     int rc = ilqr_reset(h);
@@ -952,7 +956,7 @@ int ilqr_create_sharded(const ilqr_problem_desc* d, const int32_t* devices, int3
     if (d->horizon < 2 || d->batch < 1) return fail(ILQR_ERR_INVALID, "horizon must be >= 2 and batch >= 1");
     if (n_devices > d->batch) return fail(ILQR_ERR_INVALID, "more devices than instances");
     ilqr_handle* h = new ilqr_handle();
-    h->vt = nullptr; h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr; h->trace = nullptr; h->qv = nullptr; h->done_counter = nullptr;
+    h->vt = nullptr; h->ws = nullptr; h->d_x1 = nullptr; h->d_u = nullptr; h->stream = nullptr; h->trace = nullptr; h->qv = nullptr; h->done_counter = nullptr; h->pool = nullptr;
     h->B = d->batch; h->device = devices[0]; h->constrained = d->constrained ? 1 : 0; h->trace_cap = 0; h->variant = 0;
     const int per = (d->batch + n_devices - 1) / n_devices;
     for (int i = 0, lo = 0; i < n_devices && lo < d->batch; ++i, lo += per) {
@@ -986,6 +990,7 @@ int ilqr_destroy(ilqr_handle* h) {
     if (h->ws) hipFree(h->ws);
     if (h->d_x1) hipFree(h->d_x1);
     if (h->done_counter) hipFree(h->done_counter);
+    if (h->pool) hipFree(h->pool);
     if (h->d_u) hipFree(h->d_u);
     if (h->trace) hipFree(h->trace);
     if (h->qv) hipFree(h->qv);
@@ -1172,6 +1177,13 @@ int ilqr_solve(ilqr_handle* h) {
         if (!can) live = 0;
         a.handover_outer = ho; a.handover_live = live;
         if (live > 0) HIP_TRY(hipMemsetAsync(h->done_counter, 0, sizeof(int), h->stream));
+        // the one-wave form's workgroups finish the instances handed over themselves (ilqr_device_packed.hpp: solve_kernel_packed);
+        // under the head-count rule an instance whose rejected line-search trials exceed the batch's mean by `mark` leaves at once
+        if ((ho > 0 || live > 0) && h->pool != nullptr) {
+            HIP_TRY(hipMemsetAsync(h->pool, 0, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B), h->stream));
+            a.pool = h->pool; a.pool_lds = (int)h->lds_bytes;
+            a.pool_mark = live > 0 ? (h->handover_mark < 0 ? 6 : h->handover_mark) : 0;
+        }
 #ifdef ILQR_PK_DEBUG_HOOK      // phase-timing hook of tools/packed_phases.py (see ilqr_device_packed.hpp); never compiled into the product library
         if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);
 #endif
@@ -1181,7 +1193,7 @@ int ilqr_solve(ilqr_handle* h) {
         a.stage_flag = (h->variant != 5 && per_cu <= 4) ? 2 : 0;
         a.stage_param = (double)per_cu;
         if (h->vt->launch_solve_packed(&a, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (packed variant) launch failed"));
-        a.stage_flag = 0; a.stage_param = 0.0;
+        a.stage_flag = 0; a.stage_param = 0.0; a.pool = nullptr; a.pool_mark = 0;
         if (ho > 0 || live > 0) {
             ilqr::KArgs r = a;
             r.resume = 1; r.stage = 0;
@@ -1446,6 +1458,30 @@ int ilqr_set_handover_live(ilqr_handle* h, int32_t live) {
     if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_handover_live(s, live); });
     if (!h || live < -1) return fail(ILQR_ERR_INVALID, "hand-over by head count: -1 (auto), 0 (off) or the number of surviving instances at which they leave the packed kernel");
     h->handover_live = live;
+    return ILQR_OK;
+}
+
+int ilqr_set_handover_mark(ilqr_handle* h, int32_t rejected) {
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) { return ilqr_set_handover_mark(s, rejected); });
+    if (!h || rejected < -1) return fail(ILQR_ERR_INVALID, "straggler mark: -1 (auto), 0 (never) or the number of rejected line-search trials above the batch's mean at which an instance leaves the packed kernel at once");
+    h->handover_mark = rejected;
+    return ILQR_OK;
+}
+
+int ilqr_get_handover_stats(ilqr_handle* h, int32_t* queued, int32_t* marked) {
+    if (!h || !queued || !marked) return fail(ILQR_ERR_INVALID, "null argument");
+    *queued = 0; *marked = 0;
+    if (SHARDED(h)) return each_shard(h, [&](ilqr_handle* s, size_t) {
+        int32_t q = 0, m = 0;
+        const int rc = ilqr_get_handover_stats(s, &q, &m);
+        *queued += q; *marked += m;
+        return rc; });
+    if (h->pool == nullptr) return ILQR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int words[ilqr::POOL_Q];
+    HIP_TRY(hipMemcpy(words, h->pool, sizeof(words), hipMemcpyDeviceToHost));
+    *queued = words[ilqr::POOL_TAIL]; *marked = words[ilqr::POOL_MARKED];
     return ILQR_OK;
 }
 

@@ -61,6 +61,13 @@ struct KArgs {
     // the linearisation, the accumulated Hessians, K and k are in the workspace block). 0 = off.
     int handover_live;
     int* done_counter;
+    // One-wave form of the packed kernel: its workgroups finish handed-over instances themselves (ilqr_device_packed.hpp,
+    // solve_kernel_packed). pool: queue words in HBM (null = hand-overs wait for the resume launch); pool_mark: rejected line-search
+    // trials above the batch's mean at which an instance is marked a straggler and leaves at once (0 = never); pool_lds: bytes of
+    // LDS solve_instance needs (the launcher drops the pool where that would cost the packed kernel residency); pool_ctl: where the
+    // workgroup's control words lie in LDS (set by the launcher).
+    int* pool;
+    int pool_mark, pool_lds, pool_ctl;
 };
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
@@ -2208,16 +2215,31 @@ struct ModelModule {
     // KArgs::stage_param = workgroups per CU at this batch size: taken when its two chunk buffers fit a CU's LDS at that residency
     static int launch_solve_packed(const KArgs* a, void* stream) {
         if constexpr (packed_ok<M>::value) {
-            constexpr size_t lds1 = sizeof(double) * pk::PkLds<M, false>::total, lds2 = sizeof(double) * pk::PkLds<M, true>::total;
+            constexpr size_t lds2 = sizeof(double) * pk::PkLds<M, true>::total;
             const double per_cu = a->stage_param >= 1.0 ? a->stage_param : 1.0;
             if (a->stage_flag == 2 && per_cu * (double)(lds2 + 512) <= 160.0 * 1024.0 && per_cu <= 4.0) {
                 KArgs b = *a;
                 b.stage_flag = 0; b.stage_param = 0.0;
                 hipLaunchKernelGGL((solve_kernel_packed<M, true>), dim3((a->B + 3) / 4), dim3(128), lds2, (hipStream_t)stream, b);
             } else {
+                // one-wave form: two packs per workgroup (four workgroups of 256-register waves per CU); with the pool where the
+                // latency solver's LDS fits without costing residency
                 KArgs b = *a;
                 b.stage_flag = 0; b.stage_param = 0.0;
-                hipLaunchKernelGGL((solve_kernel_packed<M, false>), dim3((a->B + 3) / 4), dim3(64), lds1, (hipStream_t)stream, b);
+                constexpr size_t pack = sizeof(double) * ((pk::PkLds<M, false>::total + 1) & ~1);
+                size_t lds = 2 * pack;
+                const size_t cu = 160 * 1024, ctl = sizeof(int) * CTL_WORDS;
+                auto per = [&](size_t bytes) { const size_t k = cu / ((bytes + 511) & ~(size_t)511); return k < 4 ? k : 4; };
+                if (b.pool != nullptr && b.pool_lds > 0) {
+                    const size_t with_pool = lds > (size_t)b.pool_lds ? lds : (size_t)b.pool_lds;
+                    if (per(with_pool + ctl) >= per(lds + ctl)) lds = with_pool; else b.pool = nullptr;
+                } else b.pool = nullptr;
+                b.pool_ctl = (int)(lds / sizeof(double));
+                lds += ctl;
+                if (lds > 64 * 1024 &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel_packed<M, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+                hipLaunchKernelGGL((solve_kernel_packed<M, false>), dim3(((a->B + 3) / 4 + 1) / 2), dim3(128), lds, (hipStream_t)stream, b);
             }
             return hipGetLastError() == hipSuccess ? 0 : -1;
         } else {

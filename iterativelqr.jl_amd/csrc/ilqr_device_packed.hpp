@@ -89,9 +89,21 @@ struct PInst {
     double objective, max_violation, step_size, gradient_norm, obj_prev, J_prev, delta, delta_next;
     int status, iterations, outer, it, trial, rollouts, potrf_info, states_eq_nominal, trace_len, state, needB, leaving;
     int nbar;          // workgroup barriers this wave has passed (two-wave form: an order to the helper wave names the barrier it is valid from)
+    // one-wave form: a workgroup holds TWO packs, one per wave, each with its own control flow and its own LDS region (lds0, in
+    // doubles from the dynamic LDS base); such a wave never meets the other at a barrier inside the state machine
+    int lds0;
+    bool paired;
+    int rej_acc;       // rejected line-search trials of the forward passes that ended in an acceptance (the straggler mark's measure); bit 30: marked
 };
-// every workgroup barrier of the solver wave goes through here
-template <class M> __device__ __forceinline__ void pk_sync(PInst<M>& I) { __syncthreads(); I.nbar += 1; }
+// every workgroup barrier of the solver wave goes through here (one-wave form: what __syncthreads() is to a lone wave — its own
+// stores and loads in order: fences of WAVEFRONT scope, which cost no s_waitcnt (in a 64-thread workgroup the compiler reduces
+// __syncthreads() to exactly that; workgroup-scope fences in the 128-thread workgroup drained every store at every sync point, +5 %
+// on the shard) — and no s_barrier, which would tie the workgroup's two independent packs together)
+template <class M> __device__ __forceinline__ void pk_sync(PInst<M>& I) {
+    if (I.paired) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    else __syncthreads();
+    I.nbar += 1;
+}
 enum { PK_LINEARISE = 1, PK_COST = 2 };
 // Two-wave form: the solver wave's order to the helper wave, valid from the solver wave's NEXT barrier on. The helper looks into
 // the mailbox after every barrier and may well see an order early (written after the barrier both just passed): it takes it only
@@ -313,7 +325,8 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
     typedef PkLds<M, TWO> LD;
     static_assert(n <= 4 && m <= 4, "packed Riccati step: nx, nu <= 4");
     constexpr bool SHARE = 2 * m <= 4;      // k's right-hand side fits into the spare rows m..2m-1 of the block and shares K's solve
-    extern __shared__ __attribute__((aligned(16))) double pk_lds[];
+    extern __shared__ __attribute__((aligned(16))) double pk_lds_[];
+    double* const pk_lds = pk_lds_ + I.lds0;                                        // this pack's region
     const Layout& L = I.L;
     const int lane = I.lane, r = I.r, c = I.c, N = L.T - 1;
     const bool on = I.valid_blk && ((mask >> I.beta) & 1u);
@@ -515,7 +528,7 @@ __device__ void linearise_riccati(PInst<M>& I, bool act_row, unsigned mask, bool
         // buffer ch & 1, while the previous chunk's steps ran here)
         if constexpr (!TWO) {
             if (act_row && I.j < cnt) {
-                LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + I.j, I.q * LD::IB, I.j, constrained ? 1 : 0};
+                LinArgs la{gr, L.xb, L.ub, L.w, L.gxx, L.guu, L.gux, L.rho, L.act, L.lam, L.c, t0 + I.j, I.lds0 + I.q * LD::IB, I.j, constrained ? 1 : 0};
                 linearise_stage<M>(la);
             }
         }
@@ -768,27 +781,28 @@ __device__ void pk_helper(const KArgs& a) {
 }
 }  // namespace pk
 
-// solve!(solver) for four instances per wave — src/solve.jl:1-54, 88-143 as a per-instance state machine
-template <class M, bool TWO = false>
-__global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a) {
+// words of KArgs::pool (ints in HBM, zeroed by the host before every launch): the device-wide queue of handed-over instances
+enum { POOL_TAIL = 0, POOL_HEAD = 1, POOL_PACKS_DONE = 2, POOL_REJECTED = 3, POOL_MARKED = 4, POOL_BUSY = 5, POOL_Q = 8 };
+// control words of a one-wave-form workgroup (ints in LDS behind everything else, KArgs::pool_ctl doubles from the base)
+enum { CTL_EVACUATE = 0, CTL_NEXT = 1, CTL_OWN = 8, CTL_WORDS = 16 };
+
+// solve!(solver) for the four instances of pack `pack` — src/solve.jl:1-54, 88-143 as a per-instance state machine. TWO: the
+// workgroup's second wave serves linearisations and trial costs (pk_helper); PAIR: the workgroup's other wave runs a pack of its
+// own. Out: per row, where the instance was handed over (0: it was not) and whether it was marked as a straggler.
+template <class M, bool TWO, bool PAIR>
+__device__ __forceinline__ void packed_solve_body(const KArgs& a, const int pack, const int lds0, int& resume_out, bool& marked_out) {
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS;
     using namespace pk;
-    if constexpr (TWO) {
-        extern __shared__ __attribute__((aligned(16))) double pk_lds[];
-        if (threadIdx.x < 8) ((volatile int*)(pk_lds + PkLds<M, true>::MBOX))[threadIdx.x] = 0;
-        __syncthreads();
-        if (threadIdx.x >= 64) { pk_helper<M>(a); return; }
-    }
     PInst<M> I;
     const Layout& L = a.L;
     I.L = L;
-    I.nbar = 0;
+    I.nbar = 0; I.lds0 = lds0; I.paired = PAIR; I.rej_acc = 0;
     I.lane = threadIdx.x & 63; I.q = I.lane >> 4; I.j = I.lane & 15; I.beta = (I.lane >> 2) & 3; I.r = I.lane >> 4; I.c = I.lane & 3;
-    const int b_row = blockIdx.x * 4 + I.q, b_blk = blockIdx.x * 4 + I.beta;
+    const int b_row = pack * 4 + I.q, b_blk = pack * 4 + I.beta;
     I.valid_row = b_row < a.B; I.valid_blk = b_blk < a.B;
     I.g = a.ws + (size_t)(I.valid_row ? b_row : a.B - 1) * (size_t)L.stride;
     I.gb = a.ws + (size_t)(I.valid_blk ? b_blk : a.B - 1) * (size_t)L.stride;
-    I.wb = (const char*)(a.ws + (size_t)(blockIdx.x * 4) * (size_t)L.stride);
+    I.wb = (const char*)(a.ws + (size_t)(pack * 4) * (size_t)L.stride);
     I.trace = a.trace ? a.trace + (size_t)(I.valid_row ? b_row : 0) * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;
     const ilqr_options& opt = a.opt;
@@ -816,6 +830,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
     // head of every cycle; once the survivors of the whole batch are few enough, every one of them leaves at its next resumable point
     int n_prev = __popcll(__ballot(live && I.j == 0));
     bool ho_now = false;
+    int mark_cycle = 0;
     auto write_scalars = [&]() {
         scal[S_OBJECTIVE] = I.objective; scal[S_MAX_VIOLATION] = I.max_violation;
         scal[S_STEP_SIZE] = I.step_size; scal[S_GRADIENT_NORM] = I.gradient_norm;
@@ -847,6 +862,37 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
             n_prev = n_now;
             const int done = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             ho_now = a.B - done <= a.handover_live;
+            if constexpr (PAIR) {
+                if (a.pool != nullptr && !ho_now && (++mark_cycle & 3) == 0) {          // (every fourth cycle: two more loads from L2)
+                    // STRAGGLERS LEAVE AT ONCE. An instance that will need twice the iterations of the others shows early: its
+                    // line searches reject before they accept (instance 2300 of config 4's shard 2: 21 rejected trials in its first
+                    // six iterations; the ordinary acrobot instance rejects none before its fourth outer iteration). The measure is
+                    // the number of rejected trials in forward passes that ENDED IN AN ACCEPTANCE — a search that fails outright
+                    // ends its inner solve, and the instances that do nothing else (four per shard of config 4: ten outer iterations
+                    // of one failed search each) are no stragglers. A row whose count exceeds the batch's mean so far by
+                    // KArgs::pool_mark, at the head of an inner iteration and while most of the batch is still running, is marked: BOTH packs of its workgroup leave at their next resumable points
+                    // (as under the head-count rule) and the workgroup turns into a latency solver — two waves, LDS-resident state —
+                    // for the marked instance, then for whatever the device-wide queue holds (solve_kernel_packed below). The other
+                    // seven instances wait in that queue for the first workgroup whose packs are done. Which instances change
+                    // kernels never shows in a result (same arithmetic), so the rule may depend on timing.
+                    extern __shared__ __attribute__((aligned(16))) double pk_lds_[];
+                    volatile int* ctl = (volatile int*)(pk_lds_ + a.pool_ctl);
+                    const int rej = I.rej_acc & 0x3fffffff;             // (posted to the batch-wide sum where it grows: at the acceptance)
+                    bool leave = ctl[CTL_EVACUATE] != 0;
+                    if (a.pool_mark > 0 && 2 * done < a.B) {
+                        const int sum = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pool + POOL_REJECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        const bool mk = I.valid_row && I.state == ST_FORWARD && I.trial == 1 &&
+                                        (long long)rej * a.B - (long long)sum >= (long long)a.pool_mark * a.B;
+                        if (mk && !(I.rej_acc >> 30) && I.j == 0) atomicAdd(a.pool + POOL_BUSY, 1);     // a marked instance on its way (until it is finished)
+                        if (mk) I.rej_acc |= 1 << 30;
+                        if (__any(mk)) { if (I.lane == 0) ctl[CTL_EVACUATE] = 1; leave = true; }
+                    }
+                    if (leave) {                // the pack's instances count as gone for the head-count rule
+                        if (n_now > 0 && I.lane == 0) atomicAdd(a.done_counter, n_now);
+                        n_prev = 0; ho_now = true;
+                    }
+                }
+            }
         }
         // ------------------------------------------------ A: outer-loop transitions (src/solve.jl:105-126) and ilqr_solve! entry (:9-18)
         {
@@ -940,6 +986,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
                         pk_sync<M>(I);
                     }
                     if (acc) { I.states_eq_nominal = 1; I.status = 1; I.needB = 1; }
+                    if constexpr (PAIR) {
+                        if (acc && I.trial > 1) {
+                            I.rej_acc += I.trial - 1;
+                            if (a.pool != nullptr && I.j == 0) atomicAdd(a.pool + POOL_REJECTED, I.trial - 1);
+                        }
+                    }
                     if (go && !acc) { I.step_size *= 0.5; I.trial += 1; }                 // (:51)
                 }
                 // the loop ends without acceptance: the forward pass is over with status = false
@@ -1011,6 +1063,107 @@ __global__ __launch_bounds__(TWO ? 128 : 64, 2) void solve_kernel_packed(KArgs a
     }
     pk_sync<M>(I);
     if (live && I.j == 0) write_scalars();
+    resume_out = live ? resume : 0; marked_out = (I.rej_acc >> 30) != 0;
+}
+
+// The workgroup as a worker of the pool, once its two packs are through. A FUNCTION, and one that reads the launch's arguments
+// from the kernel-argument segment itself: inlined behind the state machine, the latency solver's needs (all of KArgs, to the end
+// of the kernel) changed that one's scalar register allocation — 28 kernel-argument reloads inside its cycle, three in the rollout
+// loop, +5 % on a shard; as a function with a KArgs reference it would read them through vector loads.
+template <class M>
+__device__ __forceinline__ void pool_worker(const unsigned long long kernarg, const int pack, const int resume, const int marked) {
+    // the kernel's one parameter lies at offset 0 of its argument segment; the address comes in a vector register pair (a function
+    // argument) and goes back to scalar ones, as a pointer to constant memory: scalar loads
+    typedef const __attribute__((address_space(4))) KArgs* kargs_p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)kernarg), hi = __builtin_amdgcn_readfirstlane((unsigned)(kernarg >> 32));
+    const KArgs a = *(const KArgs*)(kargs_p)(((unsigned long long)hi << 32) | lo);     // (a copy: loaded once, like a kernel's own arguments)
+    extern __shared__ __attribute__((aligned(16))) double pk_lds_[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, packs = (a.B + 3) / 4;
+    volatile int* ctl = (volatile int*)(pk_lds_ + a.pool_ctl);
+    // this wave's leavers: the block is complete in HBM (release), then the marked ones stay with the workgroup and the others
+    // go to the queue (entry = instance + 1; 0 = not written yet)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... while a marked instance is still on its way: the launch will last as long as that one does, and the others must not wait
+    // behind it. Otherwise they are left to the resume launch — the latency solver in a kernel of its own is some 10 % faster than
+    // here behind the state machine (register allocation), and with no straggler about the second launch starts when the packs end.
+    if ((lane & 15) == 0 && marked) atomicAdd(a.pool + POOL_MARKED, 1);
+    if ((lane & 15) == 0 && marked && resume == 0) atomicSub(a.pool + POOL_BUSY, 1);      // marked, and finished where it was
+    if ((lane & 15) == 0 && resume > 0) {
+        const int b = pack * 4 + (lane >> 4);
+        if (marked) ctl[CTL_OWN + wave * 4 + (lane >> 4)] = b;
+        else if (__hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+            const int i = atomicAdd(a.pool + POOL_TAIL, 1);
+            __hip_atomic_store(a.pool + POOL_Q + i, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) { const int mine = packs - blockIdx.x * 2; atomicAdd(a.pool + POOL_PACKS_DONE, mine < 2 ? mine : 2); }
+    // a worker's instructions go first where it shares a SIMD with a pack's wave (a marked straggler runs beside six of them, and
+    // the launch lasts as long as it does)
+    __builtin_amdgcn_s_setprio(3);
+    bool own = false;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int b = -1;
+            if (own) { atomicSub(a.pool + POOL_BUSY, 1); own = false; }                  // the marked instance of the last round is finished
+            for (int i = 0; i < 8; ++i) if (ctl[CTL_OWN + i] >= 0) { b = ctl[CTL_OWN + i]; ctl[CTL_OWN + i] = -1; own = true; break; }
+            while (b == -1) {
+                const int done = __hip_atomic_load(a.pool + POOL_PACKS_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // BEFORE the tail
+                const int head = __hip_atomic_load(a.pool + POOL_HEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int tail = __hip_atomic_load(a.pool + POOL_TAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (head < tail) {
+                    if (atomicCAS(a.pool + POOL_HEAD, head, head + 1) == head) {
+                        int e;
+                        while ((e = __hip_atomic_load(a.pool + POOL_Q + head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(8);
+                        b = e - 1;
+                    }
+                } else if (done >= packs || __hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) b = -2;
+                else __builtin_amdgcn_s_sleep(127);        // (no marked instance on its way: nothing more will be queued, see above)
+            }
+            ctl[CTL_NEXT] = b;
+        }
+        __syncthreads();
+        const int b = ctl[CTL_NEXT];
+        __syncthreads();
+        if (b < 0) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        solve_instance<M, true>(a, pk_lds_, b);
+        __syncthreads();
+    }
+}
+
+// Four instances per wave. TWO: one pack per workgroup, the second wave its helper. Otherwise (the one-wave form) TWO PACKS per
+// workgroup, one per wave, each on its own — and once both are through (every instance finished or handed over), the workgroup is
+// a WORKER of the device-wide pool: it takes handed-over instances from the queue in HBM and finishes each with the latency
+// kernel's code (solve_instance: two waves, LDS-resident state), until every pack of the launch is through and the queue is empty.
+// So a batch that fills the chip to the last register (8192 instances: 2048 waves of 256 VGPRs) still has somewhere for a
+// straggler to go — its own workgroup, the moment it is marked (packed_solve above) — and the survivors of the head-count rule
+// are finished without a second launch (a pending launch on another stream is not given the slots that free up: measured,
+// tools/probes/probe_evict.hip). The resume launch that follows on the stream finds nothing left to do; it stays as the net.
+template <class M, bool TWO = false>
+__global__ __launch_bounds__(128, 2) void solve_kernel_packed(KArgs a) {
+    using namespace pk;
+    extern __shared__ __attribute__((aligned(16))) double pk_lds_[];
+    int resume = 0;
+    bool marked = false;
+    if constexpr (TWO) {
+        if (threadIdx.x < 8) ((volatile int*)(pk_lds_ + PkLds<M, true>::MBOX))[threadIdx.x] = 0;
+        __syncthreads();
+        if (threadIdx.x >= 64) { pk_helper<M>(a); return; }
+        packed_solve_body<M, true, false>(a, blockIdx.x, 0, resume, marked);
+    } else {
+        constexpr int PACK = (PkLds<M, false>::total + 1) & ~1;
+        // (wave index through readfirstlane: the pack's base addresses stay in scalar registers)
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), packs = (a.B + 3) / 4, pack = blockIdx.x * 2 + wave;
+        volatile int* ctl = (volatile int*)(pk_lds_ + a.pool_ctl);
+        if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = threadIdx.x >= CTL_OWN ? -1 : 0;
+        __syncthreads();
+        if (pack < packs) packed_solve_body<M, false, true>(a, pack, wave * PACK, resume, marked);
+        if (a.pool == nullptr) return;
+        pool_worker<M>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(), pack, resume, marked ? 1 : 0);
+    }
 }
 
 }  // namespace ilqr

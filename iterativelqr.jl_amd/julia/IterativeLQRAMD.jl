@@ -14,7 +14,7 @@
 module IterativeLQRAMD
 
 export Options, Solver, Dynamics, Cost, Constraint, initialize_controls!, initialize_states!, initialize_rollout!,
-       set_parameters!, solve!, solve_shared_step!, get_trajectory, get_policy, stats, set_kernel_variant!, set_handover!, set_handover_live!, enable_trace!, trace
+       set_parameters!, solve!, solve_shared_step!, get_trajectory, get_policy, stats, set_kernel_variant!, set_handover!, set_handover_live!, set_handover_mark!, enable_trace!, trace
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "lib", "libilqr_hip.so"))
 
@@ -374,6 +374,7 @@ set_kernel_variant!(s::Solver, v::Integer) = check(ccall((:ilqr_set_kernel_varia
 # live = survivors of the batch at which they all leave (-1 auto)
 set_handover!(s::Solver, outer::Integer) = check(ccall((:ilqr_set_handover, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, outer))
 set_handover_live!(s::Solver, live::Integer) = check(ccall((:ilqr_set_handover_live, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, live))
+set_handover_mark!(s::Solver, rejected::Integer) = check(ccall((:ilqr_set_handover_mark, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, rejected))
 
 # what `verbose` prints per inner iteration (src/solve.jl:40-45), recorded on the device: rows of
 # (outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts) per instance

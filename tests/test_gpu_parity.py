@@ -1462,6 +1462,48 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
             assert np.array_equal(off[k], on[k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("config,B,offset,live,mark", [("acrobot", 61, 2 * 8192 + 2290, 40, 1), ("acrobot", 61, 2 * 8192 + 2290, 40, 8),
+                                                       ("acrobot51", 45, 0, 30, 1), ("car", 37, 0, 20, 1), ("acrobot", 9, 6 * 8192 + 7605, 2, 8)])
+def test_one_wave_packed_form_finishes_its_hand_overs_itself(pkg, config, B, offset, live, mark):
+    """The one-wave form of the packed kernel (two packs per workgroup): a workgroup whose packs are through takes handed-over
+    instances from the device-wide queue and finishes them with the latency kernel's code; an instance whose rejected line-search
+    trials exceed the batch's mean by `mark` (ilqr_set_handover_mark) is marked, its workgroup's two packs leave at once and the
+    workgroup finishes the marked instance first. Batches around the two stragglers of BASELINE config 4 (instance 2300 of shard 2,
+    7609 of shard 6) and ordinary ones with the mark at one rejected trial (many marks). WHO leaves, and when, depends on the
+    timing of the run: every count, trace row and array must be the latency kernel's, bitwise, run after run, and nothing may be
+    left for the launch behind (resume = 0 everywhere)."""
+    model, T, x1, ub = pkg.workloads.make_inputs(config, B, offset=offset)
+
+    def run(variant, on=True):
+        s = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(config, {})))
+        s.set_kernel_variant_(variant); s.enable_trace_(1000)
+        if variant != "latency":
+            s.set_handover_(-1 if on else 0); s.set_handover_live_(live); s.set_handover_mark_(mark)
+        s.initialize_rollout_(x1, ub); s.solve_()
+        out = dict(x=s.get_trajectory()[0], u=s.get_trajectory()[1], K=s.get_policy()[0], k=s.get_policy()[1], st=s.stats(),
+                   tl=s.scalar("trace_len"), tr=s.trace(), resume=s.scalar("resume"), lam=s.buffer("constraint_dual"),
+                   fx=s.buffer("jacobian_state"), gxx=s.buffer("hessian_state_state"), delta=s.scalar("delta_grad_product"),
+                   ho=s.handover_stats() if variant != "latency" else (0, 0))
+        s.close()
+        return out
+    ref = run("latency")
+    marked = 0
+    for rep in range(3):
+        on = run("packed1")
+        assert (on["resume"] == 0).all()
+        marked += on["ho"][1]
+        for k in ("iterations", "outer_iterations", "rollouts", "status", "potrf_info", "objective", "max_violation", "gradient_norm", "step_size"):
+            assert np.array_equal(ref["st"][k], on["st"][k], equal_nan=True), k
+        assert np.array_equal(ref["tl"], on["tl"])
+        assert np.array_equal(ref["tr"], on["tr"], equal_nan=True)
+        for k in ("x", "u", "K", "k", "lam", "fx", "gxx", "delta"):
+            assert np.array_equal(ref[k], on[k], equal_nan=True), k
+    assert marked > 0 or config in ("car", "acrobot51")           # the straggler batches do mark
+    off = run("packed1", on=False)
+    for k in ("x", "u", "K", "lam"):
+        assert np.array_equal(ref[k], off[k], equal_nan=True), k
+
+
 def test_packed_kernel_extra_trials_for_an_instance_that_keeps_rejecting(pkg):
     """The packed kernel gives an instance with eight rejected line-search trials behind it up to three more trials within the
     cycle (ilqr_device_packed.hpp, ILQR_PK_TRIALS / ILQR_PK_REJECTS). Instance 2300 of shard 2 of BASELINE config 4 spends 1407

@@ -19,6 +19,8 @@ for r in shards:
         sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(cfg, {})))
         if m.startswith("L"):            # L<live>
             sol.set_handover_(-1); sol.set_handover_live_(int(m[1:]))
+        elif m.startswith("M"):          # M<mark>: by head count, stragglers marked at <mark> rejected trials above the batch's mean (0 = never)
+            sol.set_handover_(-1); sol.set_handover_mark_(int(m[1:]))
         else:
             sol.set_handover_(int(m))
         for _ in range(2):
@@ -30,8 +32,8 @@ for r in shards:
         same = (st["iterations"] == ref[0]["iterations"]).mean()
         dx = np.nanmax(np.abs(x - ref[1])[st["iterations"] == ref[0]["iterations"]])
         res[m].append(ms)
-        print("shard %d handover %5s: kernel %7.2f ms  iterations mean %.1f max %d  vs first mode: same control flow %.4f max|dx| %.1e"
-              % (r, m, ms, st["iterations"].mean(), st["iterations"].max(), same, dx), flush=True)
+        print("shard %d handover %5s: kernel %7.2f ms  iterations mean %.1f max %d  vs first mode: same control flow %.4f max|dx| %.1e; through the queue %d, marked %d"
+              % ((r, m, ms, st["iterations"].mean(), st["iterations"].max(), same, dx) + sol.handover_stats()), flush=True)
         sol.close()
 for m in modes:
     a = np.array(res[m])
