@@ -143,7 +143,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.qv = h->qv; a.QL = h->QL;
     a.stage_param = 0.0; a.stage_flag = 0;
     a.handover_outer = 0; a.resume = 0; a.handover_live = 0; a.done_counter = h->done_counter;
-    a.pool = nullptr; a.pool_mark = 0; a.pool_lds = 0; a.pool_ctl = 0;
+    a.pool = nullptr; a.pool_mark = 0; a.pool_lds = 0; a.pool_ctl = 0; a.pool_cu = 0;
     return a;
 }
 
@@ -939,7 +939,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     h->ws_bytes = (size_t)h->B * (size_t)h->L.stride * 8;
     if ((e = hipMalloc((void**)&h->ws, h->ws_bytes)) != hipSuccess) return bail(e, "hipMalloc(workspace)");
     if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->done_counter, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(hand-over counter)");
-    if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->pool, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B))) != hipSuccess) return bail(e, "hipMalloc(hand-over queue)");
+    if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->pool, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B + ilqr::POOL_CUS))) != hipSuccess) return bail(e, "hipMalloc(hand-over queue)");
     if ((e = hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     *out = h;
     int rc = ilqr_reset(h);
@@ -1180,7 +1180,8 @@ int ilqr_solve(ilqr_handle* h) {
         // the one-wave form's workgroups finish the instances handed over themselves (ilqr_device_packed.hpp: solve_kernel_packed);
         // under the head-count rule an instance whose rejected line-search trials exceed the batch's mean by `mark` leaves at once
         if ((ho > 0 || live > 0) && h->pool != nullptr) {
-            HIP_TRY(hipMemsetAsync(h->pool, 0, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B), h->stream));
+            HIP_TRY(hipMemsetAsync(h->pool, 0, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B + ilqr::POOL_CUS), h->stream));
+            a.pool_cu = 1;       // a marked straggler gets its CU to itself (config 4, shard 6: 126.6 -> 118.0 ms)
             a.pool = h->pool; a.pool_lds = (int)h->lds_bytes;
             a.pool_mark = live > 0 ? (h->handover_mark < 0 ? 6 : h->handover_mark) : 0;
         }

@@ -65,9 +65,9 @@ struct KArgs {
     // solve_kernel_packed). pool: queue words in HBM (null = hand-overs wait for the resume launch); pool_mark: rejected line-search
     // trials above the batch's mean at which an instance is marked a straggler and leaves at once (0 = never); pool_lds: bytes of
     // LDS solve_instance needs (the launcher drops the pool where that would cost the packed kernel residency); pool_ctl: where the
-    // workgroup's control words lie in LDS (set by the launcher).
+    // workgroup's control words lie in LDS (set by the launcher); pool_cu: every pack on a marked straggler's CU leaves with it.
     int* pool;
-    int pool_mark, pool_lds, pool_ctl;
+    int pool_mark, pool_lds, pool_ctl, pool_cu;
 };
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 

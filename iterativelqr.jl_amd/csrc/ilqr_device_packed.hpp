@@ -782,9 +782,45 @@ __device__ void pk_helper(const KArgs& a) {
 }  // namespace pk
 
 // words of KArgs::pool (ints in HBM, zeroed by the host before every launch): the device-wide queue of handed-over instances
-enum { POOL_TAIL = 0, POOL_HEAD = 1, POOL_PACKS_DONE = 2, POOL_REJECTED = 3, POOL_MARKED = 4, POOL_BUSY = 5, POOL_Q = 8 };
+enum { POOL_TAIL = 0, POOL_HEAD = 1, POOL_PACKS_DONE = 2, POOL_REJECTED = 3, POOL_MARKED = 4, POOL_BUSY = 5, POOL_FINISHED = 6, POOL_Q = 8 };
 // control words of a one-wave-form workgroup (ints in LDS behind everything else, KArgs::pool_ctl doubles from the base)
-enum { CTL_EVACUATE = 0, CTL_NEXT = 1, CTL_OWN = 8, CTL_WORDS = 16 };
+enum { CTL_EVACUATE = 0, CTL_NEXT = 1, CTL_QUIET = 2, CTL_OWN = 8, CTL_WORDS = 16 };
+enum { POOL_CUS = 2048 };      // per-CU words behind the queue (KArgs::pool + POOL_Q + B): a marked straggler's CU is vacated
+// (xcc, se, sh, cu) of the executing wave in 11 bits (HW_ID: cu 11:8, sh 12, se 15:13; tools/probes/probe_evict.hip: 256 distinct
+// ids on an MI355X, eight one-wave-form waves under each)
+__device__ __forceinline__ int cu_id() {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return (int)(((xcc & 15u) << 7) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u));
+}
+
+// The straggler mark's step at the head of every fourth cycle (packed_solve_body): a FUNCTION, out of line — inlined, its few
+// registers and its 64-bit arithmetic changed the allocation of the rollout loop a screen further down (+3 % on an ordinary shard).
+// Returns bit 0: this pack leaves; bit 1: this row's instance is marked.
+__attribute__((noinline)) __device__ int pool_mark_step(int* pool, volatile int* ctl, int B, int mark, int cu_mode, int done, int rej_acc,
+                                                        bool at_head, int j, int lane) {
+    const int rej = rej_acc & 0x3fffffff;                   // (posted to the batch-wide sum where it grows: at the acceptance)
+    bool leave = ctl[CTL_EVACUATE] != 0, mine = false;
+    int* const cu_word = pool + POOL_Q + B + cu_id();
+    if (cu_mode && !leave && __builtin_amdgcn_readfirstlane(__hip_atomic_load(cu_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+        // a straggler was marked on this CU: every pack of the CU leaves, and these workgroups keep quiet until no marked instance
+        // is on its way (it has the CU — its SIMDs, LDS, instruction cache — to itself)
+        if (lane == 0) { ctl[CTL_EVACUATE] = 1; ctl[CTL_QUIET] = 1; }
+        leave = true;
+    }
+    if (mark > 0 && 2 * done < B) {
+        const int sum = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pool + POOL_REJECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const bool mk = at_head && (long long)rej * B - (long long)sum >= (long long)mark * B;
+        if (mk && !(rej_acc >> 30) && j == 0) atomicAdd(pool + POOL_BUSY, 1);           // a marked instance on its way (until it is finished)
+        mine = mk;
+        if (__any(mk)) {
+            if (lane == 0) { ctl[CTL_EVACUATE] = 1; if (cu_mode) __hip_atomic_store(cu_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            leave = true;
+        }
+    }
+    return (leave ? 1 : 0) | (mine ? 2 : 0);
+}
 
 // solve!(solver) for the four instances of pack `pack` — src/solve.jl:1-54, 88-143 as a per-instance state machine. TWO: the
 // workgroup's second wave serves linearisations and trial costs (pk_helper); PAIR: the workgroup's other wave runs a pack of its
@@ -876,17 +912,10 @@ __device__ __forceinline__ void packed_solve_body(const KArgs& a, const int pack
                     // seven instances wait in that queue for the first workgroup whose packs are done. Which instances change
                     // kernels never shows in a result (same arithmetic), so the rule may depend on timing.
                     extern __shared__ __attribute__((aligned(16))) double pk_lds_[];
-                    volatile int* ctl = (volatile int*)(pk_lds_ + a.pool_ctl);
-                    const int rej = I.rej_acc & 0x3fffffff;             // (posted to the batch-wide sum where it grows: at the acceptance)
-                    bool leave = ctl[CTL_EVACUATE] != 0;
-                    if (a.pool_mark > 0 && 2 * done < a.B) {
-                        const int sum = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pool + POOL_REJECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        const bool mk = I.valid_row && I.state == ST_FORWARD && I.trial == 1 &&
-                                        (long long)rej * a.B - (long long)sum >= (long long)a.pool_mark * a.B;
-                        if (mk && !(I.rej_acc >> 30) && I.j == 0) atomicAdd(a.pool + POOL_BUSY, 1);     // a marked instance on its way (until it is finished)
-                        if (mk) I.rej_acc |= 1 << 30;
-                        if (__any(mk)) { if (I.lane == 0) ctl[CTL_EVACUATE] = 1; leave = true; }
-                    }
+                    const int f = pool_mark_step(a.pool, (volatile int*)(pk_lds_ + a.pool_ctl), a.B, a.pool_mark, a.pool_cu, done, I.rej_acc,
+                                                 I.valid_row && I.state == ST_FORWARD && I.trial == 1, I.j, I.lane);
+                    if (f & 2) I.rej_acc |= 1 << 30;
+                    const bool leave = (f & 1) != 0;
                     if (leave) {                // the pack's instances count as gone for the head-count rule
                         if (n_now > 0 && I.lane == 0) atomicAdd(a.done_counter, n_now);
                         n_prev = 0; ho_now = true;
@@ -1092,7 +1121,9 @@ __device__ __forceinline__ void pool_worker(const unsigned long long kernarg, co
     if ((lane & 15) == 0 && resume > 0) {
         const int b = pack * 4 + (lane >> 4);
         if (marked) ctl[CTL_OWN + wave * 4 + (lane >> 4)] = b;
-        else if (__hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+        else if (__hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 ||
+                 __hip_atomic_load(a.pool + POOL_TAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
+                 __hip_atomic_load(a.pool + POOL_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {      // (or queued work is still being done)
             const int i = atomicAdd(a.pool + POOL_TAIL, 1);
             __hip_atomic_store(a.pool + POOL_Q + i, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1103,21 +1134,28 @@ __device__ __forceinline__ void pool_worker(const unsigned long long kernarg, co
     // a worker's instructions go first where it shares a SIMD with a pack's wave (a marked straggler runs beside six of them, and
     // the launch lasts as long as it does)
     __builtin_amdgcn_s_setprio(3);
-    bool own = false;
+    bool own = false, queued = false, quiet = false;
+    if (threadIdx.x == 0) {        // vacated for another workgroup's straggler: nothing to do here until the packs of the launch are through
+        quiet = ctl[CTL_QUIET] != 0;
+        for (int i = 0; i < 8; ++i) if (ctl[CTL_OWN + i] >= 0) quiet = false;
+    }
     for (;;) {
         if (threadIdx.x == 0) {
             int b = -1;
             if (own) { atomicSub(a.pool + POOL_BUSY, 1); own = false; }                  // the marked instance of the last round is finished
+            else if (queued) atomicAdd(a.pool + POOL_FINISHED, 1);
+            queued = false;
             for (int i = 0; i < 8; ++i) if (ctl[CTL_OWN + i] >= 0) { b = ctl[CTL_OWN + i]; ctl[CTL_OWN + i] = -1; own = true; break; }
             while (b == -1) {
                 const int done = __hip_atomic_load(a.pool + POOL_PACKS_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // BEFORE the tail
+                if (quiet && done < packs && __hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) { __builtin_amdgcn_s_sleep(127); continue; }
                 const int head = __hip_atomic_load(a.pool + POOL_HEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int tail = __hip_atomic_load(a.pool + POOL_TAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (head < tail) {
                     if (atomicCAS(a.pool + POOL_HEAD, head, head + 1) == head) {
                         int e;
                         while ((e = __hip_atomic_load(a.pool + POOL_Q + head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(8);
-                        b = e - 1;
+                        b = e - 1; queued = true;
                     }
                 } else if (done >= packs || __hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) b = -2;
                 else __builtin_amdgcn_s_sleep(127);        // (no marked instance on its way: nothing more will be queued, see above)
