@@ -21,6 +21,7 @@ for cfg, B, sample in (("acrobot", 8192, nsample), ("synth32", 512, 512)):
         for _ in range(2):
             sol.reset_(); sol.initialize_rollout_(x1, ub); sol.timing_reset(); sol.solve_()
         ms, _ = sol.timing()
+        hq, hm = sol.handover_stats()
         x, u = sol.get_trajectory(); K, k = sol.get_policy(); st = sol.stats()
         idx = np.arange(B) if sample >= B else np.unique(np.r_[np.argsort(st["iterations"])[-8:], np.linspace(0, B - 1, sample).astype(int)])
         ref = oracle.solve_batch(model, T, x1[idx], ub[idx], nthreads=threads)
@@ -54,7 +55,7 @@ for cfg, B, sample in (("acrobot", 8192, nsample), ("synth32", 512, 512)):
             prop = "; max_violation <= 5e-3 on %.2f%%" % (100 * (st["max_violation"] <= 5e-3).mean())
         print("shard %d: kernel %7.2f ms (%s), iterations mean %.1f max %d%s; oracle sample %d: control flow identical "
               "%.2f%% (non-finite instances identical: %s), max|dx| %.1e max|du| %.1e max|dK|/max|K| %.1e on the regular sample%s"
-              % (r, ms, "auto variant", st["iterations"].mean(), st["iterations"].max(), prop,
+              % (r, ms, "auto variant; %d instances marked as stragglers, %d through the workgroups' queue" % (hm, hq) if cfg == "acrobot" else "auto variant", st["iterations"].mean(), st["iterations"].max(), prop,
                  len(idx), 100 * same.mean(), nanflow, dx, du, dK, slow_txt))
         worst_ms = max(worst_ms, ms); tot_it += st["iterations"].sum()
         sol.close()
