@@ -32,7 +32,7 @@ for r in shards:
     q, m = sol.handover_stats()
     print("== shard %d: kernel %.1f ms (through the queue %d, marked %d); iterations mean %.1f max %d; rejected trials per instance mean %.1f, failed searches excluded %.1f"
           % (r, ms, q, m, it.mean(), it.max(), (ro - it).mean(), acc[np.arange(B), np.maximum(ln - 1, 0)].mean()))
-    for K in (4, 6, 8):
+    for K in (6, 8):
         hit = at - mean[None, :] >= K
         first = np.where(hit.any(1), hit.argmax(1), -1)
         print("  mark at %d above the mean: %d instances" % (K, (first >= 0).sum()))
