@@ -1624,8 +1624,11 @@ __device__ __forceinline__ void gradients(Inst<M>& I, bool constrained) {
     if constexpr (is_large<M>::value) gradients_large<M>(I, constrained);
     else gradients_small<M>(I, constrained);
 }
+// (pair: the two-wave kernels' second wave, idle in a rollout, runs the NEXT trial of the line search — step size alpha / 2 — into
+// the buffers x2, u2 at the same time; forward_pass<M, true>)
 template <class M>
-__device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
+__device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out, bool pair = false,
+                                             double* x2 = nullptr, double* u2 = nullptr) {
     if constexpr (is_large<M>::value) rollout_large<M>(I, alpha, with_delta, delta_out);
     else {
         ILQR_PROF_BEGIN();
@@ -1633,9 +1636,12 @@ __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with
             rollout_small<M>(I, alpha, with_delta, delta_out);
             __syncthreads();
         } else {
-            if (I.wave == 0) {
+            if (I.wave == 0 || pair) {
                 double unused = 0.0;
-                rollout_small<M>(I, alpha, false, unused);
+                double* const xs = I.x; double* const us = I.u;
+                if (pair && I.wave == 1) { I.x = x2; I.u = u2; }
+                rollout_small<M>(I, (pair && I.wave == 1) ? 0.5 * alpha : alpha, false, unused);
+                I.x = xs; I.u = us;
             } else if (with_delta && !I.delta_next_ok) {                // stage kernels: the backward pass was another launch
                 const double d = delta_small<M>(I);
                 if (I.lane == 0) I.zs[4] = d;
@@ -1650,10 +1656,21 @@ __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with
 }
 
 // --------------------------------------------------------- forward_pass!
-template <class M>
+// SPEC (two-wave small models; 1: from the second trial on — the resume launch; 2: from the first — the packed kernel's workers, whose
+// instances are the ones that reject; 0: the latency kernel, where 97 % of the first trials are accepted and pairs measured no
+// gain): the line search takes its trials in PAIRS —
+// wave 0 rolls out step size s, wave 1 at the same time s / 2 into the LDS of the cost gradients gx, gu (same sizes as x, u; dead
+// between the backward pass and the next gradients!, which rewrites them; saved to their HBM home before the first pair and
+// brought back if the whole search fails, the one case in which nothing rewrites them). Trial by trial the search then does what
+// it always did — cost!, the Armijo test, the counters, problem.states = the last trial evaluated — only that the second trial
+// of a pair is already rolled out when the first is rejected: a rejected trial is a rollout and a cost pass, 40 us of an
+// iteration's 50, and the stragglers of a batch are the instances that reject (instance 7609 of config 4's shard 6: 1914
+// rollouts for 917 iterations). Same arithmetic on the same inputs in the same order per trial: results bitwise unchanged.
+template <class M, int SPEC = 0>
 __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrained) {
     constexpr int n = M::NX, m = M::NU;
     constexpr bool MF = true;       // Δ rides along the first rollout on both paths (small: MFMAs beside the VALU chain; large: wave 1)
+    constexpr bool SP = SPEC != 0 && !is_large<M>::value && waves_of<M>::value == 2;
     const double c1 = 1.0e-4;
     const int max_iterations = 25;
     I.status = 0;                                                     // (:10)
@@ -1665,28 +1682,75 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     I.delta = 0.0;
     I.step_size = 1.0;                                                // (:26)
     int iteration = 1;
+    bool saved = false, last_on_2 = false;
+    double* const x2 = I.gx; double* const u2 = I.gu;
+    double* const hx = I.gbase + (I.gx - I.lds); double* const hu = I.gbase + (I.gu - I.lds);     // their HBM home (stale during a launch)
+    auto accept = [&](const double* X, const double* U) {
+        // update_nominal_trajectory! (src/data/methods.jl:32-39)
+        constexpr int CS = is_large<M>::value ? 64 * waves_of<M>::value : 64;     // large path: HBM arrays, each element once
+        const int c0 = is_large<M>::value ? (int)threadIdx.x : I.lane;
+        for (int i = c0; i < I.T * n; i += CS) I.xb[i] = X[i];
+        for (int i = c0; i < I.N * m; i += CS) I.ub[i] = U[i];
+        I.states_eq_nominal = 1;
+        I.status = 1;
+    };
     while (I.step_size >= opt.min_step_size) {                        // (:28)
         if (iteration > max_iterations) break;                        // (:29)
         const bool want_delta = MF && iteration == 1 && opt.line_search == 1;
+        bool pair = false;
+        if constexpr (SP) pair = iteration >= (SPEC == 2 ? 1 : 2) && (!want_delta || I.delta_next_ok) && 0.5 * I.step_size >= opt.min_step_size && iteration + 1 <= max_iterations;
+        if constexpr (SP) {
+            if (pair && !saved) {
+                if (I.wave == 1) {
+                    for (int i = I.lane; i < I.T * n; i += 64) hx[i] = x2[i];
+                    for (int i = I.lane; i < I.N * m; i += 64) hu[i] = u2[i];
+                }
+                saved = true;
+            }
+        }
         double d = 0.0;
-        rollout_bang<M>(I, I.step_size, want_delta, d);               // (:34)
+        rollout_bang<M>(I, I.step_size, want_delta, d, pair, x2, u2);  // (:34)
         if (want_delta) { delta = d; I.delta = d; }
         cost_bang<M>(I, true, constrained);                           // (:36)
-        const double J = I.objective;
-        if (J <= J_prev + c1 * I.step_size * delta) {                 // (:44) NaN ⇒ reject
-            // update_nominal_trajectory! (src/data/methods.jl:32-39)
-            constexpr int CS = is_large<M>::value ? 64 * waves_of<M>::value : 64;     // large path: HBM arrays, each element once
-            const int c0 = is_large<M>::value ? (int)threadIdx.x : I.lane;
-            for (int i = c0; i < I.T * n; i += CS) I.xb[i] = I.x[i];
-            for (int i = c0; i < I.N * m; i += CS) I.ub[i] = I.u[i];
-            I.states_eq_nominal = 1;
-            I.status = 1;
+        last_on_2 = false;
+        if (I.objective <= J_prev + c1 * I.step_size * delta) {       // (:44) NaN ⇒ reject
+            accept(I.x, I.u);
             __syncthreads();
             break;
-        } else {
-            I.step_size *= 0.5;                                       // (:51)
-            iteration += 1;
         }
+        I.step_size *= 0.5;                                           // (:51)
+        iteration += 1;
+        if constexpr (SP) {
+            if (pair) {                                               // the pair's second trial: rolled out already
+                I.rollouts += 1;
+                double* const xs = I.x; double* const us = I.u;
+                I.x = x2; I.u = u2;
+                cost_bang<M>(I, true, constrained);
+                I.x = xs; I.u = us;
+                last_on_2 = true;
+                if (I.objective <= J_prev + c1 * I.step_size * delta) {
+                    accept(x2, u2);
+                    break;
+                }
+                I.step_size *= 0.5;
+                iteration += 1;
+            }
+        }
+    }
+    if constexpr (SP) {
+        if (last_on_2) {              // problem.states, problem.actions = the last trial evaluated (Q2 reads them)
+            __syncthreads();
+            for (int i = I.lane + 64 * I.wave; i < I.T * n; i += 128) I.x[i] = x2[i];
+            for (int i = I.lane + 64 * I.wave; i < I.N * m; i += 128) I.u[i] = u2[i];
+        }
+        if (saved && (!I.status || opt.line_search == 0)) {     // no gradients! will rewrite gx, gu: bring them back
+            __syncthreads();
+            if (I.wave == 1) {
+                for (int i = I.lane; i < I.T * n; i += 64) x2[i] = hx[i];
+                for (int i = I.lane; i < I.N * m; i += 64) u2[i] = hu[i];
+            }
+        }
+        if (saved || last_on_2) __syncthreads();
     }
 }
 
@@ -1751,7 +1815,7 @@ __device__ void al_update(Inst<M>& I, const ilqr_options& opt) {
 // (linearise, Riccati, line search) is instantiated exactly once.
 //   al_outer = true : AL outer loop (Solver with constraints)
 //   al_outer = false: a single ilqr_solve! (plain Objective, or the stage test)
-template <class M, bool STORE_VALUE>
+template <class M, bool STORE_VALUE, int SPEC = 0>
 __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constrained, bool al_outer, int o_start = 1, int it_start = 0,
                             double obj_prev0 = 0.0) {
     if (al_outer && o_start == 1 && it_start == 0) {
@@ -1780,7 +1844,7 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
         double obj_prev = mid ? obj_prev0 : 0.0;
         for (int it = mid ? it_start : 0; it <= opt.max_iterations; ++it) {     // it = 0: (:14-21); it ≥ 1: (:22-51)
             if (it == 0) cost_bang<M>(I, false, constrained);         // (:14)
-            else forward_pass<M>(I, opt, constrained);                // (:23)
+            else forward_pass<M, SPEC>(I, opt, constrained);          // (:23)
             if (it == 0 || opt.line_search != 0) {                    // (:16-18), (:27-33)
                 gradients<M>(I, constrained);
                 backward_pass<M, STORE_VALUE>(I);
@@ -1889,8 +1953,14 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
     }
 }
 
+#ifndef ILQR_SPEC_LATENCY
+#define ILQR_SPEC_LATENCY 0         // line-search trials in pairs (forward_pass<M, 1 | 2>: from the second / first trial on) in the latency kernel ...
+#endif
+#ifndef ILQR_SPEC_RESUME
+#define ILQR_SPEC_RESUME 1          // ... and in the resume launch
+#endif
 // one instance from its workspace block to the end of solve!: from the start, or (resumed) from where the packed kernel left it
-template <class M, bool RESUMED>
+template <class M, bool RESUMED, int SPEC = 0>
 __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int b) {
     constexpr bool resumed = RESUMED;
     int o_start = 1, it_start = 0;
@@ -1914,7 +1984,7 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
     }
     {
         ILQR_PROF_BEGIN();
-        solve_loops<M, false>(I, a.opt, a.constrained != 0, a.constrained != 0, o_start, it_start, obj_prev0);
+        solve_loops<M, false, SPEC>(I, a.opt, a.constrained != 0, a.constrained != 0, o_start, it_start, obj_prev0);
         ILQR_PROF_END(I, PROF_OTHER);   // total; phases are subtracted on the host
     }
     if (I.lane == 0 && I.wave == 0) {
@@ -1930,7 +2000,7 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel(KArgs
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
-    solve_instance<M, false>(a, smem, b);
+    solve_instance<M, false, ILQR_SPEC_LATENCY>(a, smem, b);
 }
 
 // The same for the instances the packed kernel handed over, in the launch that follows it on the stream: workgroup b finishes
@@ -1942,7 +2012,7 @@ __global__ __launch_bounds__(64 * waves_of<M>::value, 2) void solve_kernel_resum
     const int b = blockIdx.x;
     if (b >= a.B) return;
     if ((int)(a.ws + (size_t)b * (size_t)a.L.stride)[a.L.scal + S_RESUME] < 1) return;
-    solve_instance<M, true>(a, smem, b);
+    solve_instance<M, true, ILQR_SPEC_RESUME>(a, smem, b);
 }
 
 // throughput variant: two waves per SIMD (<= 256 registers), Jacobians in HBM (see Slim<M>)

@@ -785,6 +785,9 @@ __device__ void pk_helper(const KArgs& a) {
 enum { POOL_TAIL = 0, POOL_HEAD = 1, POOL_PACKS_DONE = 2, POOL_REJECTED = 3, POOL_MARKED = 4, POOL_BUSY = 5, POOL_FINISHED = 6, POOL_Q = 8 };
 // control words of a one-wave-form workgroup (ints in LDS behind everything else, KArgs::pool_ctl doubles from the base)
 enum { CTL_EVACUATE = 0, CTL_NEXT = 1, CTL_QUIET = 2, CTL_OWN = 8, CTL_WORDS = 16 };
+#ifndef ILQR_SPEC_WORKER
+#define ILQR_SPEC_WORKER 2
+#endif
 enum { POOL_CUS = 2048 };      // per-CU words behind the queue (KArgs::pool + POOL_Q + B): a marked straggler's CU is vacated
 // (xcc, se, sh, cu) of the executing wave in 11 bits (HW_ID: cu 11:8, sh 12, se 15:13; tools/probes/probe_evict.hip: 256 distinct
 // ids on an MI355X, eight one-wave-form waves under each)
@@ -1167,7 +1170,7 @@ __device__ __forceinline__ void pool_worker(const unsigned long long kernarg, co
         __syncthreads();
         if (b < 0) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        solve_instance<M, true>(a, pk_lds_, b);
+        solve_instance<M, true, ILQR_SPEC_WORKER>(a, pk_lds_, b);   // (line-search trials in pairs: forward_pass<M, SPEC>)
         __syncthreads();
     }
 }

@@ -272,7 +272,8 @@ def test_compile_model_stages_composes_the_template_from_c_sources_per_kind(tmp_
     S = plan.n_selectors
     rows = np.array([sel[i] for i in range(T * S)]).reshape(T, S)
     assert (rows[:-1].sum(axis=1) == 2).all() and (rows[-1] == 0).all()
-    assert os.path.exists(path.value.decode()) and L.ilqr_model_name(L.ilqr_model_count() - 1) == reg.value
+    # registered under its name (not necessarily last: a module the process has loaded before is registered once)
+    assert os.path.exists(path.value.decode()) and reg.value in [L.ilqr_model_name(i) for i in range(L.ilqr_model_count())]
     # the same objects through the symbolic lowering give the same plan
     dynamics, costs, constraints, _, _ = pkg.models.ragged(T)
     low = pkg.lowering.lower(dynamics, costs, constraints)
