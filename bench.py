@@ -452,6 +452,12 @@ def worker(args, solver_factory=None):
     }
     if secondary:
         out["secondary"] = secondary
+    if not stub and not sharded:
+        try:       # one-wave form of the packed kernel: what its workgroups did with the stragglers of this rank's last solve
+            q_, m_ = sol.handover_stats()
+            out["solve_stats"]["handover"] = {"marked_as_stragglers": m_, "through_the_workgroups_queue": q_}
+        except Exception:
+            pass
     if not stub:
         n_, m_ = sol.nx, sol.nu
         io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))     # per device

@@ -375,6 +375,11 @@ set_kernel_variant!(s::Solver, v::Integer) = check(ccall((:ilqr_set_kernel_varia
 set_handover!(s::Solver, outer::Integer) = check(ccall((:ilqr_set_handover, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, outer))
 set_handover_live!(s::Solver, live::Integer) = check(ccall((:ilqr_set_handover_live, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, live))
 set_handover_mark!(s::Solver, rejected::Integer) = check(ccall((:ilqr_set_handover_mark, LIB[]), Cint, (Ptr{Cvoid}, Int32), s.handle, rejected))
+function handover_stats(s::Solver)      # (instances through the workgroups' queue, instances marked as stragglers) of the last solve!
+    q = Ref{Int32}(0); m = Ref{Int32}(0)
+    check(ccall((:ilqr_get_handover_stats, LIB[]), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}), s.handle, q, m))
+    return (queued = Int(q[]), marked = Int(m[]))
+end
 
 # what `verbose` prints per inner iteration (src/solve.jl:40-45), recorded on the device: rows of
 # (outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts) per instance
