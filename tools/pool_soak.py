@@ -1,0 +1,43 @@
+"""Soak of the packed kernel's one-wave form as its own pool (two packs per workgroup, workgroups finishing hand-overs, stragglers
+marked and leaving at once, line-search trials in pairs): random models, batch sizes, horizons, iteration caps, head counts and
+marks; each solve compared bitwise with the latency kernel — trajectories, policies, duals, counters, objective, the cost gradients
+and problem.states (what the paired trials use as their second buffer / must leave as the last trial evaluated) — and nothing may
+be left for the launch behind. A lost wake-up would hang the launch: run under `timeout`.   python tools/pool_soak.py [rounds]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ilqr_amd_loader import load_package
+pkg = load_package()
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(11)
+bad = 0
+for r in range(rounds):
+    cfg = ["car", "acrobot51", "particle", "car_goal", "acrobot", "car_obs"][r % 6]
+    B = int(rng.integers(1, 700)) if r % 7 else int(rng.integers(2049, 2600))     # now and then more workgroups than CUs
+    off = int(rng.integers(0, 60000))
+    model, T0, x1, ub = pkg.workloads.make_inputs(cfg, B, offset=off)
+    T = int(rng.integers(2, T0 + 1)) if r % 3 == 0 else T0
+    ub = ub[:, :T - 1]
+    w = pkg.workloads.make_parameters(cfg, B, offset=off)[:, :T] if cfg == "car_obs" else None
+    live = int(rng.integers(1, B + 1)); mark = [1, 2, 6, 0][r % 4]
+    max_it = int(rng.integers(1, 40)) if r % 5 == 0 else 100
+    res = {}
+    for v in ("latency", "packed1"):
+        s = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, max_iterations=max_it))
+        s.set_kernel_variant_(v)
+        if v == "packed1":
+            s.set_handover_(-1); s.set_handover_live_(live); s.set_handover_mark_(mark)
+        if w is not None: s.set_parameters_(w)
+        s.initialize_rollout_(x1, ub); s.solve_()
+        st = s.stats()
+        res[v] = (s.get_trajectory()[0], s.get_trajectory()[1], s.get_policy()[0], s.get_policy()[1], s.buffer("constraint_dual"), st["iterations"], st["rollouts"],
+                  st["objective"], st["max_violation"], s.buffer("gradient_state"), s.buffer("gradient_action"), s.buffer("states"), s.buffer("actions"),
+                  s.buffer("jacobian_state"), s.buffer("hessian_state_state"))
+        ho = s.handover_stats() if v == "packed1" else None
+        left = int((s.scalar("resume") != 0).sum())
+        s.close()
+    same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res["latency"], res["packed1"])) and left == 0
+    bad += not same
+    print("round %2d %-9s B=%4d T=%3d cap %3d live %4d mark %d: %s (iterations max %d; %d marked, %d through the queue)"
+          % (r, cfg, B, T, max_it, live, mark, "bitwise identical" if same else "DIFFERENT", res["latency"][5].max(), ho[1], ho[0]), flush=True)
+print("soak ok" if bad == 0 else "%d round(s) differ" % bad)
