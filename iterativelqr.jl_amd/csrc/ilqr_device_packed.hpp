@@ -17,8 +17,13 @@
 //     STATE MACHINE: the wave cycles  [outer-loop transitions] -> [line-search trial] -> [linearise + Riccati]  and an
 //     instance takes part in a phase when its state asks for it (predicated stores). An instance that rejects a trial
 //     simply sits out the following linearisation; nobody waits for anybody else inside a wave beyond that.
-// Same arithmetic as the other two kernels up to the association of a few sums (tree reductions over 16 lanes instead of
-// 64) and the solve of k sharing K's division through spare rows instead of a spare block.
+// Same arithmetic as the other kernels (one canonical summation order for the objective, explicit FMAs in generated model code):
+// an instance may change kernels in the middle of a solve and no output shows it.
+//
+// Workgroups: one pack + a helper wave that linearises ahead and costs trials behind the rollout (TWO; up to four packs per CU), or
+// two packs, one per wave and each on its own, whose workgroup turns into a two-wave latency solver for handed-over instances once
+// both packs are through — a device-wide queue, a straggler marked by its rejected line-search trials leaving at once and getting
+// its workgroup, then its CU, to itself (packed_solve_body's head of the cycle, pool_mark_step, pool_worker, solve_kernel_packed).
 //
 // Reference functions reproduced: see ilqr_device.hpp (same citations, paths relative to /root/reference).
 #pragma once
