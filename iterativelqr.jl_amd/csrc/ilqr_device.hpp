@@ -1426,8 +1426,13 @@ __device__ __forceinline__ void backward_pass(Inst<M>& I) {
 // ∇Lᵀ·Δz (src/forward_pass.jl:20) as three f64 MFMAs per step on column vectors in
 // the MFMA lane layout: the matrix pipe works asynchronously beside the VALU dynamics
 // chain, so Δ costs issue slots only (it used to be a separate 54 k-cycle serial loop).
-template <class M>
-__device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double& delta_out) {
+// MULTI: up to four trials of the line search at once, one per ROW of 16 lanes — the small models' cooperative dynamics work within
+// rows everywhere (four instances per wave in the packed kernel, four identical copies of the one instance here): row r rolls out
+// step size alpha / 2^min(r, nt - 1) into its own trial buffer (trial 0: I.x, I.u; trial j >= 1: buf1 + (j - 1) * bsz, its actions
+// xs doubles further). One instruction stream, four trajectories: a round of trials costs what one trial did.
+template <class M, bool MULTI = false>
+__device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double& delta_out, int nt = 1, double* buf1 = nullptr,
+                              int xs = 0, int bsz = 0) {
     constexpr int n = M::NX, m = M::NU;
     constexpr bool MF = (n <= 4 && m <= 4) && waves_of<M>::value == 1;   // with two waves Δ is wave 1's job (delta_small)
     // The rollout is ONE instruction stream per instance and a wave issues one instruction per ~5-6 clk whatever it is
@@ -1439,16 +1444,36 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     constexpr bool PRE = (m <= n);
     typedef __attribute__((address_space(3))) double ldsd;
     const int lane = I.lane;
+    // this row's trial: buffers and step size (MULTI; alpha * 0.5^j is what j halvings of the step size give, src/forward_pass.jl:51)
+    double* xr = I.x; double* ur = I.u;
+    const double alpha0 = alpha;
+    (void)alpha0;
+    if constexpr (MULTI) {
+        const int jr = (lane >> 4) < nt - 1 ? (lane >> 4) : nt - 1;
+        if (jr > 0) { xr = buf1 + (jr - 1) * bsz; ur = xr + xs; }
+        for (int j = 0; j < jr; ++j) alpha *= 0.5;
+    }
     if constexpr (PRE) {
         for (int t = lane; t < I.N; t += 64) {
 #pragma unroll
             for (int i = 0; i < m; ++i) {
-                const double a = fma(I.k[t * m + i], alpha, I.ub[t * m + i]);     // (:24-26)
                 double b = 0.0;
 #pragma unroll
                 for (int j = 0; j < n; ++j) b = fma(I.K[t * m * n + j * m + i], I.xb[t * n + j], b);
-                I.u[t * m + i] = a;
-                I.x[(t + 1) * n + i] = b;
+                if constexpr (MULTI) {
+                    double al = alpha0;              // every trial's a_t is formed here, whoever's row it is
+                    for (int j = 0; j < nt; ++j) {
+                        double* xj = j == 0 ? I.x : buf1 + (j - 1) * bsz;
+                        double* uj = j == 0 ? I.u : xj + xs;
+                        uj[t * m + i] = fma(I.k[t * m + i], al, I.ub[t * m + i]);
+                        xj[(t + 1) * n + i] = b;
+                        al *= 0.5;
+                    }
+                } else {
+                    const double a = fma(I.k[t * m + i], alpha, I.ub[t * m + i]);     // (:24-26)
+                    I.u[t * m + i] = a;
+                    I.x[(t + 1) * n + i] = b;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // same wave reads them back: LDS operations of a wave complete in order
@@ -1458,7 +1483,7 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
 #pragma unroll
     for (int i = 0; i < n; ++i) xt[i] = I.xb[i];                      // (:19)
 #pragma unroll
-    for (int i = 0; i < n; ++i) I.x[i] = xt[i];                       // every lane the same value to the same address
+    for (int i = 0; i < n; ++i) xr[i] = xt[i];                        // every lane (of a row) the same value to the same address
     // sensitivity state (MFMA layout: element (r, c) on lane c + 4*blk + 16*r, vectors in column 0)
     const int r = lane >> 4, c = lane & 3, blk = (lane >> 2) & 3;
     const bool vnn = r < n && c < n, vnm = r < n && c < m, vmn = r < m && c < n;
@@ -1470,7 +1495,7 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     // LDS byte addresses of K_t, u[t], x[t] held in VGPRs (opaque to the compiler, which would otherwise rebuild every address
     // from scalar registers with shift / add / move triples); they advance by two steps per loop trip, all other offsets are
     // immediates. Operands of step t are fetched one step ahead; the loop is unrolled by two with ping-pong operand sets.
-    unsigned aK = (unsigned)(size_t)(ldsd*)I.K, aU = (unsigned)(size_t)(ldsd*)I.u, aX = (unsigned)(size_t)(ldsd*)I.x;
+    unsigned aK = (unsigned)(size_t)(ldsd*)I.K, aU = (unsigned)(size_t)(ldsd*)ur, aX = (unsigned)(size_t)(ldsd*)xr;
     unsigned aKb = (unsigned)(size_t)(ldsd*)I.k, aUb = (unsigned)(size_t)(ldsd*)I.ub, aXb = (unsigned)(size_t)(ldsd*)I.xb;
     asm volatile("" : "+v"(aK), "+v"(aU), "+v"(aX));
     if constexpr (!PRE) asm volatile("" : "+v"(aKb), "+v"(aUb), "+v"(aXb));
@@ -1624,11 +1649,10 @@ __device__ __forceinline__ void gradients(Inst<M>& I, bool constrained) {
     if constexpr (is_large<M>::value) gradients_large<M>(I, constrained);
     else gradients_small<M>(I, constrained);
 }
-// (pair: the two-wave kernels' second wave, idle in a rollout, runs the NEXT trial of the line search — step size alpha / 2 — into
-// the buffers x2, u2 at the same time; forward_pass<M, true>)
-template <class M>
-__device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out, bool pair = false,
-                                             double* x2 = nullptr, double* u2 = nullptr) {
+// (MULTI, nt trials of the line search at once: rollout_small<M, true>; forward_pass<M, SPEC>)
+template <class M, bool MULTI = false>
+__device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with_delta, double& delta_out, int nt = 1,
+                                             double* buf1 = nullptr, int xs = 0, int bsz = 0) {
     if constexpr (is_large<M>::value) rollout_large<M>(I, alpha, with_delta, delta_out);
     else {
         ILQR_PROF_BEGIN();
@@ -1636,12 +1660,10 @@ __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with
             rollout_small<M>(I, alpha, with_delta, delta_out);
             __syncthreads();
         } else {
-            if (I.wave == 0 || pair) {
+            if (I.wave == 0) {
                 double unused = 0.0;
-                double* const xs = I.x; double* const us = I.u;
-                if (pair && I.wave == 1) { I.x = x2; I.u = u2; }
-                rollout_small<M>(I, (pair && I.wave == 1) ? 0.5 * alpha : alpha, false, unused);
-                I.x = xs; I.u = us;
+                if constexpr (MULTI) rollout_small<M, true>(I, alpha, false, unused, nt, buf1, xs, bsz);
+                else rollout_small<M>(I, alpha, false, unused);
             } else if (with_delta && !I.delta_next_ok) {                // stage kernels: the backward pass was another launch
                 const double d = delta_small<M>(I);
                 if (I.lane == 0) I.zs[4] = d;
@@ -1657,15 +1679,15 @@ __device__ __forceinline__ void rollout_bang(Inst<M>& I, double alpha, bool with
 
 // --------------------------------------------------------- forward_pass!
 // SPEC (two-wave small models; 1: from the second trial on — the resume launch; 2: from the first — the packed kernel's workers, whose
-// instances are the ones that reject; 0: the latency kernel, where 97 % of the first trials are accepted and pairs measured no
-// gain): the line search takes its trials in PAIRS —
-// wave 0 rolls out step size s, wave 1 at the same time s / 2 into the LDS of the cost gradients gx, gu (same sizes as x, u; dead
-// between the backward pass and the next gradients!, which rewrites them; saved to their HBM home before the first pair and
-// brought back if the whole search fails, the one case in which nothing rewrites them). Trial by trial the search then does what
-// it always did — cost!, the Armijo test, the counters, problem.states = the last trial evaluated — only that the second trial
-// of a pair is already rolled out when the first is rejected: a rejected trial is a rollout and a cost pass, 40 us of an
-// iteration's 50, and the stragglers of a batch are the instances that reject (instance 7609 of config 4's shard 6: 1914
-// rollouts for 917 iterations). Same arithmetic on the same inputs in the same order per trial: results bitwise unchanged.
+// instances are the ones that reject; 0: the latency kernel): the line search takes its trials in ROUNDS of up to four, rolled out at
+// once by the four rows of wave 0 (rollout_small<M, true>) into x, u and up to three more trial buffers in the LDS of the dynamics
+// Jacobians fx, fu — dead between the backward pass and the next gradients!, which rewrites them; saved to their (stale) HBM home
+// before a search's first round and brought back if the whole search fails, the one case in which nothing rewrites them. Trial by
+// trial the search then does what it always did — cost!, the Armijo test, the counters, problem.states = the last trial evaluated
+// (Q2 reads them) — only that the next trials of a round are rolled out already when one is rejected: a rejected trial is a rollout
+// and a cost pass, 40 us of an iteration's 50, and the stragglers of a batch are the instances that reject (instance 7609 of
+// config 4's shard 6: 1914 rollouts for 917 iterations). Same arithmetic on the same inputs in the same order per trial: results
+// bitwise unchanged.
 template <class M, int SPEC = 0>
 __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrained) {
     constexpr int n = M::NX, m = M::NU;
@@ -1682,9 +1704,14 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     I.delta = 0.0;
     I.step_size = 1.0;                                                // (:26)
     int iteration = 1;
-    bool saved = false, last_on_2 = false;
-    double* const x2 = I.gx; double* const u2 = I.gu;
-    double* const hx = I.gbase + (I.gx - I.lds); double* const hu = I.gbase + (I.gu - I.lds);     // their HBM home (stale during a launch)
+    // trial buffers 1..nb behind x, u: in the LDS of fx, fu
+    const int xs = (I.T * n + 1) & ~1, bsz = xs + ((I.N * m + 1) & ~1);
+    const int region = ((I.N * n * n + 1) & ~1) + ((I.N * n * m + 1) & ~1);
+    const int nb = SP ? (region / bsz < 3 ? region / bsz : 3) : 0;
+    double* const buf1 = I.fx;
+    double* const home = I.gbase + (I.fx - I.lds);                    // the HBM home of fx, fu (stale during a launch)
+    bool saved = false;
+    int last = 0;                                                     // buffer of the last trial evaluated
     auto accept = [&](const double* X, const double* U) {
         // update_nominal_trajectory! (src/data/methods.jl:32-39)
         constexpr int CS = is_large<M>::value ? 64 * waves_of<M>::value : 64;     // large path: HBM arrays, each element once
@@ -1697,60 +1724,51 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     while (I.step_size >= opt.min_step_size) {                        // (:28)
         if (iteration > max_iterations) break;                        // (:29)
         const bool want_delta = MF && iteration == 1 && opt.line_search == 1;
-        bool pair = false;
-        if constexpr (SP) pair = iteration >= (SPEC == 2 ? 1 : 2) && (!want_delta || I.delta_next_ok) && 0.5 * I.step_size >= opt.min_step_size && iteration + 1 <= max_iterations;
+        int nt = 1;                                                   // trials of this round: those the loop would get to one after the other
         if constexpr (SP) {
-            if (pair && !saved) {
-                if (I.wave == 1) {
-                    for (int i = I.lane; i < I.T * n; i += 64) hx[i] = x2[i];
-                    for (int i = I.lane; i < I.N * m; i += 64) hu[i] = u2[i];
-                }
+            if (iteration >= (SPEC == 2 ? 1 : 2) && (!want_delta || I.delta_next_ok)) {
+                double s = 0.5 * I.step_size;
+                while (nt < 1 + nb && s >= opt.min_step_size && iteration + nt <= max_iterations) { nt += 1; s *= 0.5; }
+            }
+            if (nt > 1 && !saved) {
+                for (int i = (int)threadIdx.x; i < nb * bsz; i += 128) home[i] = buf1[i];
                 saved = true;
+                __syncthreads();                                      // read out before wave 0 writes trials there
             }
         }
         double d = 0.0;
-        rollout_bang<M>(I, I.step_size, want_delta, d, pair, x2, u2);  // (:34)
+        rollout_bang<M, SP>(I, I.step_size, want_delta, d, nt, buf1, xs, bsz);     // (:34)
         if (want_delta) { delta = d; I.delta = d; }
-        cost_bang<M>(I, true, constrained);                           // (:36)
-        last_on_2 = false;
-        if (I.objective <= J_prev + c1 * I.step_size * delta) {       // (:44) NaN ⇒ reject
-            accept(I.x, I.u);
-            __syncthreads();
-            break;
-        }
-        I.step_size *= 0.5;                                           // (:51)
-        iteration += 1;
-        if constexpr (SP) {
-            if (pair) {                                               // the pair's second trial: rolled out already
-                I.rollouts += 1;
-                double* const xs = I.x; double* const us = I.u;
-                I.x = x2; I.u = u2;
-                cost_bang<M>(I, true, constrained);
-                I.x = xs; I.u = us;
-                last_on_2 = true;
-                if (I.objective <= J_prev + c1 * I.step_size * delta) {
-                    accept(x2, u2);
-                    break;
-                }
-                I.step_size *= 0.5;
-                iteration += 1;
+        bool done = false;
+        for (int j = 0; j < nt; ++j) {                                // the round's trials, in the order of the search
+            double* const xs0 = I.x; double* const us0 = I.u;
+            if (j > 0) { I.rollouts += 1; I.x = buf1 + (j - 1) * bsz; I.u = I.x + xs; }
+            cost_bang<M>(I, true, constrained);                       // (:36)
+            const double* X = I.x; const double* U = I.u;
+            I.x = xs0; I.u = us0;
+            last = j;
+            if (I.objective <= J_prev + c1 * I.step_size * delta) {   // (:44) NaN ⇒ reject
+                accept(X, U);
+                done = true;
+                break;
             }
+            I.step_size *= 0.5;                                       // (:51)
+            iteration += 1;
         }
+        if (done) break;
     }
+    if (I.status || last > 0) __syncthreads();
     if constexpr (SP) {
-        if (last_on_2) {              // problem.states, problem.actions = the last trial evaluated (Q2 reads them)
+        if (last > 0) {               // problem.states, problem.actions = the last trial evaluated (Q2 reads them)
+            const double* X = buf1 + (last - 1) * bsz;
+            for (int i = (int)threadIdx.x; i < I.T * n; i += 128) I.x[i] = X[i];
+            for (int i = (int)threadIdx.x; i < I.N * m; i += 128) I.u[i] = X[xs + i];
             __syncthreads();
-            for (int i = I.lane + 64 * I.wave; i < I.T * n; i += 128) I.x[i] = x2[i];
-            for (int i = I.lane + 64 * I.wave; i < I.N * m; i += 128) I.u[i] = u2[i];
         }
-        if (saved && (!I.status || opt.line_search == 0)) {     // no gradients! will rewrite gx, gu: bring them back
+        if (saved && (!I.status || opt.line_search == 0)) {     // no gradients! will rewrite fx, fu: bring them back
+            for (int i = (int)threadIdx.x; i < nb * bsz; i += 128) buf1[i] = home[i];
             __syncthreads();
-            if (I.wave == 1) {
-                for (int i = I.lane; i < I.T * n; i += 64) x2[i] = hx[i];
-                for (int i = I.lane; i < I.N * m; i += 64) u2[i] = hu[i];
-            }
         }
-        if (saved || last_on_2) __syncthreads();
     }
 }
 
@@ -1954,7 +1972,7 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
 }
 
 #ifndef ILQR_SPEC_LATENCY
-#define ILQR_SPEC_LATENCY 0         // line-search trials in pairs (forward_pass<M, 1 | 2>: from the second / first trial on) in the latency kernel ...
+#define ILQR_SPEC_LATENCY 1         // line-search trials in rounds of up to four (forward_pass<M, 1 | 2>: from the second / first trial on) in the latency kernel ...
 #endif
 #ifndef ILQR_SPEC_RESUME
 #define ILQR_SPEC_RESUME 1          // ... and in the resume launch
