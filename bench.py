@@ -321,6 +321,12 @@ def worker(args, solver_factory=None):
 
     kernel_ms, launches = sol.timing()
     st = sol.stats()
+    ho_stats = None
+    if not stub and not sharded:
+        try:       # one-wave form of the packed kernel: what its workgroups did with the stragglers of this rank's last timed solve
+            ho_stats = sol.handover_stats()
+        except Exception:
+            pass
     it_sum, it_max = float(st["iterations"].sum()), float(st["iterations"].max())
 
     # ---- secondary figures of the same run (extra keys of the JSON line, never `value`): rank r on ITS OWN shard
@@ -452,12 +458,8 @@ def worker(args, solver_factory=None):
     }
     if secondary:
         out["secondary"] = secondary
-    if not stub and not sharded:
-        try:       # one-wave form of the packed kernel: what its workgroups did with the stragglers of this rank's last solve
-            q_, m_ = sol.handover_stats()
-            out["solve_stats"]["handover"] = {"marked_as_stragglers": m_, "through_the_workgroups_queue": q_}
-        except Exception:
-            pass
+    if ho_stats is not None:
+        out["solve_stats"]["handover"] = {"marked_as_stragglers": ho_stats[1], "through_the_workgroups_queue": ho_stats[0]}
     if not stub:
         n_, m_ = sol.nx, sol.nu
         io_bytes = 8.0 * B * (n_ + (T - 1) * m_ + T * n_ + (T - 1) * m_ + (T - 1) * (m_ * n_ + m_))     # per device
