@@ -1175,7 +1175,7 @@ __device__ __forceinline__ void pool_worker(const unsigned long long kernarg, co
         __syncthreads();
         if (b < 0) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        solve_instance<M, true, ILQR_SPEC_WORKER>(a, pk_lds_, b);   // (line-search trials in pairs: forward_pass<M, SPEC>)
+        solve_instance<M, true, ILQR_SPEC_WORKER>(a, pk_lds_, b);   // (line search in rounds of four trials: forward_pass<M, SPEC>)
         __syncthreads();
     }
 }

@@ -1459,7 +1459,7 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
         assert np.array_equal(off["tr"], on["tr"], equal_nan=True)            # every column, the objective included (one arithmetic for J in every kernel)
         # delta: the Armijo product of the LAST forward pass — the first one after a hand-over takes the number the packed kernel's
         # backward pass left in the block (S_DELTA_NEXT), not a sum of its own in another order
-        for k in ("x", "u", "K", "k", "lam", "fx", "gxx", "delta", "gx", "gu", "xs", "us"):     # (gx, gu, states: the resume launch's paired trials)
+        for k in ("x", "u", "K", "k", "lam", "fx", "gxx", "delta", "gx", "gu", "xs", "us"):     # (fx, gx, gu, states: the resume launch's rounds of trials)
             assert np.array_equal(off[k], on[k], equal_nan=True), k
 
 
@@ -1486,8 +1486,8 @@ def test_one_wave_packed_form_finishes_its_hand_overs_itself(pkg, config, B, off
         out = dict(x=s.get_trajectory()[0], u=s.get_trajectory()[1], K=s.get_policy()[0], k=s.get_policy()[1], st=s.stats(),
                    tl=s.scalar("trace_len"), tr=s.trace(), resume=s.scalar("resume"), lam=s.buffer("constraint_dual"),
                    fx=s.buffer("jacobian_state"), gxx=s.buffer("hessian_state_state"), delta=s.scalar("delta_grad_product"),
-                   # the workers take their line-search trials in pairs (forward_pass<M, 2>): the second wave's trial lives in the
-                   # LDS of the cost gradients, and problem.states / actions must be the LAST trial evaluated
+                   # the workers take their line-search trials in rounds of four (forward_pass<M, 2>): the extra trials live in the
+                   # LDS of fx, fu, and problem.states / actions must be the LAST trial evaluated
                    gx=s.buffer("gradient_state"), gu=s.buffer("gradient_action"), xs=s.buffer("states"), us=s.buffer("actions"),
                    ho=s.handover_stats() if variant != "latency" else (0, 0))
         s.close()

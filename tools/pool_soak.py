@@ -1,7 +1,7 @@
 """Soak of the packed kernel's one-wave form as its own pool (two packs per workgroup, workgroups finishing hand-overs, stragglers
-marked and leaving at once, line-search trials in pairs): random models, batch sizes, horizons, iteration caps, head counts and
+marked and leaving at once, the line search in rounds of four trials): random models, batch sizes, horizons, iteration caps, head counts and
 marks; each solve compared bitwise with the latency kernel — trajectories, policies, duals, counters, objective, the cost gradients
-and problem.states (what the paired trials use as their second buffer / must leave as the last trial evaluated) — and nothing may
+and problem.states, the Jacobians (what the rounds of trials use as their extra buffers / must leave as the last trial evaluated) — and nothing may
 be left for the launch behind. A lost wake-up would hang the launch: run under `timeout`.   python tools/pool_soak.py [rounds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
