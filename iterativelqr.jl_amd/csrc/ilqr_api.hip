@@ -1181,9 +1181,13 @@ int ilqr_solve(ilqr_handle* h) {
         // under the head-count rule an instance whose rejected line-search trials exceed the batch's mean by `mark` leaves at once
         if ((ho > 0 || live > 0) && h->pool != nullptr) {
             HIP_TRY(hipMemsetAsync(h->pool, 0, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B + ilqr::POOL_CUS), h->stream));
-            a.pool_cu = 1;       // a marked straggler gets its CU to itself (config 4, shard 6: 126.6 -> 118.0 ms)
+            // a marked straggler gets its CU to itself (config 4, shard 6: 126.6 -> 118.0 ms) — while the launch is ONE round of
+            // workgroups (four of them per CU): in a launch of several rounds a workgroup that waits holds the slots the next round
+            // needs, so there nobody waits (pool_cu = 0: no CU is vacated, an idle worker leaves as soon as the queue is empty)
+            a.pool_cu = ((h->B + 3) / 4 + 1) / 2 <= h->num_simds ? 1 : 0;
             a.pool = h->pool; a.pool_lds = (int)h->lds_bytes;
             a.pool_mark = live > 0 ? (h->handover_mark < 0 ? 6 : h->handover_mark) : 0;
+            if (!a.pool_cu) a.pool_mark = 0;      // (and nobody is marked: the batch's mean says nothing while half the batch has not started)
         }
 #ifdef ILQR_PK_DEBUG_HOOK      // phase-timing hook of tools/packed_phases.py (see ilqr_device_packed.hpp); never compiled into the product library
         if (const char* dbg = std::getenv("ILQR_PK_DEBUG")) a.stage = std::atoi(dbg);

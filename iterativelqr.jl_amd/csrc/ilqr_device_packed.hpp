@@ -1150,7 +1150,10 @@ __device__ __forceinline__ void pool_worker(const unsigned long long kernarg, co
     for (;;) {
         if (threadIdx.x == 0) {
             int b = -1;
-            if (own) { atomicSub(a.pool + POOL_BUSY, 1); own = false; }                  // the marked instance of the last round is finished
+            if (own) {                                                                     // the marked instance of the last round is finished
+                atomicSub(a.pool + POOL_BUSY, 1); own = false;
+                if (a.pool_cu) __hip_atomic_store(a.pool + POOL_Q + a.B + cu_id(), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the CU is everybody's again
+            }
             else if (queued) atomicAdd(a.pool + POOL_FINISHED, 1);
             queued = false;
             for (int i = 0; i < 8; ++i) if (ctl[CTL_OWN + i] >= 0) { b = ctl[CTL_OWN + i]; ctl[CTL_OWN + i] = -1; own = true; break; }
@@ -1165,7 +1168,7 @@ __device__ __forceinline__ void pool_worker(const unsigned long long kernarg, co
                         while ((e = __hip_atomic_load(a.pool + POOL_Q + head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(8);
                         b = e - 1; queued = true;
                     }
-                } else if (done >= packs || __hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) b = -2;
+                } else if (done >= packs || !a.pool_cu || __hip_atomic_load(a.pool + POOL_BUSY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) b = -2;
                 else __builtin_amdgcn_s_sleep(127);        // (no marked instance on its way: nothing more will be queued, see above)
             }
             ctl[CTL_NEXT] = b;

@@ -1465,13 +1465,14 @@ def test_straggler_handover_by_head_count_changes_no_result(pkg, config, B, live
 
 @pytest.mark.parametrize("config,B,offset,live,mark", [("acrobot", 61, 2 * 8192 + 2290, 40, 1), ("acrobot", 61, 2 * 8192 + 2290, 40, 8),
                                                        ("acrobot51", 45, 0, 30, 1), ("car", 37, 0, 20, 1), ("acrobot", 9, 6 * 8192 + 7605, 2, 8),
-                                                       ("acrobot", 4104, 2 * 8192, 512, 6)])
+                                                       ("acrobot", 4104, 2 * 8192, 512, 6), ("acrobot51", 9000, 0, 1024, 2)])
 def test_one_wave_packed_form_finishes_its_hand_overs_itself(pkg, config, B, offset, live, mark):
     """The one-wave form of the packed kernel (two packs per workgroup): a workgroup whose packs are through takes handed-over
     instances from the device-wide queue and finishes them with the latency kernel's code; an instance whose rejected line-search
     trials exceed the batch's mean by `mark` (ilqr_set_handover_mark) is marked, its workgroup's two packs leave at once and the
     workgroup finishes the marked instance first — and so do the other packs on its CU, whose workgroups keep quiet until no marked
-    instance is on its way (4104 instances: 513 workgroups, two on every CU). Batches around the two stragglers of BASELINE config 4 (instance 2300 of shard 2,
+    instance is on its way (4104 instances: 513 workgroups, two on every CU; 9000 instances: more workgroups than the chip holds at
+    once — there nobody waits for anybody, a waiting workgroup would hold the next round's slots). Batches around the two stragglers of BASELINE config 4 (instance 2300 of shard 2,
     7609 of shard 6) and ordinary ones with the mark at one rejected trial (many marks). WHO leaves, and when, depends on the
     timing of the run: every count, trace row and array must be the latency kernel's, bitwise, run after run, and nothing may be
     left for the launch behind (resume = 0 everywhere)."""
