@@ -1511,6 +1511,49 @@ def test_one_wave_packed_form_finishes_its_hand_overs_itself(pkg, config, B, off
         assert np.array_equal(ref[k], off[k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("min_step", [1.0e-5, 0.125, 0.3])
+def test_line_search_in_rounds_is_the_search_trial_by_trial(pkg, oracle, min_step):
+    """forward_pass<M, SPEC> rolls out up to four step sizes of a line search at once (the rows of the rollout's wave) and then does,
+    trial by trial, what src/forward_pass.jl:28-52 does. Against the oracle (one trial after the other): instances 880..891 of
+    BASELINE config 4 — 885 fails EVERY search (17 trials down to min_step_size, then the inner solve ends: the trial buffers in the
+    LDS of fx, fu must be brought back, problem.states must be the last trial) — and 2296..2303 (2300: two rollouts per iteration),
+    with min_step_size at its default and at values that cut a round short (0.125: s, s/2, s/4, s/8 and no further; 0.3: two
+    trials). Iterations, ROLLOUTS, status and step sizes exact; then the packed kernel's workers (rounds from the first trial) and
+    the resume launch bitwise against the latency kernel, Jacobians and problem.states included."""
+    model, T, x1a, uba = pkg.workloads.make_inputs("acrobot", 12, offset=880)
+    _, _, x1b, ubb = pkg.workloads.make_inputs("acrobot", 8, offset=2 * 8192 + 2296)
+    x1, ub = np.concatenate([x1a, x1b]), np.concatenate([uba, ubb])
+    B = len(x1)
+    opts = dict(min_step_size=min_step)
+    ref = oracle.solve_batch(model, T, x1, ub, nthreads=8, options=oracle.default_options(**opts))
+    out = {}
+    for variant in ("latency", "packed1"):
+        s = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0, **opts))
+        s.set_kernel_variant_(variant); s.enable_trace_(1100)
+        if variant == "packed1":
+            s.set_handover_(-1); s.set_handover_live_(B - 3); s.set_handover_mark_(1)
+        s.initialize_rollout_(x1, ub); s.solve_()
+        out[variant] = dict(x=s.get_trajectory()[0], u=s.get_trajectory()[1], K=s.get_policy()[0], st=s.stats(), tr=s.trace(),
+                            fx=s.buffer("jacobian_state"), fu=s.buffer("jacobian_action"), xs=s.buffer("states"), us=s.buffer("actions"),
+                            gx=s.buffer("gradient_state"))
+        s.close()
+    a = out["latency"]
+    # instance 2300 itself is chaotic (the oracle against itself with ū·(1 + 1e-15) differs by 14 in x, profiles/r05_all_shards.txt):
+    # it is in the batch for the bitwise comparison below, not for this one
+    ok = np.arange(B) != 12 + 4
+    for k in ("iterations", "rollouts", "outer_iterations", "status"):
+        assert np.array_equal(a["st"][k][ok], ref["stats"][k][ok]), k
+    assert (a["st"]["rollouts"] - a["st"]["iterations"]).max() >= 7             # searches that reject, and one instance whose searches fail
+    fin = np.isfinite(ref["x"]).reshape(B, -1).all(1) & ok
+    assert np.abs(a["x"] - ref["x"])[fin].max() < 1e-6 and np.abs(a["st"]["step_size"] - ref["stats"]["step_size"])[ok].max() == 0.0
+    b = out["packed1"]
+    for k in ("iterations", "rollouts", "status", "objective", "step_size"):
+        assert np.array_equal(a["st"][k], b["st"][k], equal_nan=True), k
+    assert np.array_equal(a["tr"], b["tr"], equal_nan=True)
+    for k in ("x", "u", "K", "fx", "fu", "xs", "us", "gx"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
 def test_packed_kernel_extra_trials_for_an_instance_that_keeps_rejecting(pkg):
     """The packed kernel gives an instance with eight rejected line-search trials behind it up to three more trials within the
     cycle (ilqr_device_packed.hpp, ILQR_PK_TRIALS / ILQR_PK_REJECTS). Instance 2300 of shard 2 of BASELINE config 4 spends 1407
