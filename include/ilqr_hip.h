@@ -256,7 +256,11 @@ int ilqr_resolved_kernel_variant(ilqr_handle* h, int32_t* variant);
  *     still running, is marked at the head of its next
  *     inner iteration; its workgroup's two packs leave at their next resumable points and the workgroup finishes the marked
  *     instance at once (BASELINE config 4: instance 2300 of shard 2 — 682 iterations, 1354 rollouts, the others 347 — is
- *     marked in its second iteration). -1 auto = 6; 0 never; n >= 1 as given. */
+ *     marked in its second iteration). -1 auto = 6; 0 never; n >= 1 as given. Marks are taken only while the launch is ONE round of
+ *     workgroups (all resident: up to 8192 instances per GPU on an MI355X); beyond that the head-count rule alone applies.
+ * The two-wave solvers (latency kernel, resume launch, the workgroups above) take the trials of a line search
+ * (src/forward_pass.jl:28-52) in rounds of up to four, rolled out at once by the four 16-lane rows of one wave; trial by trial the
+ * search is the reference's, and so are its results. */
 int ilqr_set_handover(ilqr_handle* h, int32_t outer);
 int ilqr_set_handover_live(ilqr_handle* h, int32_t live);
 int ilqr_set_handover_mark(ilqr_handle* h, int32_t rejected);
