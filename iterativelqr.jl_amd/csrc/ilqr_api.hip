@@ -112,6 +112,8 @@ struct ilqr_handle {
     int* done_counter;    // device counter of finished instances for that rule
     int* pool;            // one-wave form of the packed kernel: queue of handed-over instances its workgroups finish themselves (POOL_Q + B ints)
     int handover_mark;    // rejected line-search trials above the batch's mean at which an instance is marked a straggler (-1 auto, 0 never)
+    int* cu_slots = nullptr;   // latency kernel: critical waves per SIMD (ilqr::KArgs::cu_slots), CU_SLOT_CUS x 4 counters
+    bool pool_valid = false;   // the queue words hold the counts of THIS handle's last solve (false after a solve that did not use the queue)
     int variant;          // 0 auto, 1 latency kernel (all-LDS, 2 waves per instance; large models: four waves per instance), 2 throughput kernel (slim), 3 packed kernel (4 instances per wave, no LDS), 4 one wave per instance of a large model with nx, nu <= 16
     bool lds_fits;        // the LDS-resident kernels can hold this horizon (otherwise only the packed kernel runs it)
     int num_simds;
@@ -143,7 +145,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.qv = h->qv; a.QL = h->QL;
     a.stage_param = 0.0; a.stage_flag = 0;
     a.handover_outer = 0; a.resume = 0; a.handover_live = 0; a.done_counter = h->done_counter;
-    a.pool = nullptr; a.pool_mark = 0; a.pool_lds = 0; a.pool_ctl = 0; a.pool_cu = 0;
+    a.pool = nullptr; a.pool_mark = 0; a.pool_lds = 0; a.pool_ctl = 0; a.pool_cu = 0; a.cu_slots = nullptr;
     return a;
 }
 
@@ -941,6 +943,8 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->done_counter, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(hand-over counter)");
     if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->pool, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B + ilqr::POOL_CUS))) != hipSuccess) return bail(e, "hipMalloc(hand-over queue)");
     if ((e = hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if (!ilqr::is_large_model(vt->nx, vt->nu) && (e = hipMalloc((void**)&h->cu_slots, sizeof(int) * 4 * ilqr::CU_SLOT_CUS)) != hipSuccess) return bail(e, "hipMalloc(role counters)");
+    if (h->pool && (e = hipMemsetAsync(h->pool, 0, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B + ilqr::POOL_CUS), h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync(hand-over queue)");
     *out = h;
     int rc = ilqr_reset(h);
     if (rc != ILQR_OK) { ilqr_destroy(h); *out = nullptr; return rc; }
@@ -991,6 +995,7 @@ int ilqr_destroy(ilqr_handle* h) {
     if (h->d_x1) hipFree(h->d_x1);
     if (h->done_counter) hipFree(h->done_counter);
     if (h->pool) hipFree(h->pool);
+    if (h->cu_slots) hipFree(h->cu_slots);
     if (h->d_u) hipFree(h->d_u);
     if (h->trace) hipFree(h->trace);
     if (h->qv) hipFree(h->qv);
@@ -1147,6 +1152,7 @@ int ilqr_solve(ilqr_handle* h) {
     if (h->trace)      // rows of an earlier, longer solve must not survive
         HIP_TRY(hipMemsetAsync(h->trace, 0, (size_t)h->B * h->trace_cap * ilqr::TRACE_W * 8, h->stream));
     if (h->vt->launch_mirror) h->full_stale = true;   // the kernel works on the compact Jacobian / Hessian rows
+    h->pool_valid = false;                            // (set again below when this solve zeroes and uses the hand-over queue)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto drop = [&](int rc) { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); return rc; };
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, h->stream) != hipSuccess)
@@ -1186,6 +1192,7 @@ int ilqr_solve(ilqr_handle* h) {
             // needs, so there nobody waits (pool_cu = 0: no CU is vacated, an idle worker leaves as soon as the queue is empty)
             a.pool_cu = ((h->B + 3) / 4 + 1) / 2 <= h->num_simds ? 1 : 0;
             a.pool = h->pool; a.pool_lds = (int)h->lds_bytes;
+            h->pool_valid = true;
             a.pool_mark = live > 0 ? (h->handover_mark < 0 ? 6 : h->handover_mark) : 0;
             if (!a.pool_cu) a.pool_mark = 0;      // (and nobody is marked: the batch's mean says nothing while half the batch has not started)
         }
@@ -1213,7 +1220,15 @@ int ilqr_solve(ilqr_handle* h) {
         if (const char* pad = std::getenv("ILQR_DBG_LDS_PAD")) lds_mid += (size_t)std::atoi(pad);
 #endif
         if (h->vt->launch_solve_mid(&a, lds_mid, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (one-wave variant) launch failed"));
-    } else if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve launch failed"));
+    } else {
+        // two-wave latency kernel: one critical wave per SIMD (KArgs::cu_slots; ILQR_ROLE_SLOTS=0 leaves the roles as launched: A/B runs)
+        static const bool role_slots = !(std::getenv("ILQR_ROLE_SLOTS") && std::getenv("ILQR_ROLE_SLOTS")[0] == '0');
+        if (h->cu_slots != nullptr && role_slots) {
+            HIP_TRY(hipMemsetAsync(h->cu_slots, 0, sizeof(int) * 4 * ilqr::CU_SLOT_CUS, h->stream));
+            a.cu_slots = h->cu_slots;
+        }
+        if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve launch failed"));
+    }
     if (hipEventRecord(e1, h->stream) != hipSuccess) return drop(fail(ILQR_ERR_HIP, "hipEventRecord failed"));
     h->timing.emplace_back(e0, e1);
     if (h->timing.size() > 4096) {     // long-running callers that never read the timing: keep the newest half
@@ -1380,6 +1395,7 @@ int ilqr_scalar_slot(const char* name) {
         {"delta_grad_product", ilqr::S_DELTA}, {"trace_len", ilqr::S_TRACE_LEN}, {"count", ilqr::S_COUNT},
         {"obj_prev", ilqr::S_OBJ_PREV}, {"inner_done", ilqr::S_INNER_DONE}, {"j_prev", ilqr::S_J_PREV}, {"inner_it", ilqr::S_INNER_IT},
         {"resume", ilqr::S_RESUME}, {"literal_backward_passes", ilqr::S_LITERAL_PASSES},
+        {"t_start", ilqr::S_T_START}, {"t_end", ilqr::S_T_END}, {"hw_id_wave0", ilqr::S_HW0}, {"hw_id_wave1", ilqr::S_HW1},
     };
     if (!name) return -1;
     for (auto& s_ : slots)
@@ -1481,7 +1497,7 @@ int ilqr_get_handover_stats(ilqr_handle* h, int32_t* queued, int32_t* marked) {
         const int rc = ilqr_get_handover_stats(s, &q, &m);
         *queued += q; *marked += m;
         return rc; });
-    if (h->pool == nullptr) return ILQR_OK;
+    if (h->pool == nullptr || !h->pool_valid) return ILQR_OK;      // the last solve did not go through the queue: 0 / 0
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     int words[ilqr::POOL_Q];

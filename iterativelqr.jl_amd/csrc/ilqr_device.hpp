@@ -68,7 +68,13 @@ struct KArgs {
     // workgroup's control words lie in LDS (set by the launcher); pool_cu: every pack on a marked straggler's CU leaves with it.
     int* pool;
     int pool_mark, pool_lds, pool_ctl, pool_cu;
+    // Latency kernel, which wave of an instance is its CRITICAL one (role 0: rollout, matrix chain): the hardware places the two waves
+    // of a workgroup on two SIMDs of its own choosing, and on 3 % of the SIMDs of a full chip two critical waves end up together
+    // (tools/finish_times.py). cu_slots: 4 counters per CU (zeroed by the host before the launch; null = roles as launched) — a
+    // workgroup takes the SIMD of its first wave for role 0 if no other workgroup has, else that of its second wave (roles swapped).
+    int* cu_slots;
 };
+enum { CU_SLOT_CUS = 8 * 8 * 2 * 16 };      // xcc x se x sh x cu of HW_REG_XCC_ID / HW_REG_HW_ID
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -228,6 +234,7 @@ struct Inst {
     int T, N, C, lane, wave;
     double objective, max_violation, step_size, gradient_norm;
     int status, iterations, outer_iterations, potrf_info, rollouts, states_eq_nominal;
+    int cost_par;          // two-wave kernel: which pair of LDS slots carries the next cost pass's results from wave 0 to wave 1
 #ifdef ILQR_PROFILE
     double prof[PROF_N];
 #endif
@@ -295,7 +302,11 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
     constexpr int n = M::NX, m = M::NU, ncs = M::NCS, nct = M::NCT;
     ILQR_PROF_BEGIN();
     double Jp = 0.0, vp = 0.0;
-    for (int t = I.lane; t < I.T; t += 64) {
+    // Two waves per instance: the pass is wave 0's; wave 1 waits at the barrier and takes the two results from LDS (it used to run
+    // the same pass — idempotent, but its issue slots are another instance's critical wave's on the SIMD they share)
+    constexpr bool PARK = waves_of<M>::value == 2;
+    const int t_first = (PARK && I.wave != 0) ? I.T : I.lane;
+    for (int t = t_first; t < I.T; t += 64) {
         double w[cdim<M::NW>::v];
         load_w<M::NW>(I.w, t, w);
         double xt[n];
@@ -348,9 +359,21 @@ __device__ void cost_pass(Inst<M>& I, const double* X, const double* U, bool upd
             }
         }
     }
-    J_out = wave_sum(Jp);
-    viol_out = wave_max(vp);
-    __syncthreads();
+    if constexpr (PARK) {
+        double* hand = I.zs + 8 + 2 * I.cost_par;      // alternating pairs: wave 1 reads pair p while wave 0 may already be in the next pass
+        I.cost_par ^= 1;
+        if (I.wave == 0) {
+            J_out = wave_sum(Jp);
+            viol_out = wave_max(vp);
+            if (I.lane == 0) { hand[0] = J_out; hand[1] = viol_out; }
+        }
+        __syncthreads();
+        if (I.wave != 0) { J_out = hand[0]; viol_out = hand[1]; }
+    } else {
+        J_out = wave_sum(Jp);
+        viol_out = wave_max(vp);
+        __syncthreads();
+    }
 #ifndef ILQR_PROFILE_BAR
     ILQR_PROF_END(I, PROF_COST);
 #endif
@@ -1714,8 +1737,8 @@ __device__ void forward_pass(Inst<M>& I, const ilqr_options& opt, bool constrain
     int last = 0;                                                     // buffer of the last trial evaluated
     auto accept = [&](const double* X, const double* U) {
         // update_nominal_trajectory! (src/data/methods.jl:32-39)
-        constexpr int CS = is_large<M>::value ? 64 * waves_of<M>::value : 64;     // large path: HBM arrays, each element once
-        const int c0 = is_large<M>::value ? (int)threadIdx.x : I.lane;
+        constexpr int CS = 64 * waves_of<M>::value;     // each element once (a barrier follows: forward_pass's last lines)
+        const int c0 = is_large<M>::value ? (int)threadIdx.x : I.lane + 64 * I.wave;
         for (int i = c0; i < I.T * n; i += CS) I.xb[i] = X[i];
         for (int i = c0; i < I.N * m; i += CS) I.ub[i] = U[i];
         I.states_eq_nominal = 1;
@@ -1889,7 +1912,7 @@ __device__ void solve_loops(Inst<M>& I, const ilqr_options& opt, bool constraine
 
 // ------------------------------------------------------------ kernel glue
 template <class M>
-__device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* smem, int b) {
+__device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* smem, int b, int swap_roles = 0) {
     const Layout& L = a.L;
     double* g = a.ws + (size_t)b * (size_t)L.stride;
     I.xb = smem + L.xb; I.ub = smem + L.ub; I.x = smem + L.x; I.u = smem + L.u;
@@ -1898,7 +1921,8 @@ __device__ __forceinline__ void inst_setup(Inst<M>& I, const KArgs& a, double* s
     I.c = smem + L.c; I.lam = smem + L.lam; I.rho = smem + L.rho; I.act = smem + L.act;
     I.zs = smem + L.zslot; I.gzero = g + L.gzero; I.w = smem + L.w; I.ring = smem + L.ring;
     I.gxx = g + L.gxx; I.guu = g + L.guu; I.gux = g + L.gux; I.P = g + L.P; I.p = g + L.p; I.scal = g + L.scal;
-    I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x & 63; I.wave = threadIdx.x >> 6;
+    I.T = L.T; I.N = L.T - 1; I.C = L.C; I.lane = threadIdx.x & 63; I.wave = (int)(threadIdx.x >> 6) ^ swap_roles;
+    I.cost_par = 0;
     I.lds = smem; I.gbase = g; I.fv_off = 0; I.hc_off = 0; I.hLx = L.Lx; I.hLu = L.Lu;
     I.trace = a.trace ? a.trace + (size_t)b * (size_t)a.trace_cap * TRACE_W : nullptr;
     I.trace_cap = a.trace_cap; I.trace_len = 0;      // (the stage kernel continues from the stored count, see there)
@@ -1990,7 +2014,45 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
         obj_prev0 = sc[S_OBJ_PREV];
     }
     Inst<M> I;
-    inst_setup<M>(I, a, smem, b);
+    int swap_roles = 0, cu_slot = -1;
+    unsigned hwid = 0, xcc = 0;
+    constexpr bool TWO = !is_large<M>::value && waves_of<M>::value == 2;
+    if constexpr (TWO) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (a.cu_slots != nullptr) {
+            // one critical wave per SIMD (KArgs::cu_slots): thread 0 picks the role-0 SIMD among the workgroup's two
+            int* sm = reinterpret_cast<int*>(smem);
+            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = (int)((hwid >> 4) & 3u);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int cu = (int)(((xcc & 7u) << 8) | (((hwid >> 13) & 7u) << 5) | (((hwid >> 12) & 1u) << 4) | ((hwid >> 8) & 15u));
+                int* c = a.cu_slots + 4 * cu;
+                const int s0 = sm[0], s1 = sm[1];
+                int sw = 0, taken = 4 * cu + s0;
+                if (s0 != s1 && atomicAdd(c + s0, 1) != 0) {
+                    if (atomicAdd(c + s1, 1) == 0) { atomicSub(c + s0, 1); sw = 1; taken = 4 * cu + s1; }
+                    else atomicSub(c + s1, 1);
+                }
+                sm[2] = sw; sm[3] = taken;
+            }
+            __syncthreads();
+            swap_roles = sm[2]; cu_slot = sm[3];
+            __syncthreads();                                          // read before inst_setup fills the LDS set
+        }
+    }
+    inst_setup<M>(I, a, smem, b, swap_roles);
+    if (I.lane == 0 && I.wave == 0) I.scal[S_T_START] = (double)wall_clock64();
+    if constexpr (TWO) {
+        if (I.lane == 0) I.scal[S_HW0 + I.wave] = (double)hwid + 4294967296.0 * (double)(xcc & 15u);
+        // The SIMD's arbiter serves its OLDEST wave first: of two waves that share a SIMD the one dispatched later gets what the other
+        // leaves (measured: the fourth workgroup of a CU ran its iterations in 67 us, the first in 53; tools/finish_times.py).
+        // Wave 1 works a third of the time and its instance's critical wave waits for it at the chunk barriers of the Riccati
+        // recursion: it goes first whenever it has work, whatever its age; every critical wave then yields to ONE foreign wave 1.
+#ifndef ILQR_NO_SETPRIO
+        if (I.wave != 0) __builtin_amdgcn_s_setprio(3);
+#endif
+    }
     if (!resumed) {
         I.potrf_info = 0; I.rollouts = 0; I.outer_iterations = 0;
         if (I.lane == 0 && I.wave == 0) I.scal[S_LITERAL_PASSES] = 0.0;
@@ -2008,8 +2070,11 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
     if (I.lane == 0 && I.wave == 0) {
         I.scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
         I.scal[S_RESUME] = 0.0;
+        I.scal[S_T_END] = (double)wall_clock64();
+        if (cu_slot >= 0) atomicSub(a.cu_slots + cu_slot, 1);         // (launches of several rounds: the next workgroup on this CU sees it free)
     }
     inst_writeback<M>(I, a, smem, b);
+    if constexpr (TWO) __builtin_amdgcn_s_setprio(0);                 // (the packed kernel's workers go on after this)
 }
 
 // solve!(solver) for every instance — src/solve.jl:137-143
@@ -2227,7 +2292,7 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 8   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+#define ILQR_MODEL_ABI_VERSION 9   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against

@@ -30,7 +30,12 @@ enum {
     // backward passes of the last solve that the short nu = 1 form (backward_pass_m1) had to hand to the literal code because a
     // pivot was not positive (0 on healthy instances; the two-wave latency kernel counts, the other kernels leave it alone)
     S_LITERAL_PASSES = 26,
-    S_COUNT = 28
+    // when the instance's workgroup started / finished its solve in the latency kernel: s_memrealtime ticks (100 MHz, one counter for
+    // the whole device), so that (S_T_END - min S_T_START) of a batch is its finishing-time profile (tools/finish_times.py)
+    S_T_START = 27, S_T_END = 28,
+    // ... and where its two waves ran: HW_REG_HW_ID (wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13]) + 2^32 x XCC_ID
+    S_HW0 = 29, S_HW1 = 30,
+    S_COUNT = 32
 };
 
 // Riccati hand-over between the two waves of a small-model instance: chunks of RING_STEPS timesteps, double-buffered
@@ -44,7 +49,7 @@ struct Layout {
     int C;   // total number of constraints over the horizon
     // offsets (in doubles) inside one instance block
     int xb, ub, x, u, fx, fu, gx, gu, K, k, Lx, Lu, c, lam, rho, act, w;   // LDS-resident set (w: parameters θ_t)
-    int zslot;                                                          // [0] always 0.0, [1] write-only trash, [2..7] wave-to-wave scalars
+    int zslot;                                                          // [0] always 0.0, [1] write-only trash, [2..11] wave-to-wave scalars
     int lds_doubles;                                                    // size of that set
     int lds_doubles_slim;                                               // ... without fx, fu (throughput variant)
     int ring;                                                           // LDS: two half-rings of RING_STEPS x {Quu, Qux, ux_tmp} (4x4 each)
@@ -123,7 +128,7 @@ inline __host__ __device__ Layout make_layout(int nx, int nu, int nw, int ncs, i
     L.rho = o; o += pad2(L.C);
     L.act = o; o += pad2(L.C);
     L.w = o; o += pad2(T * nw);
-    L.zslot = o; o += 8;               // [2..7]: scalars handed from one wave of the instance to the other
+    L.zslot = o; o += 16;              // [2..7]: scalars handed from one wave of the instance to the other; [8..11]: cost pass results (two alternating pairs)
     L.lds_doubles_slim = o;            // the throughput variant keeps the Jacobians in HBM/L2
     L.fx = o; o += pad2(N * nx * nx);
     L.fu = o; o += pad2(N * nx * nu);
