@@ -77,9 +77,10 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=1,
                     help="solver handles used round-robin on separate HIP streams (1 = strictly sequential steps, "
                          "the headline setting; 2 lets the next batch fill SIMDs freed by early finishers)")
-    ap.add_argument("--generator", default="pcg64", choices=["pcg64", "splitmix64"],
-                    help="synthetic inputs: numpy PCG64 streams (the inputs of every earlier round's figures) or the library's own "
-                         "ilqr_synthetic_inputs (SURVEY 8(d): splitmix64 / Box-Muller — what a Julia or C host generates)")
+    ap.add_argument("--generator", default="splitmix64", choices=["pcg64", "splitmix64"],
+                    help="synthetic inputs: the library's own ilqr_synthetic_inputs (SURVEY 8(d) / BASELINE.md: splitmix64 / Box-Muller, "
+                         "seed 20240607 — what the cpu_baseline leg, a C host and bench/julia_ref.jl regenerate; the default since round 6) "
+                         "or numpy PCG64 streams (the inputs of the figures of rounds 1-5; reported as secondary.pcg64 by the default run)")
     ap.add_argument("--variant", default="auto", choices=["auto", "latency", "throughput", "packed", "mid", "packed1", "packed2"])
     ap.add_argument("--shared-step", action="store_true",
                     help="optional mode, NOT the reference's behaviour and not the headline: one Armijo step size per inner iteration "
@@ -121,7 +122,7 @@ def measure_traffic(args, kernel_prefix="void ilqr::solve_kernel"):
         with tempfile.TemporaryDirectory(prefix="ilqr_pmc_", dir="/tmp") as d:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config,
-                   "--batch", str(args.batch), "--steps", "2", "--variant", args.variant]
+                   "--batch", str(args.batch), "--steps", "2", "--variant", args.variant, "--generator", args.generator]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
@@ -328,6 +329,18 @@ def worker(args, solver_factory=None):
         except Exception:
             pass
     it_sum, it_max = float(st["iterations"].sum()), float(st["iterations"].max())
+    # when the instances of this rank's last timed launch finished (latency kernel: S_T_START / S_T_END, 100 MHz device counter)
+    finish = None
+    if not stub and not sharded:
+        try:
+            sc_ = sol.buffer("_scalars")
+            i0, i1 = pkg._ffi.lib().ilqr_scalar_slot(b"t_start"), pkg._ffi.lib().ilqr_scalar_slot(b"t_end")
+            if i0 >= 0 and i1 >= 0 and (sc_[:, i1] > 0).all():
+                t_end = (sc_[:, i1] - sc_[:, i0].min()) / 1e5
+                life = (sc_[:, i1] - sc_[:, i0]) / 1e5
+                finish = {"life_ms": life, "end_ms": t_end}
+        except Exception:
+            finish = None
 
     # ---- secondary figures of the same run (extra keys of the JSON line, never `value`): rank r on ITS OWN shard
     # [rB, (r+1)B) of one big synthetic batch (BASELINE config 4's situation: the step then lasts as long as the unluckiest
@@ -392,11 +405,32 @@ def worker(args, solver_factory=None):
             secondary["inflight_2"] = {"value": world * B * 2 * k2 / el, "unit": "trajectories/s", "ms_per_batch": 1e3 * el / (2 * k2),
                                        "note": "two solver handles per GPU on separate streams, alternating batches"}
             extra.close()
+        if rank == 0 and not stub and world == 1 and args.generator != "pcg64":
+            # continuity with rounds 1-5, whose figures were measured on numpy PCG64 inputs (same distribution, other draws: one
+            # instance of that batch needs 500 inner iterations where this batch's slowest needs 411)
+            _, _, x1p, ubp = pkg.workloads.make_inputs(args.config, B, generator="pcg64")
+            dp = (torch.from_numpy(x1p).to(dev), torch.from_numpy(ubp).to(dev))
+
+            def step_pcg():
+                sol.reset_()
+                sol.initialize_rollout_device_(dp[0].data_ptr(), dp[1].data_ptr())
+                sol.solve_(sync=False)
+            step_pcg()
+            sol.timing_reset()
+            el = timed(step_pcg, [sol])
+            stp = sol.stats()
+            secondary["pcg64"] = {"value": B * k2 / el, "unit": "trajectories/s", "ms_per_step": 1e3 * el / k2, "steps": k2,
+                                  "solve_kernel_ms": sol.timing()[0], "iterations_max": float(stp["iterations"].max()),
+                                  "inner_iterations_mean": float(stp["iterations"].mean()),
+                                  "note": "the same step on the numpy-PCG64 inputs every figure of rounds 1-5 was measured on"}
+            # back to the headline inputs: the last solve of this handle is what the statistics below describe
+            sol.reset_(); sol.initialize_rollout_device_(d_x1.data_ptr(), d_u.data_ptr()); sol.solve_(sync=True)
         if rank == 0 and not stub and world == 1:
             # the batch's slowest instance ALONE on the chip, same kernel: what of the step is one instance's serial latency and
             # what is the sharing of SIMDs with the other instances of the batch (tools/batch_latency.py has the whole curve)
             st_ = sol.stats()
-            worst = int(np.argmax(st_["iterations"]))
+            # the instance that finished LAST in the batch (its stamps), else the one with the most iterations
+            worst = int(np.argmax(finish["end_ms"])) if finish is not None else int(np.argmax(st_["iterations"]))
             lone = pkg.Solver(model=model, horizon=T, batch=1, device=gpu,
                               options=pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(args.config, {})))
             batch_kernel = sol.resolved_kernel_variant()         # "auto" on a batch of ONE would pick the latency kernel whatever the batch ran on
@@ -408,7 +442,9 @@ def worker(args, solver_factory=None):
                 lone_ms.append(lone.timing()[0])
             secondary["slowest_instance_alone"] = {"kernel_ms": min(lone_ms[1:]), "instance": worst, "iterations": int(lone.stats()["iterations"][0]),
                                                    "batch_iterations_max": int(st_["iterations"].max()),
-                                                   "kernel_variant": batch_kernel, "kernel_variant_of_the_batch": batch_kernel,
+                                                   "chosen_by": "last to finish in the batch (device time stamps)" if finish is not None else "most iterations",
+                                                   "lifetime_in_the_batch_ms": float(finish["life_ms"][worst]) if finish is not None else None,
+                                                   "kernel_variant": batch_kernel,
                                                    "note": "one launch of the same kernel with only the batch's slowest instance on the GPU: "
                                                            "the serial latency no batch size can go below; the step's kernel time minus this is "
                                                            "what sharing the SIMDs with the rest of the batch costs that instance"}
@@ -458,6 +494,14 @@ def worker(args, solver_factory=None):
     }
     if secondary:
         out["secondary"] = secondary
+    if finish is not None:
+        e_, l_ = finish["end_ms"], finish["life_ms"]
+        per_it = 1e3 * l_ / np.maximum(st["iterations"], 1)
+        out["solve_stats"]["finish_profile"] = {
+            "finish_ms_percentiles": {"p50": float(np.percentile(e_, 50)), "p90": float(np.percentile(e_, 90)), "p99": float(np.percentile(e_, 99)), "max": float(e_.max())},
+            "us_per_iteration_in_the_batch": {"p5": float(np.percentile(per_it, 5)), "p50": float(np.percentile(per_it, 50)), "p95": float(np.percentile(per_it, 95)), "max": float(per_it.max())},
+            "last_to_finish": {"instance": int(np.argmax(e_)), "iterations": int(st["iterations"][int(np.argmax(e_))])},
+            "note": "device time stamps of the last timed launch (tools/finish_times.py prints the whole profile and the wave placement)"}
     if ho_stats is not None:
         out["solve_stats"]["handover"] = {"marked_as_stragglers": ho_stats[1], "through_the_workgroups_queue": ho_stats[0]}
     if not stub:

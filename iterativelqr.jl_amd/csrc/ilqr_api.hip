@@ -145,7 +145,7 @@ ilqr::KArgs make_args(const ilqr_handle* h) {
     a.qv = h->qv; a.QL = h->QL;
     a.stage_param = 0.0; a.stage_flag = 0;
     a.handover_outer = 0; a.resume = 0; a.handover_live = 0; a.done_counter = h->done_counter;
-    a.pool = nullptr; a.pool_mark = 0; a.pool_lds = 0; a.pool_ctl = 0; a.pool_cu = 0; a.cu_slots = nullptr;
+    a.pool = nullptr; a.pool_mark = 0; a.pool_lds = 0; a.pool_ctl = 0; a.pool_cu = 0; a.cu_slots = nullptr; a.cu_expect = 0;
     return a;
 }
 
@@ -943,7 +943,7 @@ int ilqr_create(const ilqr_problem_desc* d, ilqr_handle** out) {
     if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->done_counter, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(hand-over counter)");
     if (vt->launch_solve_packed != nullptr && (e = hipMalloc((void**)&h->pool, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B + ilqr::POOL_CUS))) != hipSuccess) return bail(e, "hipMalloc(hand-over queue)");
     if ((e = hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
-    if (!ilqr::is_large_model(vt->nx, vt->nu) && (e = hipMalloc((void**)&h->cu_slots, sizeof(int) * 4 * ilqr::CU_SLOT_CUS)) != hipSuccess) return bail(e, "hipMalloc(role counters)");
+    if (!ilqr::is_large_model(vt->nx, vt->nu) && (e = hipMalloc((void**)&h->cu_slots, sizeof(int) * ilqr::CU_SLOT_INTS * ilqr::CU_SLOT_CUS)) != hipSuccess) return bail(e, "hipMalloc(role table)");
     if (h->pool && (e = hipMemsetAsync(h->pool, 0, sizeof(int) * (size_t)(ilqr::POOL_Q + h->B + ilqr::POOL_CUS), h->stream)) != hipSuccess) return bail(e, "hipMemsetAsync(hand-over queue)");
     *out = h;
     int rc = ilqr_reset(h);
@@ -1224,8 +1224,9 @@ int ilqr_solve(ilqr_handle* h) {
         // two-wave latency kernel: one critical wave per SIMD (KArgs::cu_slots; ILQR_ROLE_SLOTS=0 leaves the roles as launched: A/B runs)
         static const bool role_slots = !(std::getenv("ILQR_ROLE_SLOTS") && std::getenv("ILQR_ROLE_SLOTS")[0] == '0');
         if (h->cu_slots != nullptr && role_slots) {
-            HIP_TRY(hipMemsetAsync(h->cu_slots, 0, sizeof(int) * 4 * ilqr::CU_SLOT_CUS, h->stream));
-            a.cu_slots = h->cu_slots;
+            HIP_TRY(hipMemsetAsync(h->cu_slots, 0, sizeof(int) * ilqr::CU_SLOT_INTS * ilqr::CU_SLOT_CUS, h->stream));
+            const int cus = std::max(1, h->num_simds / 4);
+            a.cu_slots = h->cu_slots; a.cu_expect = std::min(4, (h->B + cus - 1) / cus);
         }
         if (h->vt->launch_solve(&a, h->lds_bytes, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve launch failed"));
     }

@@ -70,11 +70,13 @@ struct KArgs {
     int pool_mark, pool_lds, pool_ctl, pool_cu;
     // Latency kernel, which wave of an instance is its CRITICAL one (role 0: rollout, matrix chain): the hardware places the two waves
     // of a workgroup on two SIMDs of its own choosing, and on 3 % of the SIMDs of a full chip two critical waves end up together
-    // (tools/finish_times.py). cu_slots: 4 counters per CU (zeroed by the host before the launch; null = roles as launched) — a
-    // workgroup takes the SIMD of its first wave for role 0 if no other workgroup has, else that of its second wave (roles swapped).
+    // (tools/finish_times.py). cu_slots: CU_SLOT_INTS words per CU (zeroed by the host before the launch; null = roles as launched)
+    // — the workgroups of a CU write down which two SIMDs they sit on, wait (bounded) until cu_expect of them have, and all take
+    // the same assignment of critical waves to SIMDs: as many distinct SIMDs as the placement allows (pick_roles).
     int* cu_slots;
+    int cu_expect;         // workgroups the launch puts on a CU (<= 4)
 };
-enum { CU_SLOT_CUS = 8 * 8 * 2 * 16 };      // xcc x se x sh x cu of HW_REG_XCC_ID / HW_REG_HW_ID
+enum { CU_SLOT_CUS = 8 * 8 * 2 * 16, CU_SLOT_INTS = 8 };      // xcc x se x sh x cu of HW_REG_XCC_ID / HW_REG_HW_ID; [0] arrivals, [1..4] their SIMD pairs
 enum { TRACE_W = 8 };   // outer, inner, objective, gradient_norm, max_violation, step_size, status, rollouts
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -2001,6 +2003,45 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
 #ifndef ILQR_SPEC_RESUME
 #define ILQR_SPEC_RESUME 1          // ... and in the resume launch
 #endif
+// Which wave of this workgroup takes role 0 (KArgs::cu_slots): the workgroups of a CU publish the SIMDs (s0, s1) of their two waves,
+// wait until `expect` of them have (bounded: a launch that puts fewer on this CU decides on what is there), and evaluate the same
+// rule on the same table: of all assignments the one that puts critical waves on the most distinct SIMDs, then the fewest swaps,
+// then the lowest mask. Returns 1 if this workgroup's roles are swapped. (A greedy first-come choice through counters was the
+// first version: in a third of the launches the arrival order left one SIMD with two critical waves.)
+__device__ inline int pick_roles(int* c, int s0, int s1, int expect) {
+    const int k = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k >= 4) return 0;                                             // a later round of a long launch: as launched
+    __hip_atomic_store(c + 1 + k, 16 | s0 | (s1 << 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (expect > 4) expect = 4;
+    int e[4], n = 0;
+    for (int tries = 0; tries < 64; ++tries) {
+        n = 0;
+        for (int i = 0; i < 4; ++i) {
+            e[i] = __hip_atomic_load(c + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e[i] & 16) n = i + 1; 
+        }
+        bool all = n >= expect;
+        for (int i = 0; i < n; ++i) all = all && (e[i] & 16);
+        if (all) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (n <= k) n = k + 1;
+    e[k] = 16 | s0 | (s1 << 2);
+    int best = 0, best_score = -1;
+    for (int mask = 0; mask < (1 << n); ++mask) {
+        int used = 0, swaps = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!(e[i] & 16)) continue;
+            const int sw = (mask >> i) & 1;
+            used |= 1 << (sw ? (e[i] >> 2) & 3 : e[i] & 3);
+            swaps += sw;
+        }
+        const int score = 16 * __builtin_popcount(used) - swaps;
+        if (score > best_score) { best_score = score; best = mask; }
+    }
+    return (best >> k) & 1;
+}
+
 // one instance from its workspace block to the end of solve!: from the start, or (resumed) from where the packed kernel left it
 template <class M, bool RESUMED, int SPEC = 0>
 __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int b) {
@@ -2014,30 +2055,23 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
         obj_prev0 = sc[S_OBJ_PREV];
     }
     Inst<M> I;
-    int swap_roles = 0, cu_slot = -1;
+    int swap_roles = 0;
     unsigned hwid = 0, xcc = 0;
     constexpr bool TWO = !is_large<M>::value && waves_of<M>::value == 2;
     if constexpr (TWO) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         if (a.cu_slots != nullptr) {
-            // one critical wave per SIMD (KArgs::cu_slots): thread 0 picks the role-0 SIMD among the workgroup's two
+            // one critical wave per SIMD (KArgs::cu_slots)
             int* sm = reinterpret_cast<int*>(smem);
             if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = (int)((hwid >> 4) & 3u);
             __syncthreads();
             if (threadIdx.x == 0) {
                 const int cu = (int)(((xcc & 7u) << 8) | (((hwid >> 13) & 7u) << 5) | (((hwid >> 12) & 1u) << 4) | ((hwid >> 8) & 15u));
-                int* c = a.cu_slots + 4 * cu;
-                const int s0 = sm[0], s1 = sm[1];
-                int sw = 0, taken = 4 * cu + s0;
-                if (s0 != s1 && atomicAdd(c + s0, 1) != 0) {
-                    if (atomicAdd(c + s1, 1) == 0) { atomicSub(c + s0, 1); sw = 1; taken = 4 * cu + s1; }
-                    else atomicSub(c + s1, 1);
-                }
-                sm[2] = sw; sm[3] = taken;
+                sm[2] = pick_roles(a.cu_slots + CU_SLOT_INTS * cu, sm[0], sm[1], a.cu_expect);
             }
             __syncthreads();
-            swap_roles = sm[2]; cu_slot = sm[3];
+            swap_roles = sm[2];
             __syncthreads();                                          // read before inst_setup fills the LDS set
         }
     }
@@ -2071,7 +2105,6 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
         I.scal[S_TRACE_LEN] = (double)(I.trace_len < I.trace_cap ? I.trace_len : I.trace_cap);
         I.scal[S_RESUME] = 0.0;
         I.scal[S_T_END] = (double)wall_clock64();
-        if (cu_slot >= 0) atomicSub(a.cu_slots + cu_slot, 1);         // (launches of several rounds: the next workgroup on this CU sees it free)
     }
     inst_writeback<M>(I, a, smem, b);
     if constexpr (TWO) __builtin_amdgcn_s_setprio(0);                 // (the packed kernel's workers go on after this)

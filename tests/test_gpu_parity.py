@@ -1,9 +1,11 @@
-"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle (a restatement of the reference: "parity unpinned" by
+reference output).
 
-Tolerances (fp64): stage level 1e-11 relative (rounding only: FMA contraction,
-device libm, reduction order); whole solve |Δx|,|Δu| ≤ 1e-7, |ΔK| ≤ 5e-7·max|K| (10x the observed
-1.1e-8 / 2.4e-8, profiles/r01_final_parity.txt), control flow identical on ≥ 99 % of instances (observed 100 %)
-for instances whose control flow (iteration counts) matches the oracle's.
+Tolerances (fp64), as asserted below: stage level 2e-11 relative for the linearisation (rounding only: FMA contraction, device
+sincos, reduction order), 1e-8 for Riccati outputs after 50-100 recursion steps; whole solve on small models |Δx|, |Δu| ≤ 2e-8,
+|ΔK| ≤ 1e-7·max|K| with control flow identical on ≥ 99.9 % of the instances of a batch (observed at BASELINE sizes,
+profiles/r05_parity.txt: 100 %, 4e-9, 2e-8); large models (synth32, synth12) |Δx|, |Δu| ≤ 1e-11, |ΔK| ≤ 1e-11·max|K| on the literal
+BASELINE workload with control flow identical on every instance (observed 2e-15 / 1e-14 / 3e-15).
 """
 import os
 import sys
@@ -205,9 +207,9 @@ def test_resolve_is_deterministic(pkg):
 
 def test_car_full_config_batch_4096(pkg, oracle):
     """BASELINE configs[2]: car T=51 with the full constraint set, batch=4096 on one GPU."""
-    r = _whole_solve(pkg, oracle, "car", 4096, 0.99)
+    r = _whole_solve(pkg, oracle, "car", 4096, 0.999)
     st = r["st"]
-    assert (st["max_violation"] <= 5e-3).mean() > 0.99
+    assert (st["max_violation"] <= 5e-3).mean() > 0.999
 
 
 def test_acrobot_shard_of_65536_properties(pkg, oracle):
@@ -235,11 +237,20 @@ def test_acrobot_shard_of_65536_properties(pkg, oracle):
     idx = np.unique(np.r_[bad, np.arange(0, B, 257)])
     ref = oracle.solve_batch(model, T, x1[idx], ub[idx], nthreads=8)
     same = (st["iterations"][idx] == ref["stats"]["iterations"]) & (st["rollouts"][idx] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.99
+    assert same.mean() >= 0.995, same.mean()
     assert same[np.isin(idx, np.nonzero(diverged)[0])].all()          # NaN instances: identical control flow
     assert ((st["potrf_info"][idx] != 0) == (ref["stats"]["potrf_info"] != 0))[same].all()
     fin = same & ~diverged[idx]
-    assert np.abs(x[idx][fin] - ref["x"][fin]).max() < 1e-7
+    ex = np.abs(x[idx] - ref["x"]).reshape(len(idx), -1).max(1)
+    # 2e-8 like every whole-solve test — except on CHAOTIC instances (hundreds of iterations on the iteration cap), recognised by the
+    # criterion tools/all_shards.py prints: the oracle differs from ITSELF by more than a tenth of that when ū is perturbed by one
+    # part in 1e15 (profiles/r05_all_shards.txt: 3e-6 on the slowest instances of a shard)
+    loose = np.nonzero(fin & (ex > 2e-8))[0]
+    assert loose.size <= 0.02 * len(idx), loose.size
+    if loose.size:
+        pert = oracle.solve_batch(model, T, x1[idx[loose]], ub[idx[loose]] * (1.0 + 1e-15), nthreads=8)
+        own = np.abs(pert["x"] - ref["x"][loose]).reshape(loose.size, -1).max(1)
+        assert (ex[loose] <= 10.0 * own).all(), (ex[loose], own)
     sol.close()
     sub = slice(100, 164)
     small = pkg.Solver(model=model, horizon=T, batch=64, options=pkg.Options(verbose=0))
@@ -419,8 +430,8 @@ def test_synth32_whole_solve(pkg, oracle):
     rs = ref["stats"]
     same = (st["iterations"] == rs["iterations"]) & (st["outer_iterations"] == rs["outer_iterations"]) & (st["rollouts"] == rs["rollouts"])
     assert same.all(), (st["iterations"], rs["iterations"])
-    assert np.abs(x - ref["x"])[same].max() < 1e-7 and np.abs(u - ref["u"])[same].max() < 1e-7
-    assert (np.abs(K - ref["K"])[same].max() / np.abs(ref["K"]).max()) < 5e-7
+    dx_, du_, dK_ = np.abs(x - ref["x"]).max(), np.abs(u - ref["u"]).max(), np.abs(K - ref["K"]).max() / np.abs(ref["K"]).max()
+    assert dx_ <= 1e-11 and du_ <= 1e-11 and dK_ <= 1e-11, (dx_, du_, dK_)
     assert (np.abs(u[same]) <= 1.0 + 5e-3).all()          # the action box holds at the solution
     sol.close()
 
@@ -440,8 +451,9 @@ def test_synth32_shard_of_4096(pkg, oracle):
     idx = np.arange(0, B, 8)
     ref = oracle.solve_batch(model, T, x1[idx], ub[idx], nthreads=8)
     same = (st["iterations"][idx] == ref["stats"]["iterations"]) & (st["rollouts"][idx] == ref["stats"]["rollouts"])
-    assert same.mean() >= 0.99
-    assert np.abs(x[idx] - ref["x"])[same].max() < 1e-7
+    assert same.all(), same.mean()
+    dx_ = np.abs(x[idx] - ref["x"]).max()
+    assert dx_ <= 1e-11, dx_
     sol.close()
 
 
@@ -1637,9 +1649,9 @@ def test_synth32_literal_config5_shard_against_the_oracle(pkg, oracle):
     rs = ref["stats"]
     same = (st["iterations"] == rs["iterations"]) & (st["outer_iterations"] == rs["outer_iterations"]) \
         & (st["rollouts"] == rs["rollouts"]) & (st["status"] == rs["status"])
-    assert same.mean() >= 0.99, same.mean()
-    assert np.abs(x - ref["x"])[same].max() <= 1e-7 and np.abs(u - ref["u"])[same].max() <= 1e-7
-    assert np.abs(K - ref["K"])[same].max() <= 5e-7 * np.abs(ref["K"]).max()
+    assert same.all(), same.mean()
+    dx_, du_, dK_ = np.abs(x - ref["x"]).max(), np.abs(u - ref["u"]).max(), np.abs(K - ref["K"]).max() / np.abs(ref["K"]).max()
+    assert dx_ <= 1e-11 and du_ <= 1e-11 and dK_ <= 1e-11, (dx_, du_, dK_)          # observed 1.8e-15 / 1.0e-14 / 3.1e-15
     assert (st["potrf_info"] == 0).all() and (rs["potrf_info"] == 0).all()
     sol.close()
 

@@ -16,8 +16,12 @@ opts = pkg.Options(verbose=0, **pkg.workloads.CONFIG_OPTIONS.get(cfg, {}))
 s = pkg.Solver(model=model, horizon=T, batch=B, options=opts)
 s.set_kernel_variant_("latency")
 slot0, slot1 = pkg._ffi.lib().ilqr_scalar_slot(b"t_start"), pkg._ffi.lib().ilqr_scalar_slot(b"t_end")
-for rep in range(3):
+reps = []
+for rep in range(int(os.environ.get("FINISH_REPS", "3"))):
     s.reset_(); s.initialize_rollout_(x1, ub); s.timing_reset(); s.solve_(); ms = s.timing()[0]
+    sc = s.buffer("_scalars"); st_ = s.stats()
+    reps.append((ms, 1e-2 * ((sc[:, slot1] - sc[:, slot0]) / st_["iterations"]).max()))
+print("# per launch: kernel ms (slowest instance's us per iteration): " + "  ".join("%.2f (%.1f)" % r for r in reps))
 sc = s.buffer("_scalars"); st = s.stats()
 t0 = sc[:, slot0]; t1 = sc[:, slot1]
 start = (t0 - t0.min()) / 1e5; end = (t1 - t0.min()) / 1e5          # ms
