@@ -1204,7 +1204,15 @@ int ilqr_solve(ilqr_handle* h) {
         const int packs = (h->B + 3) / 4, cus = std::max(1, h->num_simds / 4), per_cu = (packs + cus - 1) / cus;
         a.stage_flag = (h->variant != 5 && per_cu <= 4) ? 2 : 0;
         a.stage_param = (double)per_cu;
+        {   // two-wave form: one solver wave per SIMD (KArgs::cu_slots; the one-wave form ignores it)
+            static const bool role_slots = !(std::getenv("ILQR_ROLE_SLOTS") && std::getenv("ILQR_ROLE_SLOTS")[0] == '0');
+            if (h->cu_slots != nullptr && role_slots && a.stage_flag == 2) {
+                HIP_TRY(hipMemsetAsync(h->cu_slots, 0, sizeof(int) * ilqr::CU_SLOT_INTS * ilqr::CU_SLOT_CUS, h->stream));
+                a.cu_slots = h->cu_slots; a.cu_expect = std::min(4, per_cu);
+            }
+        }
         if (h->vt->launch_solve_packed(&a, h->stream) != 0) return drop(fail(ILQR_ERR_HIP, "solve (packed variant) launch failed"));
+        a.cu_slots = nullptr; a.cu_expect = 0;
         a.stage_flag = 0; a.stage_param = 0.0; a.pool = nullptr; a.pool_mark = 0;
         if (ho > 0 || live > 0) {
             ilqr::KArgs r = a;
@@ -1396,7 +1404,7 @@ int ilqr_scalar_slot(const char* name) {
         {"delta_grad_product", ilqr::S_DELTA}, {"trace_len", ilqr::S_TRACE_LEN}, {"count", ilqr::S_COUNT},
         {"obj_prev", ilqr::S_OBJ_PREV}, {"inner_done", ilqr::S_INNER_DONE}, {"j_prev", ilqr::S_J_PREV}, {"inner_it", ilqr::S_INNER_IT},
         {"resume", ilqr::S_RESUME}, {"literal_backward_passes", ilqr::S_LITERAL_PASSES},
-        {"t_start", ilqr::S_T_START}, {"t_end", ilqr::S_T_END}, {"hw_id_wave0", ilqr::S_HW0}, {"hw_id_wave1", ilqr::S_HW1},
+        {"t_start", ilqr::S_T_START}, {"t_end", ilqr::S_T_END}, {"hw_id_wave0", ilqr::S_HW0}, {"hw_id_wave1", ilqr::S_HW1}, {"hw_id_wave2", ilqr::S_HW2}, {"hw_id_wave3", ilqr::S_HW3},
     };
     if (!name) return -1;
     for (auto& s_ : slots)

@@ -1608,10 +1608,13 @@ __device__ void rollout_small(Inst<M>& I, double alpha, bool with_delta, double&
     double xo[n];
     if (I.N > 0) fetch(A, 0);
     int t = 0;
-    for (; t + 1 < I.N; t += 2) {
+    // (a counted loop and an unconditional fetch of step t + 2: behind the last pair that is a read past K, u, x — inside the
+    // instance's LDS set, every one of these arrays is followed by others — whose values nobody uses; five scalar instructions
+    // per pair less than the guarded form)
+    for (int pairs = I.N >> 1; pairs > 0; --pairs, t += 2) {
         fetch(B, 1);
         step(A, t, 0, xt, xo);
-        if (t + 2 < I.N) fetch(A, 2);
+        fetch(A, 2);
         step(B, t + 1, 1, xo, xt);
         advance2();
     }
@@ -2077,6 +2080,12 @@ __device__ __forceinline__ void solve_instance(const KArgs& a, double* smem, int
     }
     inst_setup<M>(I, a, smem, b, swap_roles);
     if (I.lane == 0 && I.wave == 0) I.scal[S_T_START] = (double)wall_clock64();
+    if constexpr (is_large<M>::value && waves_of<M>::value == LARGE_WAVES) {
+        unsigned hw_, xc_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc_));
+        if (I.lane == 0) I.scal[S_HW0 + I.wave] = (double)hw_ + 4294967296.0 * (double)(xc_ & 15u);
+    }
     if constexpr (TWO) {
         if (I.lane == 0) I.scal[S_HW0 + I.wave] = (double)hwid + 4294967296.0 * (double)(xcc & 15u);
         // The SIMD's arbiter serves its OLDEST wave first: of two waves that share a SIMD the one dispatched later gets what the other

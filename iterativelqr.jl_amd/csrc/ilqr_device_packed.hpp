@@ -1199,8 +1199,31 @@ __global__ __launch_bounds__(128, 2) void solve_kernel_packed(KArgs a) {
     bool marked = false;
     if constexpr (TWO) {
         if (threadIdx.x < 8) ((volatile int*)(pk_lds_ + PkLds<M, true>::MBOX))[threadIdx.x] = 0;
-        __syncthreads();
-        if (threadIdx.x >= 64) { pk_helper<M>(a); return; }
+        // which of the two waves solves and which serves: one solver wave per SIMD (KArgs::cu_slots, pick_roles — the same geometry
+        // as the latency kernel: four two-wave workgroups per CU, and the SIMD's arbiter serves its oldest wave first)
+        __shared__ int role_sm[4];
+        int swap_roles = 0;
+        if (a.cu_slots != nullptr) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            if ((threadIdx.x & 63) == 0) role_sm[threadIdx.x >> 6] = (int)((hwid >> 4) & 3u);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int cu = (int)(((xcc & 7u) << 8) | (((hwid >> 13) & 7u) << 5) | (((hwid >> 12) & 1u) << 4) | ((hwid >> 8) & 15u));
+                role_sm[2] = pick_roles(a.cu_slots + CU_SLOT_INTS * cu, role_sm[0], role_sm[1], a.cu_expect);
+            }
+            __syncthreads();
+            swap_roles = role_sm[2];
+        } else __syncthreads();
+#ifndef ILQR_PK_HELPER_PRIO
+#define ILQR_PK_HELPER_PRIO 0
+#endif
+#ifndef ILQR_PK_SOLVER_PRIO
+#define ILQR_PK_SOLVER_PRIO 0
+#endif
+        if ((int)(threadIdx.x >> 6) != swap_roles) { __builtin_amdgcn_s_setprio(ILQR_PK_HELPER_PRIO); pk_helper<M>(a); return; }
+        __builtin_amdgcn_s_setprio(ILQR_PK_SOLVER_PRIO);
         packed_solve_body<M, true, false>(a, blockIdx.x, 0, resume, marked);
     } else {
         constexpr int PACK = (PkLds<M, false>::total + 1) & ~1;

@@ -34,8 +34,8 @@ enum {
     // the whole device), so that (S_T_END - min S_T_START) of a batch is its finishing-time profile (tools/finish_times.py)
     S_T_START = 27, S_T_END = 28,
     // ... and where its two waves ran: HW_REG_HW_ID (wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13]) + 2^32 x XCC_ID
-    S_HW0 = 29, S_HW1 = 30,
-    S_COUNT = 32
+    S_HW0 = 29, S_HW1 = 30, S_HW2 = 31, S_HW3 = 32,   // (large models: the four waves of the workgroup, by hardware wave index)
+    S_COUNT = 34
 };
 
 // Riccati hand-over between the two waves of a small-model instance: chunks of RING_STEPS timesteps, double-buffered

@@ -145,6 +145,7 @@ ILQR_HD void sincos_fast(double x, double& s, double& c) {
 struct TrigPair {
     double c[7], m, o;      // Horner coefficients, g = fma(r, m, o)
     double red[4];          // 2/pi and the three parts of pi/2 of the argument reduction (wave-uniform, but kept in VGPRs like the rest)
+    double huge;            // 2^30: arguments beyond it take the slow reduction (a pinned scalar pair: hipcc rebuilt it with two s_mov per step)
     int odd;                // 1 on cosine lanes
 };
 ILQR_HD TrigPair trig_pair_constants(bool odd) {
@@ -160,12 +161,17 @@ ILQR_HD TrigPair trig_pair_constants(bool odd) {
     t.o = odd ? 1.0 : 0.0;
     t.red[0] = 6.36619772367581382433e-01; t.red[1] = 1.5707963267948966e+00;
     t.red[2] = 6.123233995736766e-17; t.red[3] = -1.4973849048591698e-33;
+    t.huge = 1073741824.0;
     t.odd = odd ? 1 : 0;
     return t;
 }
 // kernel value of this lane (sine kernel on even, cosine kernel on odd lanes) and the quadrant of the argument
 ILQR_HD double trig_pair_own(double x, const TrigPair& t, int& quadrant) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fabs(x) < t.huge)) != 0, 0)) {
+#else
     if (ILQR_ANY_HUGE(x)) {
+#endif
 #pragma clang loop unroll(disable)
         for (int it = 0; it < 24 && !(fabs(x) < 1073741824.0) && x == x; ++it) {
             const double k = rint(x * 1.5915494309189535e-01);
@@ -236,6 +242,7 @@ __device__ __forceinline__ TrigPair make_trig_pair(int lane) {
     if constexpr (PIN_UNIFORM) {        // wave-uniform constants: opaque scalar-register pairs (pinned in VGPRs they cost the forward pass 32 registers and spills)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ILQR_OPAQUE_UNIFORM(t.red[i]);
+        ILQR_OPAQUE_UNIFORM(t.huge);
     }
     return t;
 }

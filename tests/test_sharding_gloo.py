@@ -85,7 +85,7 @@ def test_world_size_2_worker_solves_its_shard_and_the_union_is_the_whole_batch(t
     from ilqr_amd_loader import load_package
     from oracle import oracle as O
     pkg = load_package()
-    model, T, x1, ub = pkg.workloads.make_inputs(CONFIG, WORLD * B_PER_RANK)
+    model, T, x1, ub = pkg.workloads.make_inputs(CONFIG, WORLD * B_PER_RANK, generator="splitmix64")      # bench.py's default inputs
     parts = [np.load(tmp_path / ("rank%d.npz" % rk)) for rk in range(WORLD)]
     assert np.array_equal(np.concatenate([p["x1"] for p in parts]), x1) and np.array_equal(np.concatenate([p["ub"] for p in parts]), ub)
     whole = O.solve_batch(model, T, x1, ub, nthreads=2)
@@ -111,7 +111,7 @@ def test_same_instances_flag_puts_the_first_shard_on_every_rank(tmp_path):
     sys.path.insert(0, ROOT)
     from ilqr_amd_loader import load_package
     pkg = load_package()
-    model, T, x1, ub = pkg.workloads.make_inputs(CONFIG, B_PER_RANK)
+    model, T, x1, ub = pkg.workloads.make_inputs(CONFIG, B_PER_RANK, generator="splitmix64")
     for rk in range(WORLD):
         part = np.load(tmp_path / ("rank%d.npz" % rk))
         assert np.array_equal(part["x1"], x1) and np.array_equal(part["ub"], ub)
