@@ -178,6 +178,8 @@ int ilqr_run_stage_param(ilqr_handle* h, int32_t stage, double param, int32_t fl
  *   reduce(values, n, ctx): replace values[0..n) by their sum over all ranks, return 0 (an RCCL / MPI all-reduce in a host with
  *     several processes; NULL = one process: the identity). It is called the same number of times on every rank.
  *   steps / steps_cap / n_steps (optional): the accepted step size of every inner iteration (0 = line search failed), in order.
+ *     *n_steps is the number of inner iterations the solve took; min(*n_steps, steps_cap) entries of steps are written (a caller
+ *     that sized steps for fewer must not read beyond steps_cap).
  * With a batch of ONE instance the mode reproduces ilqr_solve exactly. Constrained solvers only. Synchronous. */
 typedef int (*ilqr_allreduce_sum_fn)(double* values, int32_t n, void* ctx);
 int ilqr_solve_shared_step(ilqr_handle* h, ilqr_allreduce_sum_fn reduce, void* ctx, double* steps, int32_t steps_cap, int32_t* n_steps);
@@ -408,7 +410,8 @@ int ilqr_compile_model_stages(const char* name, const ilqr_stage_kinds* kinds, c
                               char* registered_name, size_t name_len, char* library_path, size_t path_len);
 /* The selector table of a lowered problem, [T][n_selectors] (n_selectors <= num_parameter of the model): the handle keeps it and
  * writes it into the last n_selectors parameter columns of every instance, now and on every ilqr_set_parameters — which from
- * here on takes the USER's parameters only, w: [B][T][nw - n_selectors], as ilqr_get_dims reports them. n_selectors = 0 detaches. */
+ * here on takes the USER's parameters only, w: [B][T][nw - n_selectors], as ilqr_get_dims reports them. n_selectors = 0 detaches.
+ * The user's columns (the first nw - n_selectors of every timestep) keep what an earlier ilqr_set_parameters put there. */
 int ilqr_set_stage_selectors(ilqr_handle* h, const double* selectors, int32_t n_selectors);
 
 /* Synthetic inputs of the benchmark workloads, generated on the host by ONE function that every host language

@@ -520,6 +520,55 @@ static ModelStructure probe_model_structure(const ilqr_model_source* src, const 
 }
 
 // Dynamics / Cost / Constraint constructors for hosts without Python: C source of the reference's callables -> model module.
+// What the probe found, kept beside the modules under the PRE-probe hash (source, dimensions, ABI, kernel headers + flags) and the
+// probe hints: ilqr_compile_model[_rows,_stages] is called by every rank of a job and on every start of a host, and the probe —
+// a host compilation in a child process, a dlopen, 48 points x 9 callables — used to run every time although the module it
+// leads to was cached (advisor finding, round 5). Only a SUCCESSFUL probe is kept: where probing is impossible (no host
+// compiler, switched off) the answer is cheap and must not be served on a box where it would work.
+static ModelStructure probe_model_structure_cached(const ilqr_model_source* src, const std::string& dir, const std::string& tag, const ProbeHints& hints) {
+    if ((src->flags & ILQR_MODEL_DENSE_TABLES) || std::getenv("ILQR_NO_STRUCTURE_PROBE")) return probe_model_structure(src, dir, tag, hints);
+    unsigned long long hh = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(hints); ++i) { hh ^= ((const unsigned char*)&hints)[i]; hh *= 1099511628211ull; }
+    char hb[24];
+    std::snprintf(hb, sizeof(hb), "%08llx", hh & 0xffffffffull);
+    const std::string path = dir + "/probe_" + tag + "_" + hb + ".bin";
+    const int n = src->nx, m = src->nu;
+    static const char magic[8] = {'I', 'L', 'Q', 'R', 'P', 'R', 'B', '1'};
+    if (FILE* f = std::fopen(path.c_str(), "rb")) {
+        ModelStructure ms;
+        char mg[8];
+        int hd[8];
+        bool ok = std::fread(mg, 1, 8, f) == 8 && std::memcmp(mg, magic, 8) == 0 && std::fread(hd, sizeof(int), 8, f) == 8 &&
+                  hd[0] == n && hd[1] == m && hd[5] >= 0 && hd[6] >= 0 && hd[7] >= 0 && hd[5] <= n * n + n * m && hd[6] <= n * n + m * m + m * n && hd[7] <= 64;
+        if (ok) {
+            ms.nxx = hd[2]; ms.nuu = hd[3]; ms.nux = hd[4];
+            ms.fxc.resize((size_t)n * n); ms.fuc.resize((size_t)n * m); ms.jac_var.resize(hd[5]); ms.hess_idx.resize(hd[6]); ms.tile_start.resize(hd[7]);
+            ok = std::fread(ms.fxc.data(), 8, ms.fxc.size(), f) == ms.fxc.size() && std::fread(ms.fuc.data(), 8, ms.fuc.size(), f) == ms.fuc.size() &&
+                 std::fread(ms.jac_var.data(), sizeof(int), ms.jac_var.size(), f) == ms.jac_var.size() &&
+                 std::fread(ms.hess_idx.data(), sizeof(int), ms.hess_idx.size(), f) == ms.hess_idx.size() &&
+                 std::fread(ms.tile_start.data(), sizeof(int), ms.tile_start.size(), f) == ms.tile_start.size() &&
+                 ms.nxx + ms.nuu + ms.nux == (int)ms.hess_idx.size();
+        }
+        std::fclose(f);
+        if (ok) { ms.found = true; ms.note = "structure from " + path; return ms; }
+    }
+    ModelStructure ms = probe_model_structure(src, dir, tag, hints);
+    if (ms.found && (int)ms.fxc.size() == n * n && (int)ms.fuc.size() == n * m) {
+        const std::string tmp = path + "." + std::to_string((long)getpid());
+        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+            const int hd[8] = {n, m, ms.nxx, ms.nuu, ms.nux, (int)ms.jac_var.size(), (int)ms.hess_idx.size(), (int)ms.tile_start.size()};
+            bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(hd, sizeof(int), 8, f) == 8 &&
+                      std::fwrite(ms.fxc.data(), 8, ms.fxc.size(), f) == ms.fxc.size() && std::fwrite(ms.fuc.data(), 8, ms.fuc.size(), f) == ms.fuc.size() &&
+                      std::fwrite(ms.jac_var.data(), sizeof(int), ms.jac_var.size(), f) == ms.jac_var.size() &&
+                      std::fwrite(ms.hess_idx.data(), sizeof(int), ms.hess_idx.size(), f) == ms.hess_idx.size() &&
+                      std::fwrite(ms.tile_start.data(), sizeof(int), ms.tile_start.size(), f) == ms.tile_start.size();
+            ok = (std::fclose(f) == 0) && ok;
+            if (ok) std::rename(tmp.c_str(), path.c_str()); else std::remove(tmp.c_str());
+        }
+    }
+    return ms;
+}
+
 static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq_stage_words, const uint64_t* ineq_term_words,
                               char* registered_name, size_t name_len, char* library_path, size_t path_len, const ProbeHints& hints = ProbeHints());
 int ilqr_compile_model(const ilqr_model_source* src, char* registered_name, size_t name_len, char* library_path, size_t path_len) {
@@ -583,7 +632,7 @@ static int compile_model_impl(const ilqr_model_source* src, const uint64_t* ineq
     if (large) {
         char ptag[32];
         std::snprintf(ptag, sizeof(ptag), "%016llx", hsh);
-        ms = probe_model_structure(src, dir, ptag, hints);
+        ms = probe_model_structure_cached(src, dir, ptag, hints);
         mix(ms.found ? "probed" : "dense", 6);
         if (ms.found) {
             mix(ms.fxc.data(), ms.fxc.size() * 8); mix(ms.fuc.data(), ms.fuc.size() * 8);
@@ -1067,6 +1116,10 @@ int ilqr_initialize_states(ilqr_handle* h, const double* x) {
 static int write_parameters_with_selectors(ilqr_handle* h, const double* w_user) {
     const int T = h->L.T, nw = h->vt->nw, S = h->n_sel, nwu = nw - S;
     std::vector<double> full((size_t)h->B * T * nw, 0.0);
+    if (!w_user && nwu > 0) {        // selectors alone (ilqr_set_stage_selectors): the user's columns keep what they hold
+        const int rc = copy_out(h, find_buffer(h, "parameters"), full.data());
+        if (rc != ILQR_OK) return rc;
+    }
     for (int b = 0; b < h->B; ++b)
         for (int t = 0; t < T; ++t) {
             double* row = &full[((size_t)b * T + t) * nw];
@@ -1202,7 +1255,7 @@ int ilqr_solve(ilqr_handle* h) {
         // two waves per pack (a linearisation server beside the solver wave) while the batch leaves every SIMD at most two waves and
         // a CU's LDS holds the second chunk buffers: up to 4 workgroups per CU (variant 5 = one wave per pack, 6 = two where they fit)
         const int packs = (h->B + 3) / 4, cus = std::max(1, h->num_simds / 4), per_cu = (packs + cus - 1) / cus;
-        a.stage_flag = (h->variant != 5 && per_cu <= 4) ? 2 : 0;
+        a.stage_flag = (h->variant != 5 && packed2_fits(h->vt->packed2_lds_bytes, per_cu)) ? 2 : 0;
         a.stage_param = (double)per_cu;
         {   // two-wave form: one solver wave per SIMD (KArgs::cu_slots; the one-wave form ignores it)
             static const bool role_slots = !(std::getenv("ILQR_ROLE_SLOTS") && std::getenv("ILQR_ROLE_SLOTS")[0] == '0');
@@ -1470,7 +1523,7 @@ int ilqr_resolved_kernel_variant(ilqr_handle* h, int32_t* variant) {
     const bool slim = !packed && h->vt->launch_solve_slim != nullptr && (h->variant == 2 || (h->variant == 0 && h->B > h->num_simds));
     if (packed) {
         const int packs = (h->B + 3) / 4, cus = std::max(1, h->num_simds / 4), per_cu = (packs + cus - 1) / cus;
-        *variant = (h->variant != 5 && per_cu <= 4) ? 6 : 5;
+        *variant = (h->variant != 5 && packed2_fits(h->vt->packed2_lds_bytes, per_cu)) ? 6 : 5;      // the launcher's own rule (packed2_fits)
     } else if (slim) *variant = 2;
     else if (use_mid(h)) *variant = 4;
     else *variant = 1;

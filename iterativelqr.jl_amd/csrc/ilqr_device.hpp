@@ -2334,7 +2334,10 @@ __global__ __launch_bounds__(64) void init_rollout_large_kernel(KArgs a) {
 
 // Model module interface: what a compiled model (built-in or generated by
 // iterativelqr.jl_amd/codegen.py) registers with the library.
-#define ILQR_MODEL_ABI_VERSION 9   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
+// the packed kernel's two-wave form fits: its workgroups' LDS at per_cu workgroups per CU (one rule for the launcher and for
+// ilqr_solve / ilqr_resolved_kernel_variant on the host)
+inline bool packed2_fits(int lds2_bytes, int per_cu) { return lds2_bytes > 0 && per_cu >= 1 && per_cu <= 4 && (long long)per_cu * (lds2_bytes + 512) <= 160ll * 1024; }
+#define ILQR_MODEL_ABI_VERSION 10   /* bump whenever KArgs, Layout or this struct change: stale model modules are refused */
 extern "C" struct ilqr_model_vtable {
     int abi_version;     // ILQR_MODEL_ABI_VERSION the module was compiled against
     int kargs_bytes;     // sizeof(ilqr::KArgs) it was compiled against
@@ -2354,6 +2357,9 @@ extern "C" struct ilqr_model_vtable {
     // large models whose matrices are single 16x16 tiles (nx, nu <= 16), null otherwise: the one-wave-per-instance variant
     int (*launch_solve_mid)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);
     int (*launch_stage_mid)(const ilqr::KArgs* a, size_t lds_bytes, void* stream);
+    // LDS bytes of a workgroup of the packed kernel's two-wave form (0: no packed kernel): launch_solve_packed takes that form
+    // when KArgs::stage_flag == 2 and per_cu * (this + 512) <= 160 KiB — the host asks for it under the same condition
+    int packed2_lds_bytes;
 };
 
 namespace ilqr {
@@ -2412,7 +2418,7 @@ struct ModelModule {
         if constexpr (packed_ok<M>::value) {
             constexpr size_t lds2 = sizeof(double) * pk::PkLds<M, true>::total;
             const double per_cu = a->stage_param >= 1.0 ? a->stage_param : 1.0;
-            if (a->stage_flag == 2 && per_cu * (double)(lds2 + 512) <= 160.0 * 1024.0 && per_cu <= 4.0) {
+            if (a->stage_flag == 2 && packed2_fits((int)lds2, (int)per_cu)) {
                 KArgs b = *a;
                 b.stage_flag = 0; b.stage_param = 0.0;
                 hipLaunchKernelGGL((solve_kernel_packed<M, true>), dim3((a->B + 3) / 4), dim3(128), lds2, (hipStream_t)stream, b);
@@ -2431,6 +2437,15 @@ struct ModelModule {
                 } else b.pool = nullptr;
                 b.pool_ctl = (int)(lds / sizeof(double));
                 lds += ctl;
+                // marks, vacated CUs and waiting workers belong to launches whose workgroups are ALL resident (a waiting workgroup
+                // would hold the slots the next round needs): with fewer than that resident — long horizons, per() < 4 — nobody is
+                // marked and nobody waits (advisor finding, round 5: the host's test assumed four workgroups per CU)
+                {
+                    int dev = 0, cus = 0;
+                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+                    const size_t wgs = (size_t)(((a->B + 3) / 4 + 1) / 2);
+                    if (per(lds) * (size_t)cus < wgs) { b.pool_cu = 0; b.pool_mark = 0; }
+                }
                 if (lds > 64 * 1024 &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel_packed<M, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
@@ -2476,6 +2491,7 @@ struct ModelModule {
             return -1;
         }
     }
+    template <class MM = M> static constexpr int packed2_lds() { if constexpr (packed_ok<MM>::value) return (int)(sizeof(double) * pk::PkLds<MM, true>::total); else return 0; }
     template <class MM = M> static constexpr int jac_nvar() { if constexpr (is_large<MM>::value) return MM::JAC_NVAR; else return 0; }
     template <class MM = M> static constexpr int hess_nnz() { if constexpr (is_large<MM>::value) return MM::HESS_NXX + MM::HESS_NUU + MM::HESS_NUX; else return 0; }
     static const ilqr_model_vtable* vtable() {
@@ -2486,7 +2502,8 @@ struct ModelModule {
                                              is_large<M>::value ? nullptr : &launch_stage_slim,
                                              packed_ok<M>::value ? &launch_solve_packed : nullptr,
                                              jac_nvar(), hess_nnz(), is_large<M>::value ? &launch_mirror : nullptr,
-                                             mid_ok<M>::value ? &launch_solve_mid : nullptr, mid_ok<M>::value ? &launch_stage_mid : nullptr};
+                                             mid_ok<M>::value ? &launch_solve_mid : nullptr, mid_ok<M>::value ? &launch_stage_mid : nullptr,
+                                             packed2_lds<M>()};
         return &vt;
     }
 };

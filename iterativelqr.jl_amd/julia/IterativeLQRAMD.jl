@@ -365,7 +365,7 @@ function solve_shared_step!(s::Solver, reduce!::Union{Function,Nothing} = nothin
         GC.@preserve cfn check(ccall((:ilqr_solve_shared_step, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int32, Ref{Int32}),
                                      s.handle, cfn, C_NULL, steps, cap, n))
     end
-    return steps[1:n[]]
+    return steps[1:min(Int(n[]), cap)]      # n = inner iterations taken; at most `cap` entries were written
 end
 
 # 0 = auto, 1 = latency, 2 = throughput, 3 = packed (four instances per wave, no horizon limit)

@@ -387,6 +387,28 @@ def test_parameters_car_obs(pkg, oracle):
     sol.close()
 
 
+def test_stage_selectors_leave_the_users_parameter_columns_alone(pkg):
+    """ilqr_set_stage_selectors writes the LAST n_selectors parameter columns of every timestep; the user's columns (the first
+    nw - n_selectors) keep what ilqr_set_parameters put there before (advisor finding, round 5: they were zeroed). Then
+    ilqr_set_parameters takes the user's columns only and the selector column survives it."""
+    import ctypes as C
+    B = 4
+    model, T, x1, ub = pkg.workloads.make_inputs("car_obs", B)
+    w = pkg.workloads.make_parameters("car_obs", B)
+    sol = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0))
+    sol.set_parameters_(w)
+    sel = np.linspace(1.0, 2.0, T).reshape(T, 1)
+    L = pkg._ffi.lib()
+    pkg._ffi.check(L.ilqr_set_stage_selectors(sol._h, sel.ctypes.data_as(pkg._ffi.c_double_p), 1))
+    got = sol.buffer("parameters").reshape(B, T, 2)
+    assert np.array_equal(got[:, :, 0], w[:, :, 0]) and np.array_equal(got[:, :, 1], np.broadcast_to(sel[:, 0], (B, T)))
+    w1 = np.ascontiguousarray(3.0 + w[:, :, :1])
+    pkg._ffi.check(L.ilqr_set_parameters(sol._h, w1.ctypes.data_as(pkg._ffi.c_double_p)))
+    got = sol.buffer("parameters").reshape(B, T, 2)
+    assert np.array_equal(got[:, :, 0], w1[:, :, 0]) and np.array_equal(got[:, :, 1], np.broadcast_to(sel[:, 0], (B, T)))
+    sol.close()
+
+
 def test_user_defined_model_plugin_path(pkg, oracle):
     """The reference's user flow (examples/particle.jl:17-51): write f, ℓ, c as plain functions, build
     Dynamics/Cost/Constraint objects, hand lists of them to Solver. Here that goes through the code
