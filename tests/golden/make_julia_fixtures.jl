@@ -17,7 +17,10 @@
 # the output schema is the one of tests/golden/make_reference_fixtures.py.
 #
 # Models: the reference's own example problems (examples/particle.jl, test/car.jl, test/acrobot.jl; constants in
-# SURVEY.md Appendix B) and the synthetic nx = 32 model of SURVEY.md §8(d) C5, written against the package's constructors.
+# SURVEY.md Appendix B), the synthetic nx = 32 model of SURVEY.md §8(d) C5, and (round 6) the two problems of SURVEY §8 f3 —
+# car_tv (distinct objects per step) and ragged (distinct DIMENSIONS per step) — written against the package's constructors.
+# The f3 cases (ragged_T9, ragged_T41, car_tv_T21: whole solves, no stage snapshots) are read by
+# tests/test_oracle_ragged.py::test_oracle_against_reference_produced_f3_fixtures, which is skipped while no *_julia.npz exists.
 using IterativeLQR
 using LinearAlgebra
 
@@ -108,8 +111,52 @@ function synth32_problem(T)
     return dyn, costs, cons
 end
 
+# ---- SURVEY §8 f3: objects and DIMENSIONS that differ from step to step (README.md:26, src/dynamics.jl:5-7). Twins of
+# iterativelqr.jl_amd/models.py: car_tv / ragged, oracle/models.cpp "car_tv" / "ragged", reference_restatement.py: ragged_problem.
+function car_tv_problem(T)
+    fc = (x, u) -> [u[1] * cos(x[3]); u[1] * sin(x[3]); u[2]]
+    base_dyn, base_costs, base_cons = car_problem(T)
+    dyn_a = base_dyn[1]
+    dyn_b = Dynamics((x, u) -> x + 0.05 * fc(x, u), 3, 2)                   # explicit Euler, h = 0.05
+    cost_a = base_costs[1]
+    q = [5.0; 2.0; 0.5]; xg = [0.9; 1.1; 0.2]; r = [0.05; 0.02]
+    cost_b = Cost((x, u) -> sum(q[i] * (x[i] - xg[i])^2 for i = 1:3) + sum(r[j] * u[j]^2 for j = 1:2), 3, 2)
+    con_a = base_cons[1]
+    con_eq = Constraint((x, u) -> [u[2] - 0.3 * x[3] - 0.05], 3, 2)
+    dyn = [((t - 1) % 3 == 2 ? dyn_b : dyn_a) for t = 1:T-1]
+    costs = [[(2 * (t - 1) >= T - 1 ? cost_b : cost_a) for t = 1:T-1]..., base_costs[end]]
+    cons = [[((t - 1) % 4 == 0 ? con_a : ((t - 1) % 4 == 2 ? con_eq : Constraint())) for t = 1:T-1]..., base_cons[end]]
+    return dyn, costs, cons
+end
+
+const RAGGED_N = [3, 3, 4, 4, 2, 2, 3, 3]
+const RAGGED_M = [2, 1, 2, 1, 1, 2, 2, 1]
+function ragged_problem(T)
+    n_t = [RAGGED_N[(t - 1) % 8 + 1] for t = 1:T]
+    m_t = [RAGGED_M[(t - 1) % 8 + 1] for t = 1:T-1]
+    dcache = Dict{Tuple{Int,Int,Int},Any}(); ccache = Dict{Tuple{Int,Int},Any}()
+    function dynk(n0, m0, n1)
+        get!(dcache, (n0, m0, n1)) do
+            A = [(i == j ? 0.9 : 0.0) + 0.1 * cos(1.0 + (i - 1) + 2 * (j - 1) + n0) for i = 1:n1, j = 1:n0]
+            Bm = [0.3 * sin(2.0 + 3 * (i - 1) + (j - 1) + m0) for i = 1:n1, j = 1:m0]
+            Dynamics((x, u) -> [sum(A[i, j] * x[j] for j = 1:n0) + sum(Bm[i, j] * u[j] for j = 1:m0) + (i == 1 ? 0.1 * sin(x[1]) : 0.0)
+                                for i = 1:n1], n0, m0)
+        end
+    end
+    function costk(n0, m0)
+        get!(ccache, (n0, m0)) do
+            Cost((x, u) -> 0.5 * sum((1.0 + 0.1 * (i - 1)) * x[i] * x[i] for i = 1:n0) + 0.05 * sum(Float64(j) * u[j] * u[j] for j = 1:m0), n0, m0)
+        end
+    end
+    dyn = [dynk(n_t[t], m_t[t], n_t[t+1]) for t = 1:T-1]
+    nT = n_t[end]
+    costs = [[costk(n_t[t], m_t[t]) for t = 1:T-1]..., Cost((x, u) -> 5.0 * sum(x[i] * x[i] for i = 1:nT), nT, 0)]
+    cons = [[Constraint() for t = 1:T-1]..., Constraint((x, u) -> [x[1] - 0.2; x[2] + 0.1], nT, 0)]
+    return dyn, costs, cons
+end
+
 const PROBLEMS = Dict("particle" => particle_problem, "car" => car_problem, "car_goal" => T -> car_problem(T; goal_only = true),
-                      "acrobot" => acrobot_problem, "synth32" => synth32_problem)
+                      "acrobot" => acrobot_problem, "synth32" => synth32_problem, "car_tv" => car_tv_problem, "ragged" => ragged_problem)
 
 # ------------------------------------------------------------------------------------------------ recording
 mutable struct Recorder
@@ -126,6 +173,10 @@ mutable struct Recorder
 end
 const REC = Ref{Union{Nothing,Recorder}}(nothing)
 
+# per-step dimensions: vectors / matrices of a problem whose num_state, num_action vary are zero-padded to the largest (the layout
+# of the device template and of the oracle's getters); for uniform dimensions these are stackv / stackm
+padv(vs, n) = isempty(vs) ? zeros(0) : hcat([vcat(Float64.(v), zeros(n - length(v))) for v in vs]...)
+padm(ms, r, c) = isempty(ms) ? zeros(0) : cat([[Float64.(m) zeros(size(m, 1), c - size(m, 2)); zeros(r - size(m, 1), c)] for m in ms]...; dims = 3)
 stackm(ms) = isempty(ms) ? zeros(0) : cat([Float64.(m) for m in ms]...; dims = 3)      # (rows, cols, T)
 stackv(vs) = isempty(vs) ? zeros(0) : (all(isempty, vs) ? zeros(0) : hcat([Float64.(v) for v in vs]...))   # (n, T)
 catv(vs) = isempty(vs) ? zeros(0) : vcat([Float64.(v) for v in vs]...)
@@ -284,10 +335,12 @@ function generate(case)
         push!(points, (parse(Int, a), parse(Int, b)))
     end
     dyn, costs, cons = PROBLEMS[model](T)
-    n = dyn[1].num_state; m = dyn[1].num_action
-    x1 = vec(read_f64(joinpath(IN_DIR, case * ".x1.f64"), n))
+    # (dimensions may vary per step: the inputs on disk are padded to the largest, src/dynamics.jl:5-7)
+    ns = [[d.num_state for d in dyn]..., dyn[end].num_next_state]; ms_ = [d.num_action for d in dyn]
+    n = maximum(ns); m = maximum(ms_)
+    x1 = vec(read_f64(joinpath(IN_DIR, case * ".x1.f64"), n))[1:ns[1]]
     ub = read_f64(joinpath(IN_DIR, case * ".u.f64"), m, T - 1)              # row-major [T-1][m] on disk = (m, T-1) here
-    ubar = [ub[:, t] for t = 1:T-1]
+    ubar = [ub[1:ms_[t], t] for t = 1:T-1]
     xbar = rollout(dyn, x1, ubar)
     solver = Solver(dyn, costs, cons, options = Options{Float64}(verbose = false))
     initialize_controls!(solver, ubar)
@@ -308,18 +361,19 @@ function generate(case)
         haskey(renum, j) && (final["s$(renum[j])" * key[findfirst('_', key):end]] = val)
     end
     final["points"] = isempty(taken) ? zeros(0) : Float64.(hcat([[points[j+1][1], points[j+1][2]] for j in taken]...))   # (2, npoints)
-    final["x1"] = x1; final["ubar"] = stackv(ubar); final["xbar"] = stackv(xbar); final["horizon"] = [Float64(T)]
+    final["x1"] = vcat(x1, zeros(n - length(x1))); final["ubar"] = padv(ubar, m); final["xbar"] = padv(xbar, n); final["horizon"] = [Float64(T)]
+    final["state_dims"] = Float64.(ns); final["action_dims"] = Float64.(ms_)
     final["trace"] = isempty(r.trace) ? zeros(0) : hcat(r.trace...)                                       # (8, n_iter)
     xs, us = get_trajectory(solver)
-    final["x"] = stackv(xs); final["u"] = stackv(us)
+    final["x"] = padv(xs, n); final["u"] = padv(us, m)
     if model == "synth32" && T > 11
         sel = [0, 1, div(T, 2), T - 2]
         final["K_steps"] = Float64.(sel)
         final["K"] = stackm([solver.policy.K[t+1] for t in sel])
     else
-        final["K"] = stackm(solver.policy.K)
+        final["K"] = padm(solver.policy.K, m, n)
     end
-    final["k"] = stackv(solver.policy.k)
+    final["k"] = padv(solver.policy.k, m)
     d = solver.data
     # potrf_info: the reference ignores LAPACK's info (src/backward_pass.jl:69); a factorisation that failed would have thrown
     # from LAPACK.potrs! in Julia, so a solve that ends here had info == 0 throughout

@@ -92,3 +92,34 @@ def test_ragged_stages_match_the_independent_restatement(oracle):
         x, u = o.get_trajectory()
         for t in range(T):
             assert np.abs(x[t, :pr.state_dims[t]] - s.nominal_states[t]).max() < 1e-11
+
+
+@pytest.mark.parametrize("case", ["ragged_T9", "ragged_T41", "car_tv_T21"])
+def test_oracle_against_reference_produced_f3_fixtures(oracle, case, tmp_path):
+    """SURVEY §8 f3 on the route to a reference-produced pin: tests/golden/dump_fixture_inputs.py writes the inputs of three
+    whole solves with per-step objects / dimensions, tests/golden/make_julia_fixtures.jl (the REAL package; no Julia in this
+    image) solves them, julia_to_npz.py turns its output into ref_<case>_julia.npz. Always checked here: the dumped inputs are
+    what the Julia script's reader expects (padded to the largest dimensions) and the oracle solves them; compared with the
+    reference's own numbers when such a file exists, skipped (with the reason) while it does not."""
+    import dump_fixture_inputs as D
+    model, T, x1, ub, n_t, m_t = D.f3_inputs(case)
+    ind = D.main(str(tmp_path / "julia_in"))
+    assert open(os.path.join(ind, case + ".txt")).read().split("\n")[:3] == [model, str(T), "0"]
+    assert np.array_equal(np.fromfile(os.path.join(ind, case + ".x1.f64")), x1)
+    assert np.array_equal(np.fromfile(os.path.join(ind, case + ".u.f64")).reshape(T - 1, -1), ub)
+    pr = oracle.Problem(model, T)
+    assert pr.state_dims == n_t and pr.action_dims == m_t and (pr.nx, pr.nu) == (max(n_t), max(m_t))
+    got = oracle.solve_batch(model, T, x1[None], ub[None], nthreads=1)
+    st = got["stats"]
+    assert np.isfinite(got["x"]).all() and st["max_violation"][0] <= 5e-3 and st["iterations"][0] > 0
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_%s_julia.npz" % case)
+    if not os.path.exists(path):
+        pytest.skip("no reference-produced fixture for %s: the image has no Julia (tests/golden/make_julia_fixtures.jl is the route)" % case)
+    d = np.load(path)
+    iters, outer, rollouts = int(d["stats"][4]), int(d["stats"][5]), int(d["stats"][7])
+    assert (st["iterations"][0], st["outer_iterations"][0], st["rollouts"][0]) == (iters, outer, rollouts)
+    assert np.abs(got["x"][0] - d["x"]).max() <= 1e-8 and np.abs(got["u"][0] - d["u"]).max() <= 1e-8
+    K = np.asarray(d["K"])                                   # [t][m][n] padded
+    Kmax = max(1.0, np.abs(K).max())
+    assert np.abs(got["K"][0].transpose(0, 2, 1) - K).max() <= 1e-6 * Kmax
+    assert abs(st["objective"][0] - d["stats"][0]) <= 1e-8 * max(1.0, abs(d["stats"][0]))
