@@ -3,7 +3,9 @@
 # replaced by a measured reference number by anyone who has Julia. NOT run in this build's containers
 # (no Julia there); nothing in tests/, smoke() or bench.py depends on it.
 #
-#   python tools/dump_inputs.py acrobot 1024 /tmp/acrobot_inputs
+#   python tools/dump_inputs.py acrobot 1024 /tmp/acrobot_inputs        # bench.py's default inputs: ilqr_synthetic_inputs (SURVEY 8(d))
+#   (or without Python: ccall((:ilqr_synthetic_inputs, "libilqr_hip.so"), Cint, (Cstring, Int32, UInt64, Int64, Int32, Ptr{Float64}, Ptr{Float64}),
+#    "acrobot", 101, 20240607, 0, 1024, x1, ubar) fills the same two arrays — no device needed)
 #   julia -t auto bench/julia_ref.jl /tmp/acrobot_inputs [n_instances]
 #
 # Prints one JSON line: trajectories/s over the sampled instances (one Solver per thread, instances split

@@ -421,8 +421,9 @@ int ilqr_set_stage_selectors(ilqr_handle* h, const double* selectors, int32_t n_
  *   model: "particle" (u = 0.1 z, examples/particle.jl:30), "acrobot" (u = z, test/acrobot.jl:86-88), "car" / "car_goal" / "car_obs"
  *   (instance 0: test/car.jl:24-29 exactly; b >= 1: u scaled by 1 + 0.5 U(-1,1)_b, (x, y) of x1 jittered by 0.05 z), "synth32"
  *   (x1 = 0.5 z, u = 0), "synth12" (x1 = 0.5 z, u = 0.1 z). x1: [B][nx], ubar: [B][T-1][nu] of that model. No device needed.
- * (The Python bench draws from numpy's PCG64 by default, as in earlier rounds; `bench.py --generator splitmix64` and
- * workloads.make_inputs(generator = "splitmix64") use this function.) */
+ * (bench.py measures on this function's output since round 6 — `--generator pcg64` brings back the numpy PCG64 streams the figures of
+ * rounds 1-5 were measured on; workloads.make_inputs(generator = "splitmix64") calls it; bench/julia_ref.jl reads its output
+ * through tools/dump_inputs.py or `ccall`s it.) */
 int ilqr_synthetic_inputs(const char* model, int32_t horizon, uint64_t seed, int64_t first_instance, int32_t batch, double* x1, double* ubar);
 
 /* Test hook: evaluates one of the device-side scalar routines of csrc/ilqr_math.hpp on cuda device 0 — "recip_fast",
