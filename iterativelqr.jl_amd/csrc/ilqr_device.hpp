@@ -32,6 +32,7 @@
 #include "../../include/ilqr_hip.h"
 #include "ilqr_layout.hpp"
 #include "ilqr_math.hpp"
+#include "ilqr_ric_schedule.hpp"
 
 namespace ilqr {
 
@@ -2014,7 +2015,7 @@ __device__ __forceinline__ void inst_writeback(Inst<M>& I, const KArgs& a, doubl
 __device__ inline int pick_roles(int* c, int s0, int s1, int expect) {
     const int k = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k >= 4) return 0;                                             // a later round of a long launch: as launched
-    __hip_atomic_store(c + 1 + k, 16 | s0 | (s1 << 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + 1 + k, role_entry(s0, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (expect > 4) expect = 4;
     int e[4], n = 0;
     for (int tries = 0; tries < 64; ++tries) {
@@ -2029,20 +2030,8 @@ __device__ inline int pick_roles(int* c, int s0, int s1, int expect) {
         __builtin_amdgcn_s_sleep(8);
     }
     if (n <= k) n = k + 1;
-    e[k] = 16 | s0 | (s1 << 2);
-    int best = 0, best_score = -1;
-    for (int mask = 0; mask < (1 << n); ++mask) {
-        int used = 0, swaps = 0;
-        for (int i = 0; i < n; ++i) {
-            if (!(e[i] & 16)) continue;
-            const int sw = (mask >> i) & 1;
-            used |= 1 << (sw ? (e[i] >> 2) & 3 : e[i] & 3);
-            swaps += sw;
-        }
-        const int score = 16 * __builtin_popcount(used) - swaps;
-        if (score > best_score) { best_score = score; best = mask; }
-    }
-    return (best >> k) & 1;
+    e[k] = role_entry(s0, s1);
+    return (role_mask(e, n) >> k) & 1;                                // (the rule: ilqr_ric_schedule.hpp, checked on the host)
 }
 
 // one instance from its workspace block to the end of solve!: from the start, or (resumed) from where the packed kernel left it

@@ -55,4 +55,28 @@ struct RicSchedule {
     static_assert(NQ <= 16, "tile index fits five bits (TN <= 4)");
 };
 
+// ---- which wave of each workgroup of a CU is its critical one (ilqr_device.hpp: pick_roles). Plain constexpr C++
+// like the schedule above, so that the rule is checked on the host (tests/test_ric_schedule.py). Entry i of a CU's table:
+// bit 4 = present, bits 0-1 the SIMD of the workgroup's first wave, bits 2-3 that of its second. Bit i of the result = workgroup i
+// swaps its roles (its SECOND wave is the critical one). Of all assignments: the most distinct SIMDs under critical waves, then the
+// fewest swaps, then the lowest mask — one answer for every workgroup that evaluates it on the same table.
+constexpr int role_entry(int s0, int s1) { return 16 | (s0 & 3) | ((s1 & 3) << 2); }
+constexpr int role_mask(const int* e, int n) {
+    int best = 0, best_score = -1;
+    for (int mask = 0; mask < (1 << n); ++mask) {
+        int used = 0, swaps = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!(e[i] & 16)) continue;
+            const int sw = (mask >> i) & 1;
+            used |= 1 << (sw ? (e[i] >> 2) & 3 : e[i] & 3);
+            swaps += sw;
+        }
+        int covered = 0;
+        for (int b = 0; b < 4; ++b) covered += (used >> b) & 1;
+        const int score = 16 * covered - swaps;
+        if (score > best_score) { best_score = score; best = mask; }
+    }
+    return best;
+}
+
 }  // namespace ilqr

@@ -70,7 +70,52 @@ static void check() {
     std::printf("TN=%d: %d T, %d Qxx, %d P tiles, %d + 1 Qux/Quu; window C tiles per wave %d %d %d\n", TN, NQ, NQ, NQ, TN, per_wave_c[1], per_wave_c[2], per_wave_c[3]);
 }
 
+// ---- the role rule of DESIGN.md §3.0 (role_mask): on every placement of up to four two-wave workgroups on a CU's four SIMDs the
+// chosen assignment covers as many distinct SIMDs as ANY assignment can, with as few swaps as that allows, and every workgroup
+// (whatever its own index) reads the same answer off the same table; the two placements seen on MI355X come out as expected.
+static int covered_by(const int* e, int n, int mask) {
+    int used = 0;
+    for (int i = 0; i < n; ++i) used |= 1 << (((mask >> i) & 1) ? (e[i] >> 2) & 3 : e[i] & 3);
+    int c = 0;
+    for (int b = 0; b < 4; ++b) c += (used >> b) & 1;
+    return c;
+}
+static void check_roles() {
+    int cases = 0;
+    for (int n = 1; n <= 4; ++n) {
+        int total = 1;
+        for (int i = 0; i < n; ++i) total *= 12;                       // ordered pairs of distinct SIMDs per workgroup
+        for (int code = 0; code < total; ++code) {
+            int e[4], c = code;
+            for (int i = 0; i < n; ++i) {
+                const int pr = c % 12; c /= 12;
+                const int s0 = pr / 3, o = pr % 3, s1 = o >= s0 ? o + 1 : o;
+                e[i] = role_entry(s0, s1);
+            }
+            const int m = role_mask(e, n);
+            int best_cov = 0, best_swaps = 99;
+            for (int mask = 0; mask < (1 << n); ++mask) {
+                const int cov = covered_by(e, n, mask), sw = __builtin_popcount(mask);
+                if (cov > best_cov || (cov == best_cov && sw < best_swaps)) { best_cov = cov; best_swaps = sw; }
+            }
+            if (covered_by(e, n, m) != best_cov || __builtin_popcount(m) != best_swaps) fail(0, "role_mask is not optimal", n, code);
+            ++cases;
+        }
+    }
+    // the ordinary CU of a full chip: (2,1) (3,0) (0,2) (1,3) — nobody swaps; the one in sixteen with two first waves on SIMD 0:
+    // (0,2) (2,1) (1,3) (0,3) — the last workgroup swaps
+    const int normal[4] = {role_entry(2, 1), role_entry(3, 0), role_entry(0, 2), role_entry(1, 3)};
+    const int odd[4] = {role_entry(0, 2), role_entry(2, 1), role_entry(1, 3), role_entry(0, 3)};
+    if (role_mask(normal, 4) != 0) fail(0, "ordinary placement: no swap expected");
+    if (role_mask(odd, 4) != 8) fail(0, "two critical waves on SIMD 0: the fourth workgroup swaps", role_mask(odd, 4));
+    // entries that have not arrived are ignored
+    const int partial[4] = {role_entry(0, 2), 0, role_entry(0, 3), 0};
+    if (role_mask(partial, 3) != 1) fail(0, "absent entries (one swap covers both SIMDs: the lowest such mask)", role_mask(partial, 3));
+    std::printf("roles: %d placements checked\n", cases);
+}
+
 int main() {
     check<1>(); check<2>(); check<3>(); check<4>();
+    check_roles();
     return 0;
 }
