@@ -216,7 +216,10 @@ int ilqr_enable_action_value_buffers(ilqr_handle* h);
  * "trace_len" (rows the last solve wrote to the trace), "count" (length of "_scalars"); shared-step mode: "obj_prev",
  * "inner_done", "j_prev", "inner_it"; "resume" (hand-over bookkeeping, 0 after a solve);
  * "literal_backward_passes" (two-wave latency kernel, models with one action: backward passes of the last solve that met a
- * non-positive pivot and were repeated in LAPACK's literal arithmetic — 0 on healthy instances). -1 if unknown. */
+ * non-positive pivot and were repeated in LAPACK's literal arithmetic — 0 on healthy instances); "t_start", "t_end" (when the
+ * instance's workgroup started / finished its solve in the latency or large-model kernel: ticks of the device's 100 MHz
+ * real-time counter) and "hw_id_wave0" … "hw_id_wave3" (where its waves ran: HW_REG_HW_ID + 2^32 * XCC_ID) — what
+ * tools/finish_times.py reads. -1 if unknown. */
 int ilqr_scalar_slot(const char* name);
 
 /* Kernel variant of ilqr_solve. Large models (nx > 4 or nu > 4): 0 = auto, 1 = four waves per instance (two instances per CU),
