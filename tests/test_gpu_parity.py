@@ -2009,3 +2009,62 @@ def test_one_wave_variant_of_the_large_path_equals_the_four_wave_kernel(pkg, ora
     with pytest.raises(pkg._ffi.IlqrError):
         big.set_kernel_variant_("mid")
     big.close()
+
+
+def _placement(pkg, sol):
+    """(SIMD of the critical wave, SIMD of wave 1) per instance from the stamps the latency kernel leaves in the scalar block"""
+    L = pkg._ffi.lib()
+    sc = sol.buffer("_scalars")
+    def where(v):
+        v = int(v)
+        return (v >> 32, (v >> 13) & 7, (v >> 12) & 1, (v >> 8) & 15, (v >> 4) & 3)
+    h0, h1 = L.ilqr_scalar_slot(b"hw_id_wave0"), L.ilqr_scalar_slot(b"hw_id_wave1")
+    return [(where(sc[b, h0]), where(sc[b, h1])) for b in range(sc.shape[0])], sc
+
+
+def test_a_full_chip_launch_puts_one_critical_wave_on_every_simd(pkg):
+    """the workgroups of a CU agree on their critical waves (pick_roles). On a chip whose SIMDs the batch fills exactly
+    (4 workgroups of two waves per CU) no SIMD may host two critical waves — as launched, 3 % of them do, and the instances on those
+    run 1.4 x slower than the rest; the time stamps must be set. A property of scheduling, not of results: asked of two of five
+    launches (a workgroup that arrives late decides alone; observed: every launch)."""
+    from collections import Counter
+    L = pkg._ffi.lib()
+    model, T, x1, ub = pkg.workloads.make_inputs("acrobot51", 1024)
+    sol = pkg.Solver(model=model, horizon=T, batch=1024, options=pkg.Options(verbose=0, max_iterations=6, max_dual_updates=2))
+    assert sol.resolved_kernel_variant() == "latency"
+    good = 0
+    for rep in range(5):
+        sol.reset_(); sol.initialize_rollout_(x1, ub); sol.solve_()
+        W, sc = _placement(pkg, sol)
+        t0, t1 = sc[:, L.ilqr_scalar_slot(b"t_start")], sc[:, L.ilqr_scalar_slot(b"t_end")]
+        assert (t1 > t0).all() and (t0 > 0).all()
+        crit = Counter(w[0] for w in W)
+        simds = set(w[0] for w in W) | set(w[1] for w in W)
+        if len(simds) < 1024:
+            pytest.skip("the device has fewer than 1024 SIMDs: the batch does not fill it exactly")
+        assert all(w[0] != w[1] for w in W)
+        good += max(crit.values()) == 1
+    assert good >= 2, good
+    sol.close()
+
+
+def test_roles_change_no_result(pkg, tmp_path):
+    """Which wave of an instance is the critical one is decided per launch from where the hardware put them; the two
+    waves run the same code on the same data either way. ILQR_ROLE_SLOTS=0 (roles as launched) must give the same bits — in a
+    process of its own, the library reads the variable once."""
+    import subprocess
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); from ilqr_amd_loader import load_package; pkg = load_package();"
+            "h = hashlib.sha256();\n"
+            "for cfg, B, var in (('acrobot51', 300, 'latency'), ('car', 1100, 'packed2')):\n"
+            "    model, T, x1, ub = pkg.workloads.make_inputs(cfg, B); s = pkg.Solver(model=model, horizon=T, batch=B, options=pkg.Options(verbose=0));"
+            " s.set_kernel_variant_(var); s.initialize_rollout_(x1, ub); s.solve_();\n"
+            "    for a in s.get_trajectory() + s.get_policy() + (s.stats()['iterations'], s.stats()['objective'], s.buffer('constraint_dual')): h.update(np.ascontiguousarray(a).tobytes())\n"
+            "    s.close()\n"
+            "print(h.hexdigest())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, ILQR_ROLE_SLOTS=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        out[flag] = r.stdout.decode().split()[-1]
+    assert out["1"] == out["0"]
